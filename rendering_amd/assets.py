@@ -1,0 +1,193 @@
+"""Deterministic synthetic assets for the scene fixtures under scenes/.
+
+Several of the reference's own assets are missing blobs (dragon.obj, shotgun_*.bmp, input/skybox1/ --
+SURVEY.md 0.2), so every mesh / texture / skybox the five BASELINE configs need is generated here from
+closed-form formulas (no RNG) and written under scenes/assets/ (git-ignored, re-creatable).
+
+File formats are the ones the reference loaders accept: OBJ with `v`, `vn`, `vt`, `f a//a` / `f a/t/n`
+(objects.cpp:177-381) and 24-bpp BMP with a 54-byte header, bottom-up rows, no row padding
+(util.cpp:78-113).
+"""
+import hashlib
+import os
+import struct
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASSETS = os.path.join(ROOT, "scenes", "assets")
+
+
+def _write_atomic(path, data: bytes):
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(data)
+    os.replace(tmp, path)
+
+
+def bumpy_sphere_obj(nu, nv):
+    """Bumpy UV sphere of 2*nu*(nv-1) triangles (nu=500, nv=251 -> 250 000)."""
+    u = 2.0 * np.pi * np.arange(nu) / nu
+    v = np.linspace(0.002, np.pi - 0.002, nv)
+    U, V = np.meshgrid(u, v)  # [nv, nu], row j = latitude
+
+    def pos(U, V):
+        R = 1.0 + 0.08 * np.sin(9 * U) * np.sin(7 * V) + 0.03 * np.cos(23 * U + 5 * V)
+        return np.stack([R * np.sin(V) * np.cos(U), R * np.cos(V), R * np.sin(V) * np.sin(U)], -1)
+
+    P = pos(U, V)
+    h = 1e-4
+    dU = pos(U + h, V) - pos(U - h, V)
+    dV = pos(U, V + h) - pos(U, V - h)
+    N = np.cross(dU, dV)
+    flip = np.sum(N * P, -1) < 0
+    N[flip] = -N[flip]
+    N /= np.linalg.norm(N, axis=-1, keepdims=True)
+    lines = ["# bumpy sphere nu=%d nv=%d (generated)" % (nu, nv)]
+    lines += ["v %.6f %.6f %.6f" % tuple(p) for p in P.reshape(-1, 3)]
+    lines += ["vn %.6f %.6f %.6f" % tuple(n) for n in N.reshape(-1, 3)]
+    j, i = np.meshgrid(np.arange(nv - 1), np.arange(nu), indexing="ij")
+    a = j * nu + i + 1
+    b = j * nu + (i + 1) % nu + 1
+    c = (j + 1) * nu + (i + 1) % nu + 1
+    d = (j + 1) * nu + i + 1
+    quads = np.stack([a, b, c, d], -1).reshape(-1, 4)
+    for a, b, c, d in quads:
+        lines.append("f %d//%d %d//%d %d//%d" % (a, a, b, b, c, c))
+        lines.append("f %d//%d %d//%d %d//%d" % (a, a, c, c, d, d))
+    return ("\n".join(lines) + "\n").encode()
+
+
+def torus_obj(nu=32, nv=24, R=1.0, r=0.35):
+    """Textured torus, 2*nu*nv triangles, faces `v/vt/vn`, uv in [0,1] (cfg4 stand-in for shotgun.obj)."""
+    lines = ["# torus nu=%d nv=%d (generated)" % (nu, nv)]
+    for j in range(nv + 1):
+        for i in range(nu + 1):
+            a = 2 * np.pi * i / nu
+            b = 2 * np.pi * j / nv
+            x = (R + r * np.cos(b)) * np.cos(a)
+            y = r * np.sin(b)
+            z = (R + r * np.cos(b)) * np.sin(a)
+            lines.append("v %.6f %.6f %.6f" % (x, y, z))
+    for j in range(nv + 1):
+        for i in range(nu + 1):
+            a = 2 * np.pi * i / nu
+            b = 2 * np.pi * j / nv
+            lines.append("vn %.6f %.6f %.6f" % (np.cos(b) * np.cos(a), np.sin(b), np.cos(b) * np.sin(a)))
+    for j in range(nv + 1):
+        for i in range(nu + 1):
+            lines.append("vt %.6f %.6f" % (i / nu, j / nv))
+    w = nu + 1
+    for j in range(nv):
+        for i in range(nu):
+            a = j * w + i + 1
+            b = j * w + i + 2
+            c = (j + 1) * w + i + 2
+            d = (j + 1) * w + i + 1
+            # outward-facing winding for the reference's det > 0 front-face convention
+            lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d" % (a, a, a, c, c, c, b, b, b))
+            lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d" % (a, a, a, d, d, d, c, c, c))
+    return ("\n".join(lines) + "\n").encode()
+
+
+def quad_poly_obj():
+    """Tiny OBJ exercising `f a b c d` (no slashes) fan triangulation and a flat axis (objects.cpp:317-319,339-346)."""
+    return (b"# unit quad, y flat\nv -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nf 1 4 3 2\n")
+
+
+def bmp24(rgb):
+    """rgb: uint8 [H, W, 3], row 0 = TOP of the picture.  Standard bottom-up 24-bpp BMP, W % 4 == 0."""
+    h, w, _ = rgb.shape
+    assert w % 4 == 0
+    body = np.ascontiguousarray(rgb[::-1, :, ::-1]).tobytes()  # bottom-up, BGR
+    hdr = b"BM" + struct.pack("<IHHI", 54 + len(body), 0, 0, 54)
+    hdr += struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, len(body), 2835, 2835, 0, 0)
+    assert len(hdr) == 54
+    return hdr + body
+
+
+def _grid(n):
+    y, x = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    return x.astype(np.int64), y.astype(np.int64)
+
+
+def skybox_face(k, n=512):
+    x, y = _grid(n)
+    base = np.array([[60, 90, 200], [200, 120, 60], [70, 180, 90], [180, 70, 170], [120, 190, 230], [90, 80, 60]])[k]
+    chk = (((x // 32) + (y // 32)) % 2) * 40
+    r = (base[0] + chk + (x * 37 + y * 11) % 29) % 256
+    g = (base[1] + chk + (x * 13 + y * 41) % 31) % 256
+    b = (base[2] + (x + y) // 8 + (x * 7 + y * 5) % 23) % 256
+    return np.stack([r, g, b], -1).astype(np.uint8)
+
+
+def diffuse_map(n=1024):
+    x, y = _grid(n)
+    chk = (((x // 64) + (y // 64)) % 2) * 90
+    r = (80 + chk + (x * 3) % 61) % 256
+    g = (60 + chk // 2 + (y * 5) % 67) % 256
+    b = (120 + (x + 2 * y) % 97) % 256
+    return np.stack([r, g, b], -1).astype(np.uint8)
+
+
+def normal_map(n=1024):
+    x, y = _grid(n)
+    fx = np.sin(x * (2 * np.pi / 64.0)) * 0.35
+    fy = np.cos(y * (2 * np.pi / 48.0)) * 0.35
+    nz = np.sqrt(np.maximum(0.0, 1.0 - fx * fx - fy * fy))
+    r = np.clip(np.round((fx * 0.5 + 0.5) * 255), 0, 255)
+    g = np.clip(np.round((fy * 0.5 + 0.5) * 255), 0, 255)
+    b = np.clip(np.round(nz * 255), 0, 255)
+    return np.stack([r, g, b], -1).astype(np.uint8)
+
+
+def specular_map(n=1024):
+    x, y = _grid(n)
+    s = (40 + ((x // 16) * 7 + (y // 16) * 13) % 200) % 256
+    return np.stack([s, (s + 20) % 256, (s + 50) % 256], -1).astype(np.uint8)
+
+
+# name -> generator
+_GENERATORS = {
+    "bumpy_250k.obj": lambda: bumpy_sphere_obj(500, 251),
+    "bumpy_25k.obj": lambda: bumpy_sphere_obj(160, 81),
+    "bumpy_4k.obj": lambda: bumpy_sphere_obj(64, 33),
+    "torus_1536.obj": lambda: torus_obj(32, 24),
+    "quad.obj": quad_poly_obj,
+    "diffuse_1024.bmp": lambda: bmp24(diffuse_map(1024)),
+    "normal_1024.bmp": lambda: bmp24(normal_map(1024)),
+    "specular_1024.bmp": lambda: bmp24(specular_map(1024)),
+    "diffuse_256.bmp": lambda: bmp24(diffuse_map(256)),
+    "normal_256.bmp": lambda: bmp24(normal_map(256)),
+    "specular_256.bmp": lambda: bmp24(specular_map(256)),
+}
+for _k, _nm in enumerate(["left", "front", "right", "back", "top", "bottom"]):
+    _GENERATORS["sky_%s.bmp" % _nm] = (lambda k=_k: bmp24(skybox_face(k, 512)))
+
+
+def ensure(names=None):
+    """Create the named assets (default: all but the 18 MB 250k mesh) if missing.  Returns {name: path}."""
+    os.makedirs(ASSETS, exist_ok=True)
+    if names is None:
+        names = [n for n in _GENERATORS if n != "bumpy_250k.obj"]
+    out = {}
+    for n in names:
+        p = os.path.join(ASSETS, n)
+        if not os.path.exists(p):
+            _write_atomic(p, _GENERATORS[n]())
+        out[n] = p
+    return out
+
+
+def md5(name):
+    with open(os.path.join(ASSETS, name), "rb") as f:
+        return hashlib.md5(f.read()).hexdigest()
+
+
+if __name__ == "__main__":
+    import sys
+    names = sys.argv[1:] or None
+    if names == ["all"]:
+        names = list(_GENERATORS)
+    for n, p in ensure(names).items():
+        print(n, md5(n), os.path.getsize(p))
