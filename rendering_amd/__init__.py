@@ -1,0 +1,262 @@
+"""rendering_amd -- MI355X (gfx950) implementation of the holoskii/Rendering per-pixel ray-trace hot path.
+
+Python is plumbing only: this module binds (ctypes)
+  * librtx_hip.so          -- the C ABI of include/rtx.h: HIP kernels + one-time scene upload
+  * librendering_host.so   -- the C++17 host side (Scene/Options/Object API, .scene/OBJ/BMP loaders, BVH build)
+and moves device pointers of torch tensors across that boundary (torch is used for device memory, streams and
+torch.distributed only).  There is NO CPU fallback: without the compiled libraries `load()` raises, and
+without a GPU every render call fails loudly with the HIP error.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_RTX = os.path.join(HERE, "librtx_hip.so")
+LIB_HOST = os.path.join(HERE, "librendering_host.so")
+
+__all__ = ["load", "Scene", "RtxError", "device_count", "math_probe", "exported_symbols"]
+
+
+class RtxError(RuntimeError):
+    pass
+
+
+class Counters(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64)]
+
+
+_rtx = None
+_host = None
+
+# every entry point declared in include/rtx.h
+RTX_SYMBOLS = [
+    "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_set_view",
+    "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_quantize_bgr8", "rtx_render_frame_host",
+    "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
+    "rtx_cast_rays",
+]
+
+
+def load():
+    """Loads the native libraries (raises RtxError when they have not been built: run ./build.sh)."""
+    global _rtx, _host
+    if _rtx is not None:
+        return _rtx, _host
+    for p in (LIB_RTX, LIB_HOST):
+        if not os.path.exists(p):
+            raise RtxError("native library %s is missing -- build it with ./build.sh (hipcc, gfx950); "
+                           "there is no CPU fallback" % p)
+    try:
+        # let torch's bundled HIP runtime (same SONAME libamdhip64.so.7) win if torch is going to be used
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    rtx = C.CDLL(LIB_RTX, mode=C.RTLD_GLOBAL)
+    host = C.CDLL(LIB_HOST, mode=C.RTLD_GLOBAL)
+    rtx.rtx_last_error.restype = C.c_char_p
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+    rtx.rtx_device_count.argtypes = [C.POINTER(C.c_int)]
+    rtx.rtx_render_pass1.argtypes = [vp, u32, u32, vp, vp]
+    rtx.rtx_sobel.argtypes = [vp, vp, u32, u32, vp, vp]
+    rtx.rtx_render_ssaa.argtypes = [vp, vp, u32, u32, vp, vp]
+    rtx.rtx_quantize_bgr8.argtypes = [vp, vp, vp, vp]
+    rtx.rtx_render_frame_host.argtypes = [vp, i32, vp]
+    rtx.rtx_counters_enable.argtypes = [vp, i32]
+    rtx.rtx_counters_reset.argtypes = [vp]
+    rtx.rtx_counters_read.argtypes = [vp, C.POINTER(Counters)]
+    rtx.rtx_last_kernel_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
+    rtx.rtx_math_probe.argtypes = [i32, i32, u32, vp, vp, vp]
+    rtx.rtx_cast_rays.argtypes = [vp, u32, vp, vp, vp]
+    host.rah_scene_load.restype = vp
+    host.rah_scene_load.argtypes = [C.c_char_p, C.c_char_p, i32, i32]
+    host.rah_scene_free.argtypes = [vp]
+    host.rah_scene_dims.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
+    host.rah_scene_resize.argtypes = [vp, i32, i32]
+    host.rah_scene_set_device.argtypes = [vp, i32]
+    host.rah_set_flag.argtypes = [vp, C.c_char_p, i32]
+    host.rah_flatten.restype = vp
+    host.rah_flatten.argtypes = [vp]
+    host.rah_flat_desc.restype = vp
+    host.rah_flat_desc.argtypes = [vp]
+    host.rah_flat_free.argtypes = [vp]
+    host.rah_bvh_counts.argtypes = [vp, i32, vp]
+    host.rah_scene_gpu.restype = vp
+    host.rah_scene_gpu.argtypes = [vp]
+    host.rah_render_host.argtypes = [vp, vp, i32]
+    host.rah_save_bmp.argtypes = [vp, vp, C.c_char_p]
+    host.rah_bvh_dump.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    host.rah_tris.argtypes = [vp, i32, vp]
+    host.rah_camera.argtypes = [vp, vp, vp, vp, vp]
+    _rtx, _host = rtx, host
+    return rtx, host
+
+
+def exported_symbols():
+    """(declared, missing) C-ABI symbols of librtx_hip.so -- used by the CPU-side load test."""
+    rtx, _ = load()
+    missing = [s for s in RTX_SYMBOLS if not hasattr(rtx, s)]
+    return list(RTX_SYMBOLS), missing
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RtxError("%s failed (%d): %s" % (what, rc, _rtx.rtx_last_error().decode(errors="replace")))
+
+
+def device_count():
+    rtx, _ = load()
+    n = C.c_int(0)
+    _check(rtx.rtx_device_count(C.byref(n)), "rtx_device_count")
+    return n.value
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def math_probe(op, x, y=None, device=0):
+    """Evaluates the device math the parity contract depends on (see rtx_math_probe in include/rtx.h)."""
+    rtx, _ = load()
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros_like(x)
+    yp = None
+    if y is not None:
+        y = np.ascontiguousarray(np.broadcast_to(np.asarray(y, np.float32), x.shape))
+        yp = _np_ptr(y)
+    _check(rtx.rtx_math_probe(device, op, x.size, _np_ptr(x), yp, _np_ptr(out)), "rtx_math_probe")
+    return out
+
+
+class Scene:
+    """Host Scene (loaded by the C++ loader) + its uploaded GPU twin.
+
+    Mirrors the reference's Scene surface for the hot path: render() = launchWorkers + launchSSAA
+    (scene.cpp:595-606).  `width`/`height` > 0 override the scene file's resolution.
+    """
+
+    def __init__(self, scene_path, width=-1, height=-1, device=0, cwd=ROOT):
+        self.rtx, self.host = load()
+        self.h = C.c_void_p(self.host.rah_scene_load(cwd.encode(), scene_path.encode(), width, height))
+        if not self.h:
+            raise RtxError("could not load scene %s" % scene_path)
+        self.device = device
+        self.host.rah_scene_set_device(self.h, device)
+        self._dims()
+        self._gpu = None
+
+    def _dims(self):
+        w, h, no, nl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.host.rah_scene_dims(self.h, C.byref(w), C.byref(h), C.byref(no), C.byref(nl))
+        self.width, self.height, self.n_objects, self.n_lights = w.value, h.value, no.value, nl.value
+
+    def close(self):
+        if self.h:
+            self.host.rah_scene_free(self.h)
+            self.h = None
+            self._gpu = None
+
+    def resize(self, width, height):
+        self.host.rah_scene_resize(self.h, width, height)
+        self._dims()
+
+    def set_flag(self, name, value):
+        self.host.rah_set_flag(self.h, name.encode(), int(value))
+
+    # ---- host-side structures (no GPU needed) -------------------------------------------------
+    def camera(self):
+        scale, aspect = C.c_float(), C.c_float()
+        m = np.zeros(16, np.float32)
+        pos = np.zeros(3, np.float32)
+        self.host.rah_camera(self.h, C.byref(scale), C.byref(aspect), _np_ptr(m), _np_ptr(pos))
+        return np.float32(scale.value), np.float32(aspect.value), m, pos
+
+    def bvh(self, obj_idx):
+        cnt = np.zeros(5, np.int64)
+        if self.host.rah_bvh_counts(self.h, obj_idx, _np_ptr(cnt)) != 0:
+            return None
+        nn, nl, nr, md, nt = [int(x) for x in cnt]
+        d = dict(bounds=np.zeros((nn, 6), np.float32), skip=np.zeros(nn, np.int32),
+                 leaf_begin=np.zeros(nn, np.int32), leaf_count=np.zeros(nn, np.int32),
+                 refs=np.zeros(nr, np.uint32))
+        self.host.rah_bvh_dump(self.h, obj_idx, _np_ptr(d["bounds"]), _np_ptr(d["skip"]), _np_ptr(d["leaf_begin"]),
+                               _np_ptr(d["leaf_count"]), _np_ptr(d["refs"]))
+        tris = np.zeros((nt, 30), np.float32)
+        self.host.rah_tris(self.h, obj_idx, _np_ptr(tris))
+        d.update(tris=tris, n_nodes=nn, n_leaves=nl, n_refs=nr, max_depth=md, n_tris=nt)
+        return d
+
+    # ---- GPU ------------------------------------------------------------------------------------
+    def gpu(self):
+        """rtx_scene* of the uploaded scene (flatten + upload on first use; re-applies the view after resize)."""
+        self._gpu = C.c_void_p(self.host.rah_scene_gpu(self.h))
+        return self._gpu
+
+    @staticmethod
+    def _stream_ptr(stream):
+        if stream is None:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            except Exception:
+                pass
+            return None
+        return C.c_void_p(getattr(stream, "cuda_stream", stream))
+
+    def render_pass1(self, fb, rows=None, stream=None):
+        """Scene::launchWorkers on rows [r0,r1) into the device tensor fb (H,W,3 float32, pre-zeroed)."""
+        r0, r1 = rows if rows is not None else (0, self.height)
+        _check(self.rtx.rtx_render_pass1(self.gpu(), r0, r1, C.c_void_p(fb.data_ptr()), self._stream_ptr(stream)),
+               "rtx_render_pass1")
+
+    def sobel(self, fb, mask, rows=None, stream=None):
+        r0, r1 = rows if rows is not None else (0, self.height)
+        _check(self.rtx.rtx_sobel(self.gpu(), C.c_void_p(fb.data_ptr()), r0, r1, C.c_void_p(mask.data_ptr()),
+                                  self._stream_ptr(stream)), "rtx_sobel")
+
+    def render_ssaa(self, mask, fb, rows=None, stream=None):
+        r0, r1 = rows if rows is not None else (0, self.height)
+        _check(self.rtx.rtx_render_ssaa(self.gpu(), C.c_void_p(mask.data_ptr()), r0, r1, C.c_void_p(fb.data_ptr()),
+                                        self._stream_ptr(stream)), "rtx_render_ssaa")
+
+    def quantize(self, fb, out, stream=None):
+        _check(self.rtx.rtx_quantize_bgr8(self.gpu(), C.c_void_p(fb.data_ptr()), C.c_void_p(out.data_ptr()),
+                                          self._stream_ptr(stream)), "rtx_quantize_bgr8")
+
+    def render_host(self, ssaa=True):
+        """Whole frame into a numpy array through the host-buffer convenience entry (PCIe-inclusive)."""
+        fb = np.zeros((self.height, self.width, 3), np.float32)
+        _check(self.rtx.rtx_render_frame_host(self.gpu(), int(bool(ssaa)), _np_ptr(fb)), "rtx_render_frame_host")
+        return fb
+
+    def cast_rays(self, rays):
+        """Render::trace + Render::castRay(depth 0) for n probe rays (n x 6 host array) -> (hits n x 8, colours n x 3)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        hits = np.zeros((n, 8), np.float32)
+        col = np.zeros((n, 3), np.float32)
+        _check(self.rtx.rtx_cast_rays(self.gpu(), n, _np_ptr(rays), _np_ptr(hits), _np_ptr(col)), "rtx_cast_rays")
+        return hits, col
+
+    def counters_enable(self, on=True):
+        _check(self.rtx.rtx_counters_enable(self.gpu(), int(on)), "rtx_counters_enable")
+
+    def counters_reset(self):
+        _check(self.rtx.rtx_counters_reset(self.gpu()), "rtx_counters_reset")
+
+    def counters(self):
+        c = Counters()
+        _check(self.rtx.rtx_counters_read(self.gpu(), C.byref(c)), "rtx_counters_read")
+        return np.array([c.rays, c.box_tests, c.tri_tests], np.int64)
+
+    def last_kernel_ms(self, which=0):
+        ms = C.c_float(0)
+        _check(self.rtx.rtx_last_kernel_ms(self.gpu(), which, C.byref(ms)), "rtx_last_kernel_ms")
+        return ms.value
+
+    def save_bmp(self, fb, name_no_ext):
+        fb = np.ascontiguousarray(fb, np.float32)
+        return self.host.rah_save_bmp(self.h, _np_ptr(fb), name_no_ext.encode())

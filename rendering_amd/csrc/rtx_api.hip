@@ -1,0 +1,472 @@
+// C-ABI implementation (include/rtx.h): one-time flatten+upload of the scene into HBM and the launches of
+// the gfx950 kernels in rtx_kernels.hip.  No CPU fallback exists: without a HIP device every entry point
+// fails with RTX_ERR_NO_DEVICE / RTX_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "rtx_device.h"
+
+using namespace rtxd;
+
+// single translation unit: the kernels are compiled together with their launch code
+#include "rtx_kernels.hip"
+
+namespace {
+
+thread_local std::string gErr;
+
+int fail(int code, const std::string& msg) { gErr = msg; return code; }
+
+#define HIPCHK(expr)                                                                                         \
+	do {                                                                                                     \
+		hipError_t e_ = (expr);                                                                              \
+		if (e_ != hipSuccess)                                                                                \
+			return fail(RTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+	} while (0)
+
+struct DevBuf {
+	void* p = nullptr;
+	~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+template <typename T> int upload(std::vector<void*>& owned, const T* src, size_t count, const T** out)
+{
+	*out = nullptr;
+	if (!src || count == 0) return RTX_OK;
+	void* d = nullptr;
+	HIPCHK(hipMalloc(&d, count * sizeof(T)));
+	owned.push_back(d);
+	HIPCHK(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));
+	*out = (const T*)d;
+	return RTX_OK;
+}
+
+} // namespace
+
+struct rtx_scene {
+	int device = 0;
+	int numCUs = 0;
+	std::vector<void*> owned;     // device allocations freed on destroy
+	Params params;                // template of the kernel argument block
+	bool stats = false;
+	// lazily sized work buffers
+	float* frames = nullptr; size_t framesBytes = 0;
+	uint32_t* list = nullptr; size_t listCount = 0;
+	uint32_t* work = nullptr;     // [0] pass-1 queue head, [1] ssaa queue head, [2] ssaa list length
+	unsigned long long* counters = nullptr;
+	int blocksPass1 = 0, blocksSsaa = 0;
+	hipEvent_t ev[3][2];
+	bool evValid[3] = { false, false, false };
+};
+
+namespace {
+
+int setView(rtx_scene* s, const rtx_view* v)
+{
+	if (v->width < 2 || v->height < 2) return fail(RTX_ERR_ARG, "view: width/height must be >= 2");
+	View& d = s->params.view;
+	d.width = v->width; d.height = v->height; d.bias = v->bias; d.maxDepth = v->max_ray_depth;
+	memcpy(d.bg, v->background, 12);
+	d.flags = v->flags;
+	memcpy(d.camPos, v->cam_pos, 12);
+	memcpy(d.camM, v->cam_matrix, 64);
+	d.scale = v->scale; d.aspect = v->aspect;
+	if ((d.flags & RTX_FLAG_SKYBOX) && !s->params.sky[0]) return fail(RTX_ERR_ARG, "view: skybox flag without skybox faces");
+	if (d.maxDepth < 0) d.maxDepth = -1;
+	return RTX_OK;
+}
+
+int ensureWork(rtx_scene* s)
+{
+	HIPCHK(hipSetDevice(s->device));
+	if (!s->work) {
+		HIPCHK(hipMalloc((void**)&s->work, 16 * sizeof(uint32_t)));
+		HIPCHK(hipMemset(s->work, 0, 16 * sizeof(uint32_t)));
+		HIPCHK(hipMalloc((void**)&s->counters, 3 * sizeof(unsigned long long)));
+		HIPCHK(hipMemset(s->counters, 0, 3 * sizeof(unsigned long long)));
+		for (int i = 0; i < 3; i++) { HIPCHK(hipEventCreate(&s->ev[i][0])); HIPCHK(hipEventCreate(&s->ev[i][1])); }
+		int b = 0;
+		HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxPass1Kernel<false>, 256, 0));
+		if (b < 1) b = 1;
+		s->blocksPass1 = b * s->numCUs;
+		HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxSsaaKernel<false>, 256, 0));
+		if (b < 1) b = 1;
+		s->blocksSsaa = b * s->numCUs;
+	}
+	const int blocks = s->blocksPass1 > s->blocksSsaa ? s->blocksPass1 : s->blocksSsaa;
+	const uint32_t totalLanes = (uint32_t)blocks * 256u;
+	const int slots = s->params.view.maxDepth + 2;
+	const size_t need = (size_t)(slots < 1 ? 1 : slots) * kFrameFields * sizeof(float) * totalLanes;
+	if (need > s->framesBytes) {
+		if (s->frames) HIPCHK(hipFree(s->frames));
+		s->frames = nullptr; s->framesBytes = 0;
+		HIPCHK(hipMalloc((void**)&s->frames, need));
+		s->framesBytes = need;
+	}
+	s->params.frames = s->frames;
+	s->params.totalLanes = totalLanes;
+	s->params.workCounter = s->work;
+	s->params.counters = s->counters;
+	return RTX_OK;
+}
+
+int ensureList(rtx_scene* s)
+{
+	const size_t need = (size_t)s->params.view.width * s->params.view.height;
+	if (need > s->listCount) {
+		if (s->list) HIPCHK(hipFree(s->list));
+		s->list = nullptr; s->listCount = 0;
+		HIPCHK(hipMalloc((void**)&s->list, need * sizeof(uint32_t)));
+		s->listCount = need;
+	}
+	return RTX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rtx_last_error(void) { return gErr.c_str(); }
+
+int rtx_device_count(int* count)
+{
+	if (!count) return fail(RTX_ERR_ARG, "count is NULL");
+	*count = 0;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess) return fail(RTX_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+	*count = n;
+	return RTX_OK;
+}
+
+int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
+{
+	if (!desc || !out) return fail(RTX_ERR_ARG, "desc/out is NULL");
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RTX_ERR_NO_DEVICE, "no HIP device visible");
+	if (device < 0 || device >= n) return fail(RTX_ERR_ARG, "device index out of range");
+	HIPCHK(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, device));
+
+	rtx_scene* s = new rtx_scene;
+	s->device = device;
+	s->numCUs = prop.multiProcessorCount;
+	memset(&s->params, 0, sizeof(Params));
+	auto bail = [&](int code) { rtx_scene_destroy(s); return code; };
+
+	// meshes: nodes -> 32-byte records, leaf references -> 64-byte (v0, e1, e2, tri) lines
+	std::vector<Mesh> meshes(desc->n_meshes);
+	for (uint32_t mi = 0; mi < desc->n_meshes; mi++) {
+		const rtx_mesh& m = desc->meshes[mi];
+		if (!m.node_bounds || !m.node_skip || !m.leaf_begin || !m.leaf_count || (m.n_refs && !m.refs) || (m.n_tris && (!m.tri_pos || !m.tri_nrm || !m.tri_uv)))
+			return bail(fail(RTX_ERR_ARG, "mesh arrays missing"));
+		if (m.normal_map && !m.tri_tb) return bail(fail(RTX_ERR_ARG, "normal map without tangents"));
+		std::vector<Node> nodes(m.n_nodes);
+		for (uint32_t i = 0; i < m.n_nodes; i++) {
+			Node& nd = nodes[i];
+			memcpy(nd.lo, m.node_bounds + (size_t)i * 6, 12);
+			memcpy(nd.hi, m.node_bounds + (size_t)i * 6 + 3, 12);
+			if (m.leaf_count[i] < 0) {
+				if (m.node_skip[i] <= (int32_t)i + 1 || m.node_skip[i] > (int32_t)m.n_nodes) return bail(fail(RTX_ERR_ARG, "bad skip index"));
+				nd.link = m.node_skip[i]; nd.first = 0;
+			}
+			else {
+				if ((uint32_t)m.leaf_begin[i] + (uint32_t)m.leaf_count[i] > m.n_refs) return bail(fail(RTX_ERR_ARG, "leaf range out of bounds"));
+				nd.link = ~m.leaf_count[i]; nd.first = m.leaf_begin[i];
+			}
+		}
+		std::vector<LeafTri> leaf(m.n_refs);
+		for (uint32_t r = 0; r < m.n_refs; r++) {
+			const uint32_t t = m.refs[r];
+			if (t >= m.n_tris) return bail(fail(RTX_ERR_ARG, "leaf reference out of range"));
+			const float* p = m.tri_pos + (size_t)t * 9;
+			LeafTri& lt = leaf[r];
+			memset(&lt, 0, sizeof(lt));
+			for (int k = 0; k < 3; k++) {
+				lt.v0[k] = p[k];
+				lt.e1[k] = p[3 + k] - p[k];      // v0v1 = v1 - v0 (objects.cpp:70)
+				lt.e2[k] = p[6 + k] - p[k];      // v0v2 = v2 - v0 (objects.cpp:71)
+			}
+			lt.tri = t;
+		}
+		Mesh& dm = meshes[mi];
+		memset(&dm, 0, sizeof(dm));
+		int rc;
+		if ((rc = upload(s->owned, nodes.data(), nodes.size(), &dm.nodes))) return bail(rc);
+		if ((rc = upload(s->owned, leaf.data(), leaf.size(), &dm.leaf))) return bail(rc);
+		if ((rc = upload(s->owned, m.tri_nrm, (size_t)m.n_tris * 9, &dm.nrm))) return bail(rc);
+		if ((rc = upload(s->owned, m.tri_uv, (size_t)m.n_tris * 6, &dm.uv))) return bail(rc);
+		if ((rc = upload(s->owned, m.tri_tb, m.tri_tb ? (size_t)m.n_tris * 6 : 0, &dm.tb))) return bail(rc);
+		if ((rc = upload(s->owned, m.diffuse_map, (size_t)m.diffuse_w * m.diffuse_h * 3, &dm.diffuse))) return bail(rc);
+		if ((rc = upload(s->owned, m.normal_map, (size_t)m.normal_w * m.normal_h * 3, &dm.normal))) return bail(rc);
+		if ((rc = upload(s->owned, m.specular_map, (size_t)m.specular_w * m.specular_h, &dm.specular))) return bail(rc);
+		dm.nNodes = m.n_nodes; dm.nRefs = m.n_refs; dm.nTris = m.n_tris;
+		dm.dW = m.diffuse_w; dm.dH = m.diffuse_h; dm.nW = m.normal_w; dm.nH = m.normal_h; dm.sW = m.specular_w; dm.sH = m.specular_h;
+	}
+	std::vector<Object> objs(desc->n_objects);
+	for (uint32_t i = 0; i < desc->n_objects; i++) {
+		const rtx_object& o = desc->objects[i];
+		Object& d = objs[i];
+		memset(&d, 0, sizeof(d));
+		if (o.type < RTX_OBJ_SPHERE || o.type > RTX_OBJ_MESH) return bail(fail(RTX_ERR_ARG, "bad object type"));
+		if (o.material < 0 || o.material > 3) return bail(fail(RTX_ERR_ARG, "bad material"));
+		if (o.type == RTX_OBJ_MESH && (o.mesh < 0 || (uint32_t)o.mesh >= desc->n_meshes)) return bail(fail(RTX_ERR_ARG, "bad mesh index"));
+		d.type = o.type; d.material = o.material;
+		memcpy(d.pos, o.pos, 12); memcpy(d.color, o.color, 12); memcpy(d.normal, o.normal, 12);
+		d.ior = o.ior; d.ambient = o.ambient; d.diffuse = o.diffuse; d.specular = o.specular; d.nSpecular = o.n_specular;
+		d.r2 = o.radius2; d.mesh = o.mesh;
+	}
+	std::vector<Light> lights(desc->n_lights);
+	for (uint32_t i = 0; i < desc->n_lights; i++) {
+		const rtx_light& l = desc->lights[i];
+		Light& d = lights[i];
+		memset(&d, 0, sizeof(d));
+		if (l.type < RTX_LIGHT_DISTANT || l.type > RTX_LIGHT_AREA) return bail(fail(RTX_ERR_ARG, "bad light type"));
+		d.type = l.type; memcpy(d.color, l.color, 12); d.intensity = l.intensity;
+		memcpy(d.dir, l.dir, 12); memcpy(d.pos, l.pos, 12);
+		d.nPoints = l.n_points;
+		if (l.type == RTX_LIGHT_AREA) {
+			if (!l.points || l.n_points == 0) return bail(fail(RTX_ERR_ARG, "area light without sample points"));
+			int rc;
+			if ((rc = upload(s->owned, l.points, (size_t)l.n_points * 3, &d.points))) return bail(rc);
+		}
+	}
+	int rc;
+	if ((rc = upload(s->owned, meshes.data(), meshes.size(), &s->params.meshes))) return bail(rc);
+	if ((rc = upload(s->owned, objs.data(), objs.size(), &s->params.objects))) return bail(rc);
+	if ((rc = upload(s->owned, lights.data(), lights.size(), &s->params.lights))) return bail(rc);
+	s->params.nObjects = desc->n_objects; s->params.nLights = desc->n_lights;
+	if (desc->sky_w && desc->sky_h && desc->sky[0]) {
+		for (int k = 0; k < 6; k++) {
+			if (!desc->sky[k]) return bail(fail(RTX_ERR_ARG, "skybox face missing"));
+			if ((rc = upload(s->owned, desc->sky[k], (size_t)desc->sky_w * desc->sky_h * 3, &s->params.sky[k]))) return bail(rc);
+		}
+		s->params.skyW = desc->sky_w; s->params.skyH = desc->sky_h;
+	}
+	if ((rc = setView(s, &desc->view))) return bail(rc);
+	if ((rc = ensureWork(s))) return bail(rc);
+	*out = s;
+	return RTX_OK;
+}
+
+void rtx_scene_destroy(rtx_scene* s)
+{
+	if (!s) return;
+	(void)hipSetDevice(s->device);
+	(void)hipDeviceSynchronize();
+	for (void* p : s->owned) (void)hipFree(p);
+	if (s->frames) (void)hipFree(s->frames);
+	if (s->list) (void)hipFree(s->list);
+	if (s->work) {
+		(void)hipFree(s->work); (void)hipFree(s->counters);
+		for (int i = 0; i < 3; i++) { (void)hipEventDestroy(s->ev[i][0]); (void)hipEventDestroy(s->ev[i][1]); }
+	}
+	delete s;
+}
+
+int rtx_scene_set_view(rtx_scene* s, const rtx_view* v)
+{
+	if (!s || !v) return fail(RTX_ERR_ARG, "scene/view is NULL");
+	int rc = setView(s, v);
+	if (rc) return rc;
+	return ensureWork(s);
+}
+
+int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, void* stream)
+{
+	if (!s || !fb_dev) return fail(RTX_ERR_ARG, "scene/fb is NULL");
+	const uint32_t W = s->params.view.width, H = s->params.view.height;
+	if (rowEnd > H) rowEnd = H;
+	if (rowBegin >= rowEnd) return RTX_OK;
+	int rc = ensureWork(s);
+	if (rc) return rc;
+	hipStream_t st = (hipStream_t)stream;
+	Params p = s->params;
+	p.fb = fb_dev;
+	p.rowBegin = rowBegin; p.rowEnd = rowEnd;
+	p.tilesX = (W - 1 + 7) / 8;
+	p.tileRow0 = rowBegin / 8;
+	const uint32_t lastRow = (rowEnd < H - 1 ? rowEnd : H - 1);   // exclusive; row H-1 is never rendered
+	if (lastRow <= rowBegin) return RTX_OK;
+	const uint32_t tilesY = (lastRow + 7) / 8 - p.tileRow0;
+	p.nTiles = p.tilesX * tilesY;
+	p.workCounter = s->work + 0;
+	HIPCHK(hipMemsetAsync(s->work + 0, 0, sizeof(uint32_t), st));
+	uint32_t blocks = (uint32_t)s->blocksPass1;
+	const uint32_t wavesNeeded = (p.nTiles + 3) / 4;
+	if (blocks > wavesNeeded) blocks = wavesNeeded ? wavesNeeded : 1;
+	HIPCHK(hipEventRecord(s->ev[0][0], st));
+	if (s->stats) hipLaunchKernelGGL(rtxPass1Kernel<true>, dim3(blocks), dim3(256), 0, st, p);
+	else hipLaunchKernelGGL(rtxPass1Kernel<false>, dim3(blocks), dim3(256), 0, st, p);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(s->ev[0][1], st));
+	s->evValid[0] = true;
+	return RTX_OK;
+}
+
+int rtx_sobel(rtx_scene* s, const float* fb_dev, uint32_t rowBegin, uint32_t rowEnd, uint8_t* mask_dev, void* stream)
+{
+	if (!s || !fb_dev || !mask_dev) return fail(RTX_ERR_ARG, "scene/fb/mask is NULL");
+	const uint32_t W = s->params.view.width, H = s->params.view.height;
+	if (rowEnd > H) rowEnd = H;
+	if (rowBegin >= rowEnd) return RTX_OK;
+	int rc = ensureWork(s);
+	if (rc) return rc;
+	hipStream_t st = (hipStream_t)stream;
+	HIPCHK(hipEventRecord(s->ev[1][0], st));
+	dim3 grid((W + 63) / 64, (rowEnd - rowBegin + 3) / 4);
+	hipLaunchKernelGGL(rtxSobelKernel, grid, dim3(256), 0, st, fb_dev, mask_dev, (uint32_t*)nullptr, (uint32_t*)nullptr, W, H, rowBegin, rowEnd);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(s->ev[1][1], st));
+	s->evValid[1] = true;
+	return RTX_OK;
+}
+
+int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, void* stream)
+{
+	if (!s || !fb_dev || !mask_dev) return fail(RTX_ERR_ARG, "scene/fb/mask is NULL");
+	const uint32_t W = s->params.view.width, H = s->params.view.height;
+	if (rowEnd > H) rowEnd = H;
+	if (rowBegin >= rowEnd) return RTX_OK;
+	int rc = ensureWork(s);
+	if (rc) return rc;
+	if ((rc = ensureList(s))) return rc;
+	hipStream_t st = (hipStream_t)stream;
+	HIPCHK(hipMemsetAsync(s->work + 1, 0, 2 * sizeof(uint32_t), st));
+	HIPCHK(hipEventRecord(s->ev[2][0], st));
+	dim3 grid((W + 63) / 64, (rowEnd - rowBegin + 3) / 4);
+	hipLaunchKernelGGL(rtxMaskListKernel, grid, dim3(256), 0, st, mask_dev, s->list, s->work + 2, W, H, rowBegin, rowEnd);
+	HIPCHK(hipGetLastError());
+	Params p = s->params;
+	p.fb = fb_dev;
+	p.workCounter = s->work + 1;
+	p.ssaaList = s->list;
+	p.ssaaCount = s->work + 2;
+	if (s->stats) hipLaunchKernelGGL(rtxSsaaKernel<true>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
+	else hipLaunchKernelGGL(rtxSsaaKernel<false>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(s->ev[2][1], st));
+	s->evValid[2] = true;
+	return RTX_OK;
+}
+
+int rtx_quantize_bgr8(rtx_scene* s, const float* fb_dev, uint8_t* bgr_dev, void* stream)
+{
+	if (!s || !fb_dev || !bgr_dev) return fail(RTX_ERR_ARG, "scene/fb/out is NULL");
+	const uint32_t W = s->params.view.width, H = s->params.view.height;
+	if (W % 4) return fail(RTX_ERR_UNSUPPORTED, "saveImage is only defined for width % 4 == 0 (util.cpp:28-29)");
+	HIPCHK(hipSetDevice(s->device));
+	const size_t n = (size_t)W * H;
+	hipLaunchKernelGGL(rtxQuantizeKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fb_dev, bgr_dev, W, H);
+	HIPCHK(hipGetLastError());
+	return RTX_OK;
+}
+
+int rtx_render_frame_host(rtx_scene* s, int with_ssaa, float* fb_host)
+{
+	if (!s || !fb_host) return fail(RTX_ERR_ARG, "scene/fb is NULL");
+	HIPCHK(hipSetDevice(s->device));
+	const uint32_t W = s->params.view.width, H = s->params.view.height;
+	const size_t bytes = (size_t)W * H * 3 * sizeof(float);
+	DevBuf fb, mask;
+	HIPCHK(hipMalloc(&fb.p, bytes));
+	HIPCHK(hipMemset(fb.p, 0, bytes));                 // new Vec3f[H*W] is zero-initialised (scene.cpp:599)
+	int rc = rtx_render_pass1(s, 0, H, (float*)fb.p, nullptr);
+	if (rc) return rc;
+	if (with_ssaa) {
+		HIPCHK(hipMalloc(&mask.p, (size_t)W * H));
+		if ((rc = rtx_sobel(s, (const float*)fb.p, 0, H, (uint8_t*)mask.p, nullptr))) return rc;
+		if ((rc = rtx_render_ssaa(s, (const uint8_t*)mask.p, 0, H, (float*)fb.p, nullptr))) return rc;
+	}
+	HIPCHK(hipMemcpy(fb_host, fb.p, bytes, hipMemcpyDeviceToHost));
+	return RTX_OK;
+}
+
+int rtx_counters_enable(rtx_scene* s, int enable)
+{
+	if (!s) return fail(RTX_ERR_ARG, "scene is NULL");
+	s->stats = enable != 0;
+	return RTX_OK;
+}
+
+int rtx_counters_reset(rtx_scene* s)
+{
+	if (!s) return fail(RTX_ERR_ARG, "scene is NULL");
+	int rc = ensureWork(s);
+	if (rc) return rc;
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemset(s->counters, 0, 3 * sizeof(unsigned long long)));
+	return RTX_OK;
+}
+
+int rtx_counters_read(rtx_scene* s, rtx_counters* out)
+{
+	if (!s || !out) return fail(RTX_ERR_ARG, "scene/out is NULL");
+	int rc = ensureWork(s);
+	if (rc) return rc;
+	HIPCHK(hipDeviceSynchronize());
+	unsigned long long c[3];
+	HIPCHK(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
+	out->rays = c[0]; out->box_tests = c[1]; out->tri_tests = c[2];
+	return RTX_OK;
+}
+
+int rtx_last_kernel_ms(rtx_scene* s, int which, float* ms)
+{
+	if (!s || !ms || which < 0 || which > 2) return fail(RTX_ERR_ARG, "bad argument");
+	if (!s->evValid[which]) return fail(RTX_ERR_ARG, "no such launch recorded yet");
+	HIPCHK(hipSetDevice(s->device));
+	HIPCHK(hipEventSynchronize(s->ev[which][1]));
+	HIPCHK(hipEventElapsedTime(ms, s->ev[which][0], s->ev[which][1]));
+	return RTX_OK;
+}
+
+int rtx_cast_rays(rtx_scene* s, uint32_t n, const float* rays, float* hits, float* colours)
+{
+	if (!s || !rays || !hits || !colours) return fail(RTX_ERR_ARG, "NULL argument");
+	if (n == 0) return RTX_OK;
+	int rc = ensureWork(s);
+	if (rc) return rc;
+	DevBuf dr, dh, dc;
+	HIPCHK(hipMalloc(&dr.p, (size_t)n * 24)); HIPCHK(hipMalloc(&dh.p, (size_t)n * 32)); HIPCHK(hipMalloc(&dc.p, (size_t)n * 12));
+	HIPCHK(hipMemcpy(dr.p, rays, (size_t)n * 24, hipMemcpyHostToDevice));
+	HIPCHK(hipMemset(s->work + 3, 0, sizeof(uint32_t)));
+	Params p = s->params;
+	p.workCounter = s->work + 3;
+	p.probeRays = (const float*)dr.p; p.probeHits = (float*)dh.p; p.probeColours = (float*)dc.p; p.nProbe = n;
+	uint32_t blocks = (uint32_t)s->blocksPass1;
+	const uint32_t need = ((n + 63) / 64 + 3) / 4;
+	if (blocks > need) blocks = need;
+	hipLaunchKernelGGL(rtxProbeKernel, dim3(blocks), dim3(256), 0, nullptr, p);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpy(hits, dh.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(colours, dc.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+	return RTX_OK;
+}
+
+int rtx_math_probe(int device, int op, uint32_t n, const float* x, const float* y, float* out)
+{
+	if (!x || !out || op < 0 || op > 4) return fail(RTX_ERR_ARG, "bad argument");
+	int cnt = 0;
+	if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fail(RTX_ERR_NO_DEVICE, "no HIP device visible");
+	HIPCHK(hipSetDevice(device));
+	DevBuf dx, dy, dout;
+	const size_t bytes = (size_t)n * sizeof(float);
+	HIPCHK(hipMalloc(&dx.p, bytes)); HIPCHK(hipMalloc(&dy.p, bytes)); HIPCHK(hipMalloc(&dout.p, bytes));
+	HIPCHK(hipMemcpy(dx.p, x, bytes, hipMemcpyHostToDevice));
+	if (y) HIPCHK(hipMemcpy(dy.p, y, bytes, hipMemcpyHostToDevice));
+	else HIPCHK(hipMemset(dy.p, 0, bytes));
+	hipLaunchKernelGGL(rtxMathProbeKernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, op, n, (const float*)dx.p, (const float*)dy.p, (float*)dout.p);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+	return RTX_OK;
+}
+
+} // extern "C"

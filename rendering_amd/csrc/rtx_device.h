@@ -1,0 +1,111 @@
+// Device-side data layout of the flattened scene (gfx950).  Shared by the kernels and the upload code.
+//
+// Everything the traversal touches is laid out so that a WAVE reads it through the scalar unit: one BVH
+// node is one 32-byte s_load_dwordx8, one leaf triangle is one cache-line-aligned 64-byte s_load_dwordx16.
+// The 64 lanes of a wave hold 64 different rays (an 8x8 pixel tile or 16 SSAA pixels x 4 samples); node and
+// triangle operands sit in SGPRs, so the VALU does nothing but the reference's own arithmetic.
+#pragma once
+#include <stdint.h>
+
+namespace rtxd {
+
+// Pre-order BVH node (reference: AccelerationStructure, objects.h:125-164).
+//   link  > 0 : inner node; link = pre-order index of the first node after this subtree ("skip")
+//   link  < 0 : leaf with ~link triangles starting at leaf-triangle index `first`
+struct Node {
+	float lo[3];
+	float hi[3];
+	int32_t link;
+	int32_t first;
+};
+static_assert(sizeof(Node) == 32, "node must be one s_load_dwordx8");
+
+// One leaf reference, duplicated per leaf in the reference's DFS-left-first order (objects.cpp:622-629).
+// e1 = b - a and e2 = c - a are the fp32 differences the reference recomputes per test (objects.cpp:70-71);
+// they are ray-independent, so computing them once on upload is bit-identical.
+struct LeafTri {
+	float v0[3];
+	float e1[3];
+	float e2[3];
+	uint32_t tri;     // index into the per-triangle shading arrays
+	uint32_t pad[6];
+};
+static_assert(sizeof(LeafTri) == 64, "leaf triangle must be one 64-byte line");
+
+struct Mesh {
+	const Node* nodes;
+	const LeafTri* leaf;
+	const float* nrm;      // n_tris x 9
+	const float* uv;       // n_tris x 6
+	const float* tb;       // n_tris x 6 (tangent, bitangent) or null
+	const float* diffuse;  // w*h x 3 or null
+	const float* normal;   // w*h x 3 or null
+	const float* specular; // w*h or null
+	uint32_t nNodes, nRefs, nTris;
+	uint32_t dW, dH, nW, nH, sW, sH;
+	uint32_t pad;
+};
+
+struct Object {
+	int32_t type, material;
+	float pos[3];
+	float color[3];
+	float ior, ambient, diffuse, specular, nSpecular;
+	float r2;
+	float normal[3];
+	int32_t mesh;
+};
+
+struct Light {
+	int32_t type;
+	float color[3];
+	float intensity;
+	float dir[3];
+	float pos[3];
+	uint32_t nPoints;
+	const float* points;
+};
+
+struct View {
+	uint32_t width, height;
+	float bias;
+	int32_t maxDepth;
+	float bg[3];
+	uint32_t flags;
+	float camPos[3];
+	float camM[16];
+	float scale, aspect;
+};
+
+// Kernel argument block (lives in the kernarg segment -> scalar loads).
+struct Params {
+	View view;
+	const Object* objects;
+	const Mesh* meshes;
+	const Light* lights;
+	const float* sky[6];
+	uint32_t nObjects, nLights, skyW, skyH;
+	// work distribution
+	uint32_t rowBegin, rowEnd;      // pass 1: image rows [rowBegin,rowEnd)
+	uint32_t tilesX, tileRow0, nTiles;
+	uint32_t* workCounter;          // persistent-wave work queue head
+	// SSAA work list
+	const uint32_t* ssaaList;       // flagged pixel indices y*W+x
+	const uint32_t* ssaaCount;
+	// recursion frames: [slot][field][lane]
+	float* frames;
+	uint32_t totalLanes;
+	uint32_t pad0;
+	float* fb;
+	// probe rays (rtx_cast_rays)
+	const float* probeRays;
+	float* probeHits;
+	float* probeColours;
+	uint32_t nProbe;
+	uint32_t pad1;
+	unsigned long long* counters;   // rays, boxTests, triTests
+};
+
+constexpr int kFrameFields = 14;
+
+} // namespace rtxd

@@ -1,0 +1,847 @@
+// gfx950 kernels of the ray-trace hot path: Render::castRay / Render::trace / BVH walk / Moller-Trumbore /
+// Phong-Fresnel-texture-skybox shading / Sobel mask / SSAA (reference: src/scene.cpp:381-946,
+// src/objects.cpp:59-175,534-631,766-824, src/lights.cpp:18-63).  Citations are file:line into the reference.
+//
+// Execution model:
+//   * persistent waves pull work items (8x8 pixel tiles, or 16 SSAA pixels x 4 samples) from an atomic queue;
+//   * the 64 lanes of a wave are 64 rays; every Render::trace of the wave is ONE cooperative walk of the
+//     pre-order node array: node boxes and leaf triangles are fetched with scalar loads (s_load_dwordx8/x16)
+//     into SGPRs, each lane runs the reference's slab test / Moller-Trumbore on its own ray;
+//   * the walk is stackless: a lane that fails a box stores the node's skip index in `resume` and sleeps
+//     until the wave's node cursor reaches it; the wave skips a subtree when the ballot of passing lanes is
+//     empty.  This visits, for every lane, exactly the nodes the reference's recursion visits, in the same
+//     order, so "strict <, first hit wins" is reproduced without a stack (objects.cpp:587-631);
+//   * castRay's recursion is an explicit per-lane frame stack in HBM ([slot][field][lane], coalesced) so the
+//     nested colour expressions keep the reference's association order (scene.cpp:858-940).
+//
+// Numerics contract: compiled with -ffp-contract=off, no fast-math; fp32 divide/sqrt are the
+// correctly rounded expansions; fp64 islands where the reference has them; powf is the restated glibc 2.35
+// (FMA variant) algorithm.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtx_device.h"
+
+#pragma clang fp contract(off)
+
+using namespace rtxd;
+
+namespace {
+
+#define RTX_AS4 __attribute__((address_space(4)))
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+
+// Wave-uniform loads through the constant address space -> SMEM instructions.
+__device__ __forceinline__ uint32_t sload1(const void* p) { return *(const RTX_AS4 uint32_t*)(uintptr_t)p; }
+__device__ __forceinline__ u32x8 sload8(const void* p) { return *(const RTX_AS4 u32x8*)(uintptr_t)p; }
+__device__ __forceinline__ u32x16 sload16(const void* p) { return *(const RTX_AS4 u32x16*)(uintptr_t)p; }
+__device__ __forceinline__ float sloadf(const float* p) { return __uint_as_float(sload1(p)); }
+__device__ __forceinline__ const void* sloadp(const void* p)
+{
+	u32x2 v = *(const RTX_AS4 u32x2*)(uintptr_t)p;
+	return (const void*)(((uint64_t)v.y << 32) | v.x);
+}
+#define F(x) __uint_as_float(x)
+// Pins a wave-uniform value into SGPRs (v_readfirstlane) so that addresses derived from it select SMEM loads
+// even when register pressure made the compiler park it in a VGPR.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T> __device__ __forceinline__ const T* uni(const T* p)
+{
+	const uint64_t a = (uint64_t)p;
+	return (const T*)(((uint64_t)uni((uint32_t)(a >> 32)) << 32) | uni((uint32_t)a));
+}
+
+__device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
+constexpr float kFltMax = 3.402823466e+38f;
+// (double)x < 1e-8 for a float x  <=>  x < 0x322bcc78 (the smallest float >= the double 1e-8);
+// objects.cpp:76,79,810 compare in double.
+#define RTX_EPS8 __uint_as_float(0x322bcc78u)
+constexpr uint32_t kNever = 0x7fffffffu;
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // geometry.h:84-87
+__device__ __forceinline__ float len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+// geometry.h:99-102: (float)sqrt((double)len2) == correctly rounded sqrtf (53 >= 2*24+2)
+__device__ __forceinline__ float length(V3 a) { return __builtin_sqrtf(len2(a)); }
+// geometry.h:104-112: factor = (float)(1 / sqrt((double)len2))
+__device__ __forceinline__ float invLenD(float l2) { return (float)(1.0 / __builtin_sqrt((double)l2)); }
+__device__ __forceinline__ V3 normalized(V3 a)
+{
+	float l2 = len2(a);
+	if (l2 > 0) {
+		float f = invLenD(l2);
+		a.x *= f; a.y *= f; a.z *= f;
+	}
+	return a;
+}
+__device__ __forceinline__ float fminRef(float a, float b) { return (b < a) ? b : a; }   // std::min(a,b)
+__device__ __forceinline__ float fmaxRef(float a, float b) { return (a < b) ? b : a; }   // std::max(a,b)
+__device__ __forceinline__ float clampRef(float lo, float hi, float v) { return fmaxRef(lo, fminRef(hi, v)); }
+
+// ------------------------------------------------------------------------------------------------
+// powf -- glibc 2.35 e_powf.c (ARM optimized-routines) as executed by the x86-64 FMA ifunc variant.
+// Tables: __powf_log2_data (16 x {invc, logc}, poly A[5]) and __exp2f_data (32 x u64, shift, poly C[3]).
+// ------------------------------------------------------------------------------------------------
+__device__ const double kLog2Tab[32] = {
+	0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2, 0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2,
+	0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2,  0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2,
+	0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2, 0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3,
+	0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3, 0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4,
+	0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5, 0x1p+0, 0x0p+0,
+	0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4,  0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3,
+	0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3,  0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2,
+	0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2,  0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2,
+};
+__device__ const uint64_t kExp2Tab[32] = {
+	0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b,
+	0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb,
+	0x3feedea64c123422, 0x3feece086061892d, 0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429,
+	0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13,
+	0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d, 0x3feee89f995ad3ad,
+	0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+	0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
+};
+
+__device__ __forceinline__ int powfCheckInt(uint32_t iy)
+{
+	int e = iy >> 23 & 0xff;
+	if (e < 0x7f) return 0;
+	if (e > 0x7f + 23) return 2;
+	if (iy & ((1u << (0x7f + 23 - e)) - 1)) return 0;
+	if (iy & (1u << (0x7f + 23 - e))) return 1;
+	return 2;
+}
+__device__ __forceinline__ bool zeroInfNan(uint32_t i) { return 2 * i - 1 >= 2u * 0x7f800000 - 1; }
+
+__device__ __noinline__ float powfRef(float x, float y)
+{
+	uint32_t signBias = 0;
+	uint32_t ix = __float_as_uint(x), iy = __float_as_uint(y);
+	if (ix - 0x00800000 >= 0x7f800000 - 0x00800000 || zeroInfNan(iy)) {
+		if (zeroInfNan(iy)) {
+			if (2 * iy == 0) return 1.0f;
+			if (ix == 0x3f800000) return 1.0f;
+			if (2 * ix > 2u * 0x7f800000 || 2 * iy > 2u * 0x7f800000) return x + y;
+			if (2 * ix == 2 * 0x3f800000) return 1.0f;
+			if ((2 * ix < 2 * 0x3f800000) == !(iy & 0x80000000)) return 0.0f;
+			return y * y;
+		}
+		if (zeroInfNan(ix)) {
+			float x2 = x * x;
+			if ((ix & 0x80000000) && powfCheckInt(iy) == 1) x2 = -x2;
+			return (iy & 0x80000000) ? 1 / x2 : x2;
+		}
+		if (ix & 0x80000000) {
+			int yint = powfCheckInt(iy);
+			if (yint == 0) return __uint_as_float(0x7fc00000u);
+			if (yint == 1) signBias = 1u << 16;
+			ix &= 0x7fffffff;
+		}
+		if (ix < 0x00800000) {
+			ix = __float_as_uint(x * 0x1p23f);
+			ix &= 0x7fffffff;
+			ix -= 23 << 23;
+		}
+	}
+	uint32_t tmp = ix - 0x3f330000;
+	int i = (tmp >> 19) % 16;
+	uint32_t top = tmp & 0xff800000;
+	uint32_t iz = ix - top;
+	int k = (int32_t)top >> 23;
+	double invc = kLog2Tab[2 * i], logc = kLog2Tab[2 * i + 1];
+	double z = (double)__uint_as_float(iz);
+	double r = __builtin_fma(z, invc, -1.0);
+	double y0 = logc + (double)k;
+	double r2 = r * r;
+	double yy = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+	double p = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+	double r4 = r2 * r2;
+	double q = __builtin_fma(0x1.71547652ab82bp+0, r, y0);
+	q = __builtin_fma(p, r2, q);
+	double logx = __builtin_fma(yy, r4, q);
+	double ylogx = (double)y * logx;
+	if ((__double_as_longlong(ylogx) >> 47 & 0xffff) >= (0x405f800000000000LL >> 47)) {
+		if (ylogx > 0x1.fffffffd1d571p+6) return signBias ? -__builtin_inff() : __builtin_inff();
+		if (ylogx <= -150.0) return signBias ? -0.0f : 0.0f;
+		if (ylogx < -149.0) return signBias ? -0x1p-149f : 0x1p-149f;
+	}
+	double kd = ylogx + 0x1.8p+47;
+	uint64_t ki = (uint64_t)__double_as_longlong(kd);
+	kd -= 0x1.8p+47;
+	double rr = ylogx - kd;
+	uint64_t t = kExp2Tab[ki % 32];
+	t += (ki + signBias) << (52 - 5);
+	double s = __longlong_as_double((long long)t);
+	double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+	double rr2 = rr * rr;
+	double yv = __builtin_fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
+	yv = __builtin_fma(zz, rr2, yv);
+	yv = yv * s;
+	return (float)yv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shading helpers (scene.cpp:672-722, 381-442; lights.cpp:18-38)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ V3 reflectDir(V3 d, V3 n) { float k = 2 * dot(d, n); return d - n * k; }   // scene.cpp:674
+
+__device__ __forceinline__ V3 refractDir(V3 d, V3 n, float ior)      // scene.cpp:677-696
+{
+	float n1 = 1, n2 = ior;
+	float cosi = clampRef(-1, 1, dot(d, n));
+	V3 mn = n;
+	if (cosi < 0) cosi = -cosi;
+	else { float t = n1; n1 = n2; n2 = t; mn = -n; }
+	float rri = n1 / n2;
+	float k = 1 - rri * rri * (1 - cosi * cosi);
+	if (k < 0) return mk(0, 0, 0);
+	return d * rri + mn * (rri * cosi - __builtin_sqrtf(k));
+}
+
+__device__ __forceinline__ float fresnelKr(V3 d, V3 n, float ior)    // scene.cpp:698-722
+{
+	float n1 = 1, n2 = ior;
+	float cosi = clampRef(-1, 1, dot(d, n));
+	if (cosi > 0) { float t = n1; n1 = n2; n2 = t; }
+	float sint = n1 / n2 * __builtin_sqrtf(fmaxRef(0.f, 1 - cosi * cosi));
+	if (sint >= 1) return 1;
+	float cost = __builtin_sqrtf(fmaxRef(0.f, 1 - sint * sint));
+	cosi = fabsf(cosi);
+	float rs = ((n2 * cosi) - (n1 * cost)) / ((n2 * cosi) + (n1 * cost));
+	float rp = ((n1 * cosi) - (n2 * cost)) / ((n1 * cosi) + (n2 * cost));
+	return (rs * rs + rp * rp) / 2;
+}
+
+__device__ __forceinline__ int toPixel(float v, int mx)               // scene.cpp:387-392
+{
+	int val = (int)((v + 1.0f) / 2.0f * mx);
+	if (val >= mx) val = mx - 1;
+	return val;
+}
+__device__ __forceinline__ V3 load3(const float* p) { return mk(p[0], p[1], p[2]); }
+
+__device__ __noinline__ V3 skyColor(const Params& P, V3 dir)           // scene.cpp:381-442
+{
+	if (!(P.view.flags & 2u)) return mk(P.view.bg[0], P.view.bg[1], P.view.bg[2]);
+	const int W = (int)P.skyW, H = (int)P.skyH;
+	float ax = fabsf(dir.x), ay = fabsf(dir.y), az = fabsf(dir.z);
+	float m = fmaxRef(ax, fmaxRef(ay, az));
+	V3 a; int face, i, j;
+	if (m == az) {
+		if (dir.z < 0) { a = dir * (1 / -dir.z); face = 1; i = toPixel(a.y, H); j = toPixel(a.x, W); }
+		else { a = dir * (1 / dir.z); face = 3; i = toPixel(a.y, H); j = toPixel(-a.x, W); }
+	}
+	else if (m == ax) {
+		if (dir.x < 0) { a = dir * (1 / -dir.x); face = 0; i = toPixel(a.y, H); j = toPixel(-a.z, W); }
+		else { a = dir * (1 / dir.x); face = 2; i = toPixel(a.y, H); j = toPixel(a.z, W); }
+	}
+	else {
+		if (dir.y < 0) { a = dir * (1 / -dir.y); face = 5; i = toPixel(a.z, H); j = toPixel(a.x, W); }
+		else { a = dir * (1 / dir.y); face = 4; i = toPixel(a.z, H); j = toPixel(a.x, W); }
+	}
+	return load3(P.sky[face] + ((size_t)i * W + j) * 3);
+}
+
+__device__ __forceinline__ int texel(int dim, float coord) { int v = (int)(dim * coord); if (v >= dim) v = dim - 1; return v; }
+
+// 4*M_PI*len2/1000 attenuation in fp64 (lights.cpp:35; scene.cpp:796,832,875,925)
+__device__ __forceinline__ float attenuation(float intensity, float l2)
+{
+	return fminRef(1.0f, (float)((double)intensity / (4 * 3.14159265358979323846 * (double)l2 / 1000)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Render::trace for a whole wave (scene.cpp:724-756)
+// ------------------------------------------------------------------------------------------------
+struct Hit { int obj; float t; uint32_t tri; float u, v; };
+struct Counts { unsigned long long rays, box, tri; };
+
+template <bool STATS>
+__device__ __forceinline__ void traceWave(const Params& P, bool active, bool shadow, V3 o, V3 d, float tmax,
+                                          Hit& h, Counts& cnt)
+{
+	h.obj = -1; h.t = tmax; h.tri = 0; h.u = 0; h.v = 0;
+	if (STATS) cnt.rays += __popcll(ballot(active));
+	const bool cull = (P.view.flags & 1u) != 0;
+	// AccelerationStructure::intersectBox's per-ray part (objects.cpp:543-544), hoisted out of the walk
+	const float ix = 1 / d.x, iy = 1 / d.y, iz = 1 / d.z;
+	const bool sx = ix < 0, sy = iy < 0, sz = iz < 0;
+	bool live = active;
+	const uint32_t nObj = uni(P.nObjects);
+	for (uint32_t oi = 0; oi < nObj; oi = uni(oi + 1)) {
+		const Object* ob = uni(P.objects + oi);
+		const int type = (int)sload1(&ob->type);
+		const int mat = (int)sload1(&ob->material);
+		// transparent objects do not cast shadows (scene.cpp:733)
+		const bool consider = live && !(shadow && mat == 2);
+		if (ballot(consider) == 0) continue;
+		if (type == 3) {
+			const Mesh* M = uni(P.meshes + (int)sload1(&ob->mesh));
+			const Node* nodes = uni((const Node*)sloadp(&M->nodes));
+			const LeafTri* leaf = uni((const LeafTri*)sloadp(&M->leaf));
+			const uint32_t nN = uni(sload1(&M->nNodes));
+			// objects.cpp:587-631 as a stackless pre-order walk
+			uint32_t resume = consider ? 0u : kNever;
+			float bt = kFltMax, bu = 0, bv = 0; uint32_t btri = 0; bool found = false;
+			uint32_t i = 0;
+			while (i < nN) {
+				const u32x8 nd = sload8(nodes + i);
+				const int32_t link = (int32_t)nd[6];
+				const uint32_t after = link > 0 ? (uint32_t)link : i + 1;
+				const bool act = i >= resume;
+				// slab test, objects.cpp:546-567 (sign-indexed bounds, sequential compares)
+				const float bx0 = sx ? F(nd[3]) : F(nd[0]), bx1 = sx ? F(nd[0]) : F(nd[3]);
+				const float by0 = sy ? F(nd[4]) : F(nd[1]), by1 = sy ? F(nd[1]) : F(nd[4]);
+				const float bz0 = sz ? F(nd[5]) : F(nd[2]), bz1 = sz ? F(nd[2]) : F(nd[5]);
+				float tmin = (bx0 - o.x) * ix, tmx = (bx1 - o.x) * ix;
+				const float tymin = (by0 - o.y) * iy, tymax = (by1 - o.y) * iy;
+				bool fail = (tmin > tymax) || (tymin > tmx);
+				if (tymin > tmin) tmin = tymin;
+				if (tymax < tmx) tmx = tymax;
+				const float tzmin = (bz0 - o.z) * iz, tzmax = (bz1 - o.z) * iz;
+				fail = fail || (tmin > tzmax) || (tzmin > tmx);
+				bool pass = act && !fail;
+				if (act && fail) resume = after;
+				if (STATS) cnt.box += __popcll(ballot(act));
+				const uint64_t m = ballot(pass);
+				if (m == 0) { i = uni(after); continue; }
+				if (link < 0) {
+					const uint32_t n = (uint32_t)~link;
+					const uint32_t first = nd[7];
+					if (STATS) cnt.tri += (unsigned long long)__popcll(m) * n;
+					for (uint32_t k = 0; k < n; ++k) {
+						const u32x16 td = sload16(leaf + first + k);
+						// Triangle::rayTriangleIntersect, objects.cpp:59-95
+						const float e1x = F(td[3]), e1y = F(td[4]), e1z = F(td[5]);
+						const float e2x = F(td[6]), e2y = F(td[7]), e2z = F(td[8]);
+						const float px = d.y * e2z - d.z * e2y, py = d.z * e2x - d.x * e2z, pz = d.x * e2y - d.y * e2x;
+						const float det = e1x * px + e1y * py + e1z * pz;
+						bool ok = pass;
+						if (cull) ok = ok && !(det < RTX_EPS8);
+						ok = ok && !(fabsf(det) < RTX_EPS8);
+						if (ballot(ok) == 0) continue;
+						const float inv = 1 / det;
+						const float tx = o.x - F(td[0]), ty = o.y - F(td[1]), tz = o.z - F(td[2]);
+						const float u = (tx * px + ty * py + tz * pz) * inv;
+						ok = ok && !(u < 0 || u > 1);
+						if (ballot(ok) == 0) continue;
+						const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+						const float v = (d.x * qx + d.y * qy + d.z * qz) * inv;
+						ok = ok && !(v < 0 || u + v > 1);
+						if (ballot(ok) == 0) continue;
+						const float t = (e2x * qx + e2y * qy + e2z * qz) * inv;
+						ok = ok && !(t < 0) && (t < bt);     // objects.cpp:91, 623
+						if (ok) { bt = t; bu = u; bv = v; btri = td[9]; found = true; }
+					}
+					// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is
+					// true for this lane no later triangle or object can change the answer.
+					if (!STATS) { if (shadow && found && bt < h.t) resume = kNever; }
+				}
+				i = uni(i + 1);
+			}
+			if (found && bt < h.t) { h.obj = (int)oi; h.t = bt; h.tri = btri; h.u = bu; h.v = bv; }   // scene.cpp:740-745
+		}
+		else {
+			const V3 c = mk(sloadf(&ob->pos[0]), sloadf(&ob->pos[1]), sloadf(&ob->pos[2]));
+			float t0 = kFltMax; bool hit;
+			if (type == 1) {                       // Sphere::intersectObject, objects.cpp:774-786
+				const float r2 = sloadf(&ob->r2);
+				const V3 L = c - o;
+				const float tca = dot(L, d);
+				const float d2 = dot(L, L) - tca * tca;
+				hit = !(d2 > r2);
+				const float thc = __builtin_sqrtf(r2 - d2);
+				t0 = tca - thc;
+				const float t1 = tca + thc;
+				if (t0 < 0) t0 = t1;
+				if (t0 < 0) hit = false;
+			}
+			else {                                 // Plane::intersectObject, objects.cpp:807-814
+				const V3 n = mk(sloadf(&ob->normal[0]), sloadf(&ob->normal[1]), sloadf(&ob->normal[2]));
+				const float denom = dot(d, n);
+				hit = !(fabsf(denom) < RTX_EPS8);
+				t0 = dot(c - o, n) / denom;
+				hit = hit && (t0 >= 0);
+			}
+			if (consider && hit && t0 < h.t) { h.obj = (int)oi; h.t = t0; h.u = 0; h.v = 0; }   // scene.cpp:748-752
+		}
+		if (!STATS) live = live && !(shadow && h.obj >= 0);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// castRay as a per-lane state machine (scene.cpp:758-946)
+// ------------------------------------------------------------------------------------------------
+enum : int {
+	ST_DONE = 0, ST_NEWRAY, ST_WAIT_PRIMARY, ST_WAIT_SHADOW, ST_NEXT_LIGHT, ST_LIGHTS_DONE, ST_RETURN
+};
+enum : int { FR_REFL = 1, FR_TRANS1 = 2, FR_TRANS2 = 3 };
+
+struct Lane {
+	int state;
+	int sp;                       // recursion depth == number of live frames
+	V3 ro, rd;                    // current ray
+	V3 col;                       // value being returned
+	// hit being shaded
+	int obj, mat;
+	V3 P, N, objColor, diff, spec, L, I;
+	float specCoef, nSpec, dsum, ssum;
+	uint32_t li, si;
+	// pending trace request
+	V3 qo, qd; float qtmax; bool qshadow;
+};
+
+__device__ __forceinline__ float& frameAt(const Params& P, uint32_t gl, int slot, int field)
+{
+	return P.frames[((size_t)slot * kFrameFields + field) * P.totalLanes + gl];
+}
+
+__device__ __forceinline__ void shadePrimary(const Params& P, Lane& s, const Hit& h)
+{
+	// scene.cpp:763-775 + Object::getSurfaceData overrides
+	const Object* ob = P.objects + h.obj;
+	s.obj = h.obj;
+	s.mat = ob->material;
+	s.objColor = mk(ob->color[0], ob->color[1], ob->color[2]);
+	s.specCoef = ob->specular;
+	s.nSpec = ob->nSpecular;
+	s.P = s.ro + s.rd * h.t;
+	const int type = ob->type;
+	if (type == 1) s.N = normalized(s.P - mk(ob->pos[0], ob->pos[1], ob->pos[2]));          // objects.cpp:788-796
+	else if (type == 2) s.N = mk(ob->normal[0], ob->normal[1], ob->normal[2]);             // objects.cpp:816-824
+	else {
+		// Mesh::getSurfaceData, objects.cpp:121-151
+		const Mesh* M = P.meshes + ob->mesh;
+		const float* uvp = M->uv + (size_t)h.tri * 6;
+		const float* np = M->nrm + (size_t)h.tri * 9;
+		const float u = h.u, v = h.v;
+		const float w = 1 - u - v;
+		const float texx = uvp[2] * u + uvp[4] * v + uvp[0] * w;
+		const float texy = uvp[3] * u + uvp[5] * v + uvp[1] * w;
+		V3 n = (load3(np + 3) * u + load3(np + 6) * v + load3(np) * (1 - u - v)) / 3;
+		n = normalized(n);
+		if (M->normal) {
+			const float* tbp = M->tb + (size_t)h.tri * 6;
+			const int x = texel((int)M->nW, texx), y = texel((int)M->nH, texy);
+			// normalise(texel as loaded): the reference's in-place re-normalisation race is resolved this way
+			const V3 tn = normalized(load3(M->normal + ((size_t)y * M->nW + x) * 3));
+			V3 r;
+			r.x = tn.x * tbp[0] + tn.y * tbp[3] + tn.z * n.x + 0.0f;
+			r.y = tn.x * tbp[1] + tn.y * tbp[4] + tn.z * n.y + 0.0f;
+			r.z = tn.x * tbp[2] + tn.y * tbp[5] + tn.z * n.z + 0.0f;
+			n = normalized(r);
+		}
+		s.N = n;
+		if (M->diffuse)                                     // Mesh::getDiffuseColor, objects.cpp:153-163
+			s.objColor = load3(M->diffuse + ((size_t)texel((int)M->dH, texy) * M->dW + texel((int)M->dW, texx)) * 3);
+		if (M->specular)                                    // Mesh::getSpecularValue, objects.cpp:165-175
+			s.specCoef = M->specular[(size_t)texel((int)M->sH, texy) * M->sW + texel((int)M->sW, texx)];
+	}
+	s.diff = mk(0, 0, 0); s.spec = mk(0, 0, 0);
+	s.li = 0; s.si = 0; s.dsum = 0; s.ssum = 0;
+}
+
+// Runs the lane's castRay state machine until it needs a Render::trace (returns true) or is finished.
+__device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
+{
+	const int maxDepth = P.view.maxDepth;
+	const float bias = P.view.bias;
+	for (;;) {
+		if (s.state == ST_NEWRAY) {
+			if (s.sp > maxDepth) { s.col = skyColor(P, s.rd); s.state = ST_RETURN; continue; }   // scene.cpp:760
+			s.qo = s.ro; s.qd = s.rd; s.qtmax = kFltMax; s.qshadow = false;
+			s.state = ST_WAIT_PRIMARY;
+			return;
+		}
+		if (s.state == ST_NEXT_LIGHT) {
+			if (s.li >= P.nLights) { s.state = ST_LIGHTS_DONE; continue; }
+			const Light* l = P.lights + s.li;
+			const int lt = l->type;
+			float dist;
+			if (lt == 1) {                 // DistantLight::illuminate, lights.cpp:18-23
+				s.L = mk(l->dir[0], l->dir[1], l->dir[2]);
+				s.I = mk(l->color[0], l->color[1], l->color[2]) * l->intensity;
+				dist = kFltMax;
+			}
+			else if (lt == 2) {            // PointLight::illuminate, lights.cpp:32-38
+				const V3 lp = mk(l->pos[0], l->pos[1], l->pos[2]);
+				V3 L = s.P - lp;
+				s.I = mk(l->color[0], l->color[1], l->color[2]) * attenuation(l->intensity, len2(L));
+				s.L = normalized(L);
+				dist = length(s.P - lp);
+			}
+			else {                         // area light sample loop, scene.cpp:790-806 etc.
+				const uint32_t np = l->nPoints;
+				if (s.si == 0) {
+					const V3 lp = mk(l->pos[0], l->pos[1], l->pos[2]);
+					s.I = mk(l->color[0], l->color[1], l->color[2]) * attenuation(l->intensity, len2(s.P - lp));
+					s.dsum = 0; s.ssum = 0;
+				}
+				if (s.si >= np) {
+					const float fn = (float)np;
+					if (s.mat == 0) s.diff = s.diff + s.I * (s.dsum / fn);                       // scene.cpp:805
+					else if (s.mat == 3) {                                                      // scene.cpp:845-846
+						s.diff = s.diff + s.I * (s.dsum / fn);
+						s.spec = s.spec + s.I * powfRef(s.ssum / fn, s.nSpec);
+					}
+					else s.spec = s.spec + s.I * powfRef(s.ssum / fn, s.nSpec);                  // scene.cpp:887, 937
+					s.li++; s.si = 0;
+					continue;
+				}
+				V3 L = s.P - load3(l->points + (size_t)s.si * 3);
+				dist = length(L);
+				s.L = normalized(L);
+			}
+			s.qo = s.P + s.N * bias; s.qd = -s.L; s.qtmax = dist; s.qshadow = true;               // scene.cpp:787
+			s.state = ST_WAIT_SHADOW;
+			return;
+		}
+		if (s.state == ST_LIGHTS_DONE) {
+			const Object* ob = P.objects + s.obj;
+			if (s.mat == 0) { s.col = s.objColor * s.diff; s.state = ST_RETURN; continue; }       // scene.cpp:808
+			if (s.mat == 3) {                                                                   // scene.cpp:852
+				s.col = s.objColor * ob->ambient + s.diff * ob->diffuse + s.spec * s.specCoef;
+				s.state = ST_RETURN; continue;
+			}
+			if (s.mat == 1) {                                                                   // scene.cpp:856-858, 890
+				frameAt(P, gl, s.sp, 0) = __int_as_float(FR_REFL);
+				frameAt(P, gl, s.sp, 2) = s.spec.x; frameAt(P, gl, s.sp, 3) = s.spec.y; frameAt(P, gl, s.sp, 4) = s.spec.z;
+				const V3 nd = s.rd - s.N * (2 * dot(s.rd, s.N));
+				s.ro = s.P + s.N * bias; s.rd = nd;
+				s.sp++; s.state = ST_NEWRAY; continue;
+			}
+			// Transparent, scene.cpp:893-907
+			const float ior = ob->ior;
+			const float kr = fresnelKr(s.rd, s.N, ior);
+			const bool outside = dot(s.rd, s.N) < 0;
+			const V3 biasVec = s.N * bias;
+			const V3 fd = normalized(reflectDir(s.rd, s.N));
+			const V3 fo = outside ? s.P + biasVec : s.P - biasVec;
+			frameAt(P, gl, s.sp, 1) = kr;
+			frameAt(P, gl, s.sp, 2) = s.spec.x; frameAt(P, gl, s.sp, 3) = s.spec.y; frameAt(P, gl, s.sp, 4) = s.spec.z;
+			if (kr < 1) {
+				const V3 rd = normalized(refractDir(s.rd, s.N, ior));
+				const V3 ro = outside ? s.P - biasVec : s.P + biasVec;
+				frameAt(P, gl, s.sp, 0) = __int_as_float(FR_TRANS1);
+				frameAt(P, gl, s.sp, 8) = fo.x; frameAt(P, gl, s.sp, 9) = fo.y; frameAt(P, gl, s.sp, 10) = fo.z;
+				frameAt(P, gl, s.sp, 11) = fd.x; frameAt(P, gl, s.sp, 12) = fd.y; frameAt(P, gl, s.sp, 13) = fd.z;
+				s.ro = ro; s.rd = rd;
+			}
+			else {
+				frameAt(P, gl, s.sp, 0) = __int_as_float(FR_TRANS2);
+				frameAt(P, gl, s.sp, 5) = 0.f; frameAt(P, gl, s.sp, 6) = 0.f; frameAt(P, gl, s.sp, 7) = 0.f;
+				s.ro = fo; s.rd = fd;
+			}
+			s.sp++; s.state = ST_NEWRAY; continue;
+		}
+		if (s.state == ST_RETURN) {
+			if (s.sp == 0) { s.state = ST_DONE; return; }
+			s.sp--;
+			const int kind = __float_as_int(frameAt(P, gl, s.sp, 0));
+			const V3 spec = mk(frameAt(P, gl, s.sp, 2), frameAt(P, gl, s.sp, 3), frameAt(P, gl, s.sp, 4));
+			if (kind == FR_REFL) { s.col = s.col * 0.8f + spec; continue; }                      // scene.cpp:858, 890
+			const float kr = frameAt(P, gl, s.sp, 1);
+			if (kind == FR_TRANS1) {                                                             // scene.cpp:896-902
+				const V3 acc = mk(0, 0, 0) + s.col * (1 - kr);
+				frameAt(P, gl, s.sp, 0) = __int_as_float(FR_TRANS2);
+				frameAt(P, gl, s.sp, 5) = acc.x; frameAt(P, gl, s.sp, 6) = acc.y; frameAt(P, gl, s.sp, 7) = acc.z;
+				s.ro = mk(frameAt(P, gl, s.sp, 8), frameAt(P, gl, s.sp, 9), frameAt(P, gl, s.sp, 10));
+				s.rd = mk(frameAt(P, gl, s.sp, 11), frameAt(P, gl, s.sp, 12), frameAt(P, gl, s.sp, 13));
+				s.sp++; s.state = ST_NEWRAY; continue;
+			}
+			V3 acc = mk(frameAt(P, gl, s.sp, 5), frameAt(P, gl, s.sp, 6), frameAt(P, gl, s.sp, 7));
+			acc = acc + s.col * kr;                                                              // scene.cpp:908
+			s.col = acc + spec * kr;                                                             // scene.cpp:940
+			continue;
+		}
+		return;   // ST_DONE / waiting states
+	}
+}
+
+// Consumes a finished Render::trace for this lane.
+__device__ __forceinline__ void consume(const Params& P, Lane& s, const Hit& h)
+{
+	if (s.state == ST_WAIT_PRIMARY) {
+		if (h.obj < 0) { s.col = skyColor(P, s.rd); s.state = ST_RETURN; return; }             // scene.cpp:945
+		shadePrimary(P, s, h);
+		s.state = ST_NEXT_LIGHT;
+		return;
+	}
+	if (s.state == ST_WAIT_SHADOW) {
+		const float vis = (h.obj < 0) ? 1.0f : 0.0f;       // bool vis = !trace(...)
+		const bool area = P.lights[s.li].type == 3;
+		const V3 nL = -s.L;
+		if (s.mat == 0) {
+			const float c = vis * fmaxRef(0.f, dot(s.N, nL));
+			if (!area) s.diff = s.diff + s.I * c;                                              // scene.cpp:788
+			else s.dsum += c;                                                                  // scene.cpp:803
+		}
+		else {
+			const V3 R = reflectDir(s.L, s.N);
+			const float sd = fmaxRef(0.f, dot(R, -s.rd));
+			if (!area) {
+				const V3 vI = s.I * vis;
+				if (s.mat == 3) s.diff = s.diff + vI * fmaxRef(0.f, dot(s.N, nL));             // scene.cpp:820
+				s.spec = s.spec + vI * powfRef(sd, s.nSpec);                                   // scene.cpp:824,867,917
+			}
+			else {
+				if (s.mat == 3) s.dsum += vis * fmaxRef(0.f, dot(s.N, nL));                    // scene.cpp:841
+				s.ssum += vis * sd;                                                            // scene.cpp:843,885,935
+			}
+		}
+		if (area) s.si++; else s.li++;
+		s.state = ST_NEXT_LIGHT;
+	}
+}
+
+__device__ __forceinline__ void primaryRay(const Params& P, float x, float y, V3& o, V3& d)
+{
+	// scene.cpp:453-457 (getPixels adds another 0.5) and Camera::getRay, scene.cpp:52-53
+	const float w = (float)P.view.width, hgt = (float)P.view.height;
+	const float xp = (2 * (x + 0.5f) / w - 1) * P.view.scale * P.view.aspect;
+	const float yp = -(2 * (y + 0.5f) / hgt - 1) * P.view.scale;
+	const V3 s = normalized(mk(xp, yp, -1));
+	const float* M = P.view.camM;
+	V3 r;
+	r.x = s.x * M[0] + s.y * M[4] + s.z * M[8] + M[12];
+	r.y = s.x * M[1] + s.y * M[5] + s.z * M[9] + M[13];
+	r.z = s.x * M[2] + s.y * M[6] + s.z * M[10] + M[14];
+	const float ww = s.x * M[3] + s.y * M[7] + s.z * M[11] + M[15];
+	if (ww != 0.0f && ww != 1.0f) { const float wi = 1.0f / ww; r.x *= wi; r.y *= wi; r.z *= wi; }   // geometry.h:300-305
+	o = mk(P.view.camPos[0], P.view.camPos[1], P.view.camPos[2]);
+	d = r;
+}
+
+template <bool STATS>
+__device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 d, uint32_t gl, Counts& cnt)
+{
+	Lane s;
+	s.state = valid ? ST_NEWRAY : ST_DONE;
+	s.sp = 0; s.ro = o; s.rd = d; s.col = mk(0, 0, 0);
+	s.obj = 0; s.mat = 0; s.li = 0; s.si = 0;
+	s.P = s.N = s.objColor = s.diff = s.spec = s.L = s.I = mk(0, 0, 0);
+	s.specCoef = s.nSpec = s.dsum = s.ssum = 0;
+	s.qo = o; s.qd = d; s.qtmax = kFltMax; s.qshadow = false;
+	advance(P, s, gl);
+	while (ballot(s.state != ST_DONE) != 0) {
+		Hit h;
+		traceWave<STATS>(P, s.state != ST_DONE, s.qshadow, s.qo, s.qd, s.qtmax, h, cnt);
+		if (s.state != ST_DONE) {
+			consume(P, s, h);
+			advance(P, s, gl);
+		}
+	}
+	return s.col;
+}
+
+__device__ __forceinline__ uint32_t nextWork(uint32_t* counter)
+{
+	uint32_t w = 0;
+	if (__lane_id() == 0) w = atomicAdd(counter, 1u);
+	return __builtin_amdgcn_readfirstlane(w);
+}
+
+__device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
+{
+	if (__lane_id() == 0) {
+		atomicAdd(P.counters + 0, c.rays);
+		atomicAdd(P.counters + 1, c.box);
+		atomicAdd(P.counters + 2, c.tri);
+	}
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// Pass 1: Scene::renderWorker over 8x8 pixel tiles (scene.cpp:444-468)
+// ------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ void __launch_bounds__(256) rtxPass1Kernel(const Params P)
+{
+	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t lane = __lane_id();
+	const uint32_t W = P.view.width, H = P.view.height;
+	Counts cnt = { 0, 0, 0 };
+	for (;;) {
+		const uint32_t tile = nextWork(P.workCounter);
+		if (tile >= P.nTiles) break;
+		const uint32_t ty = tile / P.tilesX, tx = tile - ty * P.tilesX;
+		const uint32_t x = tx * 8 + (lane & 7), y = (P.tileRow0 + ty) * 8 + (lane >> 3);
+		// x1/y1 are clamped to W-1/H-1: the last column and row are never rendered (scene.cpp:369-372)
+		const bool valid = x < W - 1 && y < H - 1 && y >= P.rowBegin && y < P.rowEnd;
+		V3 o, d;
+		primaryRay(P, (float)x + 0.5f, (float)y + 0.5f, o, d);
+		const V3 c = castRayWave<STATS>(P, valid, o, d, gl, cnt);
+		if (valid) {
+			float* px = P.fb + ((size_t)y * W + x) * 3;
+			px[0] = c.x; px[1] = c.y; px[2] = c.z;
+		}
+	}
+	if (STATS) flushCounts(P, cnt);
+	else if (lane == 0 && P.counters) { /* rays are counted by the STATS variant only */ }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pass 2: SSAAworker (scene.cpp:523-537): 16 flagged pixels x 4 sub-samples per wave
+// ------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ void __launch_bounds__(256) rtxSsaaKernel(const Params P)
+{
+	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t lane = __lane_id();
+	const uint32_t W = P.view.width;
+	const uint32_t n = sload1(P.ssaaCount);
+	const uint32_t nWork = (n + 15) / 16;
+	Counts cnt = { 0, 0, 0 };
+	for (;;) {
+		const uint32_t work = nextWork(P.workCounter);
+		if (work >= nWork) break;
+		const uint32_t item = work * 16 + (lane >> 2), sub = lane & 3;
+		const bool valid = item < n;
+		const uint32_t pix = valid ? P.ssaaList[item] : 0;
+		const uint32_t y = pix / W, x = pix - y * W;
+		// offsets in the reference's order: (.25,.25) (.25,.75) (.75,.25) (.75,.75)  (scene.cpp:527-534)
+		const float fx = (float)x + ((sub & 2) ? 0.75f : 0.25f), fy = (float)y + ((sub & 1) ? 0.75f : 0.25f);
+		V3 o, d;
+		primaryRay(P, fx, fy, o, d);
+		const V3 c = castRayWave<STATS>(P, valid, o, d, gl, cnt);
+		// color = 0; color += c0; += c1; += c2; += c3; fb = color / 4
+		const int base = (int)(lane & ~3u);
+		V3 sum = mk(0, 0, 0);
+		for (int k = 0; k < 4; ++k)
+			sum = sum + mk(__shfl(c.x, base + k), __shfl(c.y, base + k), __shfl(c.z, base + k));
+		if (valid && sub == 0) {
+			float* px = P.fb + (size_t)pix * 3;
+			px[0] = sum.x / 4; px[1] = sum.y / 4; px[2] = sum.z / 4;
+		}
+	}
+	if (STATS) flushCounts(P, cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Probe rays: Render::trace + Render::castRay for arbitrary rays (64 per wave), used by the parity tests
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rtxProbeKernel(const Params P)
+{
+	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t lane = __lane_id();
+	const uint32_t nWork = (P.nProbe + 63) / 64;
+	Counts cnt = { 0, 0, 0 };
+	for (;;) {
+		const uint32_t work = nextWork(P.workCounter);
+		if (work >= nWork) break;
+		const uint32_t i = work * 64 + lane;
+		const bool valid = i < P.nProbe;
+		V3 o = mk(0, 0, 0), d = mk(0, 0, -1);
+		if (valid) { o = load3(P.probeRays + (size_t)i * 6); d = load3(P.probeRays + (size_t)i * 6 + 3); }
+		Hit h;
+		traceWave<false>(P, valid, false, o, d, kFltMax, h, cnt);
+		if (valid) {
+			float* out = P.probeHits + (size_t)i * 8;
+			const bool hit = h.obj >= 0;
+			const bool mesh = hit && P.objects[hit ? h.obj : 0].type == 3;
+			out[0] = hit ? 1.f : 0.f; out[1] = hit ? (float)h.obj : -1.f; out[2] = mesh ? (float)h.tri : -1.f;
+			out[3] = h.t; out[4] = hit ? h.u : -1.f; out[5] = hit ? h.v : -1.f; out[6] = 0; out[7] = 0;
+		}
+		const V3 c = castRayWave<false>(P, valid, o, d, gl, cnt);
+		if (valid) { float* pc = P.probeColours + (size_t)i * 3; pc[0] = c.x; pc[1] = c.y; pc[2] = c.z; }
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sobel mask + compaction of the flagged pixels (scene.cpp:547-568)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rtxSobelKernel(const float* __restrict__ fb, uint8_t* __restrict__ mask,
+                                                      uint32_t* __restrict__ list, uint32_t* __restrict__ count,
+                                                      uint32_t W, uint32_t H, uint32_t rowBegin, uint32_t rowEnd)
+{
+	const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+	const uint32_t y = rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
+	bool flag = false;
+	const bool inImage = x < W && y < rowEnd && y < H;
+	if (inImage && x >= 1 && x + 1 < W && y >= 1 && y + 1 < H) {
+		V3 gx = mk(0, 0, 0), gy = mk(0, 0, 0);
+		const float op[3][3] = { { -1, 0, 1 }, { -2, 0, 2 }, { -1, 0, 1 } };
+#pragma unroll
+		for (int a = 0; a < 3; ++a)
+#pragma unroll
+			for (int b = 0; b < 3; ++b) {
+				const V3 p = load3(fb + ((size_t)(y - 1 + a) * W + (x - 1 + b)) * 3);
+				gx = gx + p * op[a][b];
+				gy = gy + p * op[b][a];
+			}
+		const float lx = length(gx), ly = length(gy);
+		const float val = __builtin_sqrtf(lx * lx + ly * ly);       // powf(.,2) == x*x (g++ folds it)
+		flag = val > 0.5f;
+	}
+	if (inImage) mask[(size_t)y * W + x] = flag ? 1 : 0;       // borders are defined as 0 (reference: uninitialised)
+	if (list) {
+		const uint64_t m = ballot(flag);
+		if (m) {
+			uint32_t base = 0;
+			if (__lane_id() == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
+			base = __builtin_amdgcn_readfirstlane(base);
+			if (flag) list[base + __popcll(m & ((1ull << __lane_id()) - 1))] = y * W + x;
+		}
+	}
+}
+
+// Builds the SSAA work list from an externally supplied mask (rtx_render_ssaa takes the mask, not the list).
+__global__ void __launch_bounds__(256) rtxMaskListKernel(const uint8_t* __restrict__ mask, uint32_t* __restrict__ list,
+                                                         uint32_t* __restrict__ count, uint32_t W, uint32_t H,
+                                                         uint32_t rowBegin, uint32_t rowEnd)
+{
+	const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+	const uint32_t y = rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
+	// the workers only visit x < W-1, y < H-1 (scene.cpp:369-372, 523-525)
+	const bool flag = x + 1 < W && y + 1 < H && y < rowEnd && mask[(size_t)y * W + x] != 0;
+	const uint64_t m = ballot(flag);
+	if (m) {
+		uint32_t base = 0;
+		if (__lane_id() == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
+		base = __builtin_amdgcn_readfirstlane(base);
+		if (flag) list[base + __popcll(m & ((1ull << __lane_id()) - 1))] = y * W + x;
+	}
+}
+
+// saveImage's quantiser (util.cpp:46-58)
+__global__ void __launch_bounds__(256) rtxQuantizeKernel(const float* __restrict__ fb, uint8_t* __restrict__ out,
+                                                         uint32_t W, uint32_t H)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // output pixel index, bottom-up rows
+	if (i >= (size_t)W * H) return;
+	const uint32_t row = (uint32_t)(i / W), x = (uint32_t)(i - (size_t)row * W);
+	const float* px = fb + ((size_t)(H - 1 - row) * W + x) * 3;
+	for (int k = 2; k >= 0; --k) out[i * 3 + (2 - k)] = (uint8_t)(int)(clampRef(0.0f, 1.0f, px[k]) * 255);
+}
+
+// Device-math self-check (rtx_math_probe)
+__global__ void rtxMathProbeKernel(int op, uint32_t n, const float* x, const float* y, float* out)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	float r = 0;
+	if (op == 0) r = powfRef(x[i], y[i]);
+	else if (op == 1) r = 1 / x[i];
+	else if (op == 2) r = __builtin_sqrtf(x[i]);
+	else if (op == 3) r = invLenD(x[i]);
+	else if (op == 4) r = x[i] / y[i];
+	out[i] = r;
+}
+
+// explicit instantiations used by rtx_api.hip
+template __global__ void rtxPass1Kernel<false>(const Params);
+template __global__ void rtxPass1Kernel<true>(const Params);
+template __global__ void rtxSsaaKernel<false>(const Params);
+template __global__ void rtxSsaaKernel<true>(const Params);

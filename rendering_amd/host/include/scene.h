@@ -1,0 +1,70 @@
+// Scene / Camera / Render (reference: include/scene.h).  Same public surface -- Scene(path), render(),
+// launchWorkers(Vec3f*), launchSSAA(Vec3f*), getTiles(), objects / lights / options / camera -- but the
+// two worker loops are launches of the gfx950 kernels through the C ABI in include/rtx.h.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "geometry.h"
+#include "lights.h"
+#include "objects.h"
+#include "options.h"
+
+struct rtx_scene;
+struct rtx_scene_desc;
+
+typedef struct { size_t x0, x1, y0, y1; } tileInfo;
+
+class Camera {
+public:
+	Vec3f pos{ 0, 0, 0 };
+	Vec3f rot{ 0, 0, 0 };
+	Matrix44f rMatrix;
+	float fov = 60.0f;
+	float zNear = 0.1f, zFar = 100.0f;
+	bool cameraRotated = false;
+	void ensureMatrix();          // the lazy part of Camera::getRay (scene.cpp:22-49), done before upload
+};
+
+// Result of one probe ray (Render::trace + Render::castRay at depth 0)
+struct ProbeResult { float hit, object, triangle, t, u, v, pad0, pad1; float colour[3]; };
+
+class Scene {
+public:
+	bool sceneLoadSuccess = true;
+	ObjectVector objects;
+	LightsVector lights;
+	Options options;
+	Camera camera;
+	int skyboxWidth = 0, skyboxHeight = 0;
+	std::vector<Vec3f> skyboxes[6];
+
+	explicit Scene(const std::string& sceneName);
+	~Scene();
+	Scene(const Scene&) = delete;
+	Scene& operator=(const Scene&) = delete;
+
+	bool loadScene(const std::string& sceneName);
+	void loadSkybox();
+	void render();
+	void launchWorkers(Vec3f* frameBuffer);   // pass 1 on the GPU, result copied into the caller's buffer
+	void launchSSAA(Vec3f* frameBuffer);      // Sobel + 4-ray re-render on the GPU
+	std::vector<tileInfo> getTiles();
+
+	// MI355X side
+	int device = 0;
+	rtx_scene* gpu();                          // flattens + uploads on first use; LOG_ERROR()s without a GPU
+	void invalidateView();                     // call after changing options.width/height, camera, flags
+	double lastPass1Ms = 0, lastSobelMs = 0, lastSsaaMs = 0;
+
+private:
+	rtx_scene* gpu_ = nullptr;
+	bool viewDirty_ = true;
+};
+
+// Host-side flattening used by Scene::gpu(); exposed for tests and for maintainers wiring the reference's own
+// Scene to the C ABI.
+struct FlatScene;
+FlatScene* flattenScene(Scene& scene);
+const rtx_scene_desc* flatDesc(const FlatScene*);
+void freeFlatScene(FlatScene*);

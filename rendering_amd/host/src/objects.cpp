@@ -1,0 +1,327 @@
+// Mesh loading and the spatial-split "SAH" acceleration-structure build (reference: src/objects.cpp:177-458,
+// 470-526, 633-763), re-implemented over flat arrays.  The build must reproduce the reference's topology and
+// bounds bit-for-bit because the kernels traverse exactly these boxes; tests compare it with
+// the oracle and with the golden BVH digests of the real reference.
+#include "objects.h"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+
+#include "stats.h"
+#include "timer.h"
+#include "util.h"
+
+template <> Matrix44f Matrix44f::fromEulerDegrees(const Vec3f& rot)
+{
+	const float a = degToRad(rot.x), b = degToRad(rot.y), c = degToRad(rot.z);
+	Matrix44f mx, my, mz;
+	mx[1][1] = cosf(a); mx[1][2] = -sinf(a); mx[2][1] = sinf(a); mx[2][2] = cosf(a);
+	my[0][0] = cosf(b); my[0][2] = sinf(b); my[2][0] = -sinf(b); my[2][2] = cosf(b);
+	mz[0][0] = cosf(c); mz[0][1] = -sinf(c); mz[1][0] = sinf(c); mz[1][1] = cosf(c);
+	return mz * my * mx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// acceleration structure
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Builder {
+	const std::vector<Triangle>& tris;
+	const int penalty;
+	AccelerationStructure& out;
+	// per-axis extent of every triangle: "some vertex <= s" == lo <= s, "some vertex >= s" == hi >= s
+	std::vector<float> lo[3], hi[3];
+
+	Builder(const std::vector<Triangle>& t, int p, AccelerationStructure& o) : tris(t), penalty(p), out(o)
+	{
+		for (int ax = 0; ax < 3; ++ax) {
+			lo[ax].resize(t.size()); hi[ax].resize(t.size());
+			for (size_t i = 0; i < t.size(); ++i) {
+				const float a = t[i].a[ax], b = t[i].b[ax], c = t[i].c[ax];
+				lo[ax][i] = std::min(a, std::min(b, c));
+				hi[ax][i] = std::max(a, std::max(b, c));
+			}
+		}
+	}
+
+	// nLeft*(s - min) + nRight*(max - s), counts promoted to float (objects.cpp:633-674)
+	float cost(int ax, const std::vector<uint32_t>& ids, float mn, float mx, float s) const
+	{
+		int nl = 0, nr = 0;
+		const float* l = lo[ax].data(); const float* h = hi[ax].data();
+		for (uint32_t id : ids) { nl += l[id] <= s; nr += h[id] >= s; }
+		return nl * (s - mn) + nr * (mx - s);
+	}
+
+	// bisection on [left,right] until narrower than 0.1, comparing the cost 0.05 either side of the midpoint
+	// (objects.cpp:676-689)
+	float split(int ax, const std::vector<uint32_t>& ids, float mn, float mx) const
+	{
+		float left = mn, right = mx;
+		for (;;) {
+			const float mid = right - (right - left) / 2;
+			if (right - left < 0.1f) return mid;
+			if (cost(ax, ids, mn, mx, mid - 0.05f) < cost(ax, ids, mn, mx, mid + 0.05f)) right = mid;
+			else left = mid;
+		}
+	}
+
+	void leaf(int32_t node, const std::vector<uint32_t>& ids)
+	{
+		out.nodes[node].leafBegin = (int32_t)out.refs.size();
+		out.nodes[node].leafCount = (int32_t)ids.size();
+		out.refs.insert(out.refs.end(), ids.begin(), ids.end());
+		stats::triCopiesCount += ids.size();
+	}
+
+	void build(const Vec3f& bmin, const Vec3f& bmax, std::vector<uint32_t>& ids, int depth)
+	{
+		const int32_t me = (int32_t)out.nodes.size();
+		out.nodes.emplace_back();
+		out.nodes[me].bounds[0] = bmin; out.nodes[me].bounds[1] = bmax;
+		if (depth > out.maxDepth) out.maxDepth = depth;
+		stats::acCount++;
+		bool isLeaf = ids.size() <= depth * (size_t)penalty;                 // objects.cpp:477
+		std::vector<uint32_t> L, R;
+		int ax = 2; float s = 0;
+		if (!isLeaf) {
+			const Vec3f dim = bmax - bmin;                                       // objects.cpp:486-490
+			if (dim.x > dim.y && dim.x > dim.z) ax = 0;
+			else if (dim.y > dim.z) ax = 1;
+			s = split(ax, ids, bmin[ax], bmax[ax]);
+			const float* l = lo[ax].data(); const float* h = hi[ax].data();
+			for (uint32_t id : ids) {                                            // objects.cpp:737-760
+				if (l[id] <= s) L.push_back(id);
+				if (h[id] >= s) R.push_back(id);
+			}
+			isLeaf = L.empty() || R.empty() || (L.size() + R.size() >= ids.size() * 1.5);   // objects.cpp:498
+		}
+		if (isLeaf) {
+			leaf(me, ids);
+			out.nodes[me].skip = me + 1;
+			return;
+		}
+		{ std::vector<uint32_t>().swap(ids); }
+		Vec3f lmax = bmax, rmin = bmin;                                          // objects.cpp:510-521
+		lmax[ax] = s; rmin[ax] = s;
+		build(bmin, lmax, L, depth + 1);
+		{ std::vector<uint32_t>().swap(L); }
+		build(rmin, bmax, R, depth + 1);
+		out.nodes[me].skip = (int32_t)out.nodes.size();
+	}
+};
+
+} // namespace
+
+void AccelerationStructure::setup(const std::vector<Triangle>& tris, const Options& options)
+{
+	nodes.clear(); refs.clear(); maxDepth = 0;
+	Builder b(tris, options.acPenalty, *this);
+	std::vector<uint32_t> ids(tris.size());
+	for (size_t i = 0; i < ids.size(); ++i) ids[i] = (uint32_t)i;
+	b.build(rootBounds[0], rootBounds[1], ids, 1);                               // root depth 1 (objects.cpp:389)
+}
+
+size_t AccelerationStructure::leafCount() const
+{
+	size_t n = 0;
+	for (const Node& nd : nodes) n += nd.leafCount >= 0;
+	return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// OBJ loader
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// index reader of the reference (objects.cpp:207-215): skips blanks and one '/', stops at blank, '/' or NUL
+size_t readIndex(const char*& p)
+{
+	size_t v = 0;
+	while (*p == ' ') ++p;
+	if (*p == '/') ++p;
+	for (; *p && *p != ' ' && *p != '/'; ++p) v = v * 10 + (size_t)(*p - '0');
+	return v;
+}
+
+void faceNormal(Triangle& t) { t.n_a = t.n_b = t.n_c = (t.b - t.a).crossProduct(t.c - t.a); }   // objects.cpp:20
+
+void tangentFrame(Triangle& t)                                                 // objects.cpp:43-55
+{
+	const Vec3f e1 = t.b - t.a, e2 = t.c - t.a;
+	const Vec2f d1 = t.t_b - t.t_a, d2 = t.t_c - t.t_a;
+	const float f = 1.0f / (d1.x * d2.y - d2.x * d1.y);
+	for (int k = 0; k < 3; ++k) {
+		t.tangent[k] = f * (d2.y * e1[k] - d1.y * e2[k]);
+		t.bitangent[k] = f * (-d2.x * e1[k] + d1.x * e2[k]);
+	}
+}
+
+} // namespace
+
+bool Mesh::loadOBJ(const std::string& filename, const Options& options)
+{
+	const Matrix44f R = Matrix44f::fromEulerDegrees(rot);
+	Timer timer("OBJ loading");
+	std::ifstream in(filename);
+	if (!in.good()) {
+		std::cout << "Error, failed to load obj, filename: " << filename << '\n';
+		return false;
+	}
+	if (options::enableOutput) std::cout << "Mesh: " << filename << '\n';
+	ac = std::make_unique<AccelerationStructure>();
+	std::vector<Vec3f> P, N;
+	std::vector<Vec2f> T;
+	const float big = std::numeric_limits<float>::max(), tiny = std::numeric_limits<float>::min();
+	Vec3f lo(big), hi(tiny);              // `max` starts at the smallest positive float (objects.cpp:231)
+	bool placed = false;
+
+	// First face: fit the vertices into `size` (keeping proportions), centre, rotate, translate; pin flat axes;
+	// derive the root box from the rotated size vector (objects.cpp:282-331).
+	auto place = [&]() {
+		const Vec3f range = hi - lo;
+		Vec3f ns = size;
+		if (!(range.x < options.bias || range.y < options.bias || range.z < options.bias)) {
+			const Vec3f stretch = size / range;
+			const float m = std::min(stretch.x, std::min(stretch.y, stretch.z));
+			if (m == stretch.x) { ns.y = ns.x / (range.x / range.y); ns.z = ns.x / (range.x / range.z); }
+			else if (m == stretch.y) { ns.x = ns.y / (range.y / range.x); ns.z = ns.y / (range.y / range.z); }
+			else { ns.x = ns.z / (range.z / range.x); ns.y = ns.z / (range.z / range.y); }
+		}
+		for (Vec3f& v : P) {
+			v.x = ns.x * ((v.x - lo.x) / range.x - 0.5f);
+			v.y = ns.y * ((v.y - lo.y) / range.y - 0.5f);
+			v.z = ns.z * ((v.z - lo.z) / range.z - 0.5f);
+			v = R.multVecMatrix(v);
+			v.x += pos.x; v.y += pos.y; v.z += pos.z;
+			if (range.x < options.bias) v.x = pos.x;
+			if (range.y < options.bias) v.y = pos.y;
+			if (range.z < options.bias) v.z = pos.z;
+		}
+		for (Vec3f& n : N) n = R.multVecMatrix(n);
+		Vec3f ext = R.multVecMatrix(ns);
+		ext = Vec3f(std::fabs(ext.x), std::fabs(ext.y), std::fabs(ext.z));
+		ac->setBounds(pos - ext / 2, pos + ext / 2);
+	};
+
+	std::string line;
+	while (std::getline(in, line)) {
+		const size_t hash = line.find('#');
+		if (hash != std::string::npos) line.erase(hash);
+		if (line.empty()) continue;
+		char tag[32] = { 0 };
+		if (sscanf(line.c_str(), "%31s", tag) == 0) return false;
+		const char* rest = line.c_str() + strlen(tag) + 1;
+		if (!strcmp(tag, "v")) {
+			float x, y, z;
+			if (sscanf(rest, "%f %f %f", &x, &y, &z) != 3) LOG_ERROR();
+			lo.x = std::min(x, lo.x); lo.y = std::min(y, lo.y); lo.z = std::min(z, lo.z);
+			hi.x = std::max(x, hi.x); hi.y = std::max(y, hi.y); hi.z = std::max(z, hi.z);
+			P.emplace_back(x, y, z);
+		}
+		else if (!strcmp(tag, "vn")) {
+			float x, y, z;
+			if (sscanf(rest, "%f %f %f", &x, &y, &z) != 3) LOG_ERROR();
+			N.push_back(Vec3f(x, y, z).normalize());
+		}
+		else if (!strcmp(tag, "vt")) {
+			float x, y;
+			if (sscanf(rest, "%f %f", &x, &y) != 2) LOG_ERROR();
+			T.emplace_back(x, y);
+		}
+		else if (!strcmp(tag, "f")) {
+			if (!placed) { placed = true; place(); }
+			int slashes = 0;
+			for (const char* p = rest; *p; ++p) slashes += (*p == '/');
+			if (slashes != 0 && slashes % 2 != 0) {
+				std::cout << "Unhandled slash count: " << slashes << '\n';       // objects.cpp:376-378
+				continue;
+			}
+			std::vector<size_t> vi, ti, ni;
+			const char* p = rest;
+			for (size_t v; (v = readIndex(p)) > 0;) {
+				vi.push_back(v);
+				if (slashes) {
+					const size_t t = readIndex(p), n = readIndex(p);
+					if (t > 0) ti.push_back(t);
+					if (n > 0) ni.push_back(n);
+				}
+			}
+			// triangle fan (objects.cpp:344-373)
+			for (size_t k = 1; k + 1 < vi.size(); ++k) {
+				Triangle t;
+				t.a = P.at(vi[0] - 1); t.b = P.at(vi[k] - 1); t.c = P.at(vi[k + 1] - 1);
+				faceNormal(t);
+				if (!ni.empty()) {
+					t.n_a = N.at(ni.at(0) - 1); t.n_b = N.at(ni.at(k) - 1); t.n_c = N.at(ni.at(k + 1) - 1);
+					if (!ti.empty()) {
+						t.t_a = T.at(ti.at(0) - 1); t.t_b = T.at(ti.at(k) - 1); t.t_c = T.at(ti.at(k + 1) - 1);
+						tangentFrame(t);
+					}
+				}
+				allTris.push_back(t);
+			}
+		}
+	}
+	ac->setup(allTris, options);
+	stats::meshCount += allTris.size();
+	return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// texture maps (objects.cpp:396-458): byte/256, bottom-up rows kept as loaded
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Pixels {
+	int w = 0, h = 0;
+	std::unique_ptr<unsigned char[]> data;
+	explicit Pixels(const std::string& fn) { data.reset(loadBMP(fn.c_str(), w, h)); }
+	Vec3f at(size_t i) const
+	{
+		float r = data[i * 3], g = data[i * 3 + 1], b = data[i * 3 + 2];
+		r /= 256; g /= 256; b /= 256;
+		return Vec3f(r, g, b);
+	}
+	size_t count() const { return (size_t)w * h; }
+};
+}
+
+bool Mesh::loadDiffuseMap(const std::string& filename)
+{
+	if (!options::useTextures) return false;
+	Pixels px(filename);
+	diffuseMapWidth = px.w; diffuseMapHeight = px.h;
+	diffuseMap.resize(px.count());
+	for (size_t i = 0; i < px.count(); ++i) diffuseMap[i] = px.at(i);
+	return true;
+}
+
+bool Mesh::loadNormalMap(const std::string& filename)
+{
+	if (!options::useTextures) return false;
+	Pixels px(filename);
+	normalMapWidth = px.w; normalMapHeight = px.h;
+	normalMap.resize(px.count());
+	for (size_t i = 0; i < px.count(); ++i) {
+		const Vec3f c = px.at(i);
+		normalMap[i] = Vec3f(c.x * 2 - 1, -(c.y * 2 - 1), c.z).normalize();     // objects.cpp:433
+	}
+	return true;
+}
+
+bool Mesh::loadSpecularMap(const std::string& filename)
+{
+	if (!options::useTextures) return false;
+	Pixels px(filename);
+	specularMapWidth = px.w; specularMapHeight = px.h;
+	specularMap.resize(px.count());
+	for (size_t i = 0; i < px.count(); ++i) {
+		const Vec3f c = px.at(i);
+		specularMap[i] = (c.x + c.y + c.z) / 3.0f;
+	}
+	return true;
+}

@@ -1,0 +1,149 @@
+// Loader helpers, BMP I/O, timers and statistics of the host side (reference: src/util.cpp, include/util.h,
+// timer.h, stats.h) -- own implementation.
+#include "util.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+
+#include "stats.h"
+#include "timer.h"
+
+void logError(const char* file, const char* func, int line)
+{
+	// same message and exit status as the reference (util.h:13-19)
+	std::cout << "Error: " << file << ' ' << func << ' ' << line << std::endl;
+	std::exit(-1);
+}
+
+namespace {
+template <typename T> T parseValue(std::string_view s)
+{
+	T v{};
+	std::istringstream in{ std::string(s) };
+	in >> v;
+	if (!in.eof() && !in.good()) LOG_ERROR();
+	return v;
+}
+}
+
+bool strToBool(std::string_view s) { return parseValue<bool>(s); }
+int strToInt(std::string_view s) { return parseValue<int>(s); }
+float strToFloat(std::string_view s) { return parseValue<float>(s); }
+
+Vec3f str3ToFloat(const std::vector<std::string>& p)
+{
+	if (p.size() != 3) LOG_ERROR();
+	return Vec3f(strToFloat(p[0]), strToFloat(p[1]), strToFloat(p[2]));
+}
+
+std::vector<std::string> splitString(std::string_view s, char delim)
+{
+	std::vector<std::string> out;
+	std::istringstream in{ std::string(s) };
+	for (std::string cell; std::getline(in, cell, delim);) out.push_back(cell);
+	return out;
+}
+
+namespace {
+// The reference writes its 54-byte header with overlapping 8-byte stores (util.cpp:33-43); only the resulting
+// bytes matter.  For W%4==0 they are a standard BITMAPINFOHEADER except biClrUsed/biClrImportant = 0.
+void bmpHeader(unsigned char* h, size_t w, size_t ht)
+{
+	memset(h, 0, 54);
+	const uint64_t arr = (uint64_t)ht * w * 3;
+	auto put = [&](int off, uint64_t v) { memcpy(h + off, &v, 8); };
+	h[0] = 'B'; h[1] = 'M';
+	put(0x02, 54 + arr); put(0x0A, 54); put(0x0E, 40); put(0x12, w); put(0x16, ht);
+	h[0x1A] = 1; h[0x1C] = 24;
+	put(0x22, arr); put(0x26, 2835); put(0x2A, 2835);
+}
+}
+
+int saveImageBGR(const unsigned char* bgr, const Options& options)
+{
+	if (options.width % 4 != 0) {
+		std::cout << "saveImage: width must be a multiple of 4" << '\n';   // the reference corrupts memory here (util.cpp:28-57)
+		return -2;
+	}
+	const std::string path = options.imageName + ".bmp";
+	FILE* f = fopen(path.c_str(), "wb");
+	if (!f) { std::cout << "Could not open output file " << path << '\n'; return -1; }
+	std::cout << "Successfully wrote to output file " << path << '\n';
+	unsigned char hdr[54];
+	bmpHeader(hdr, options.width, options.height);
+	fwrite(hdr, 1, 54, f);
+	fwrite(bgr, 1, options.width * options.height * 3, f);
+	fclose(f);
+	return 0;
+}
+
+int saveImage(const Vec3f* fb, const Options& options)
+{
+	std::vector<unsigned char> px(options.width * options.height * 3);
+	unsigned char* p = px.data();
+	for (size_t row = 0; row < options.height; ++row) {
+		const Vec3f* src = fb + (options.height - 1 - row) * options.width;      // bottom-up
+		for (size_t x = 0; x < options.width; ++x)
+			for (int k = 2; k >= 0; --k) *p++ = (unsigned char)(int)(clamp(0.0f, 1.0f, src[x][k]) * 255);
+	}
+	return saveImageBGR(px.data(), options);
+}
+
+unsigned char* loadBMP(const char* filename, int& width, int& height)
+{
+	FILE* f = fopen(filename, "rb");
+	if (!f) {
+		std::cout << "Could not open .bmp file: " << filename << '\n';
+		LOG_ERROR();
+	}
+	unsigned char hdr[54];
+	if (fread(hdr, 1, 54, f) != 54) { fclose(f); LOG_ERROR(); }
+	memcpy(&width, hdr + 18, 4);
+	memcpy(&height, hdr + 22, 4);
+	const size_t n = (size_t)3 * width * height;
+	unsigned char* data = new unsigned char[n];
+	const size_t got = fread(data, 1, n, f);
+	(void)got;
+	fclose(f);
+	for (size_t i = 0; i + 2 < n; i += 3) { unsigned char t = data[i]; data[i] = data[i + 2]; data[i + 2] = t; }
+	return data;
+}
+
+// ---- options / stats / timer -------------------------------------------------------------------
+void options::reset()
+{
+	outputProgress = true; useBackfaceCulling = true; collectStatistics = false; enableOutput = true;
+	imageOutput = true; useAC = true; showAC = false; useSkybox = false; useTextures = true;
+	showNormals = false; enableSSAA = true;
+}
+
+void stats::reset() { rayTriTests = accelStructTests = triCopiesCount = meshCount = acCount = raysCasted = 0; }
+
+void stats::printStats()
+{
+	std::cout.precision(2);
+	std::cout << "Statistics:\n";
+	auto line = [](const char* name, double v) { std::cout << std::left << std::setw(36) << name << std::setw(10) << std::scientific << v << '\n'; };
+	line("Ray triangle tests:", (double)rayTriTests);
+	line("Ray acceleration structure tests:", (double)accelStructTests);
+	line("Total intersection test:", (double)rayTriTests + (double)accelStructTests);
+	std::cout << std::left << std::setw(36) << "Total triangle copies:" << triCopiesCount << '\n';
+	std::cout << std::left << std::setw(36) << "Total triangle count:" << meshCount << '\n';
+	std::cout << std::left << std::setw(36) << "Acceleration structure count:" << acCount << '\n';
+	line("Rays casted:", (double)raysCasted);
+}
+
+Timer::Timer(std::string name) : name_(std::move(name)), start_(std::chrono::steady_clock::now()) {}
+Timer::~Timer() { stop(); }
+long long Timer::stop()
+{
+	if (!running_) return 0;
+	running_ = false;
+	const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - start_).count();
+	if (options::enableOutput) std::cout << std::setw(18) << std::left << name_ << ms << " ms" << std::endl;
+	return ms;
+}
