@@ -161,9 +161,20 @@ int rtx_counters_enable(rtx_scene* scene, int enable);
 int rtx_counters_reset(rtx_scene* scene);
 int rtx_counters_read(rtx_scene* scene, rtx_counters* out); /* synchronises the device */
 
-/* Duration in ms of the most recent pass-1 / ssaa kernel of this scene, from HIP events recorded on the
- * launch stream (synchronises on the stop event).  which: 0 = pass 1, 1 = sobel, 2 = ssaa. */
+/* Kernel timing from HIP events recorded on the launch stream around every launch.
+ * which: 0 = pass 1, 1 = sobel, 2 = ssaa (mask compaction + 4-ray kernel).
+ * rtx_last_kernel_ms: the most recent launch (synchronises on its stop event).
+ * rtx_kernel_time_stats: number of launches and their summed duration since rtx_kernel_time_reset
+ * (synchronises on the recorded events; call it after the timed region). */
 int rtx_last_kernel_ms(rtx_scene* scene, int which, float* ms);
+int rtx_kernel_time_reset(rtx_scene* scene);
+int rtx_kernel_time_stats(rtx_scene* scene, int which, uint32_t* launches, double* total_ms);
+
+/* Pixel sharding across the GPUs of a node: bands of band_height rows are dealt round-robin
+ * to n_parts devices; this device renders / masks / re-renders only rows y with (y / band_height) % n_parts
+ * == part.  With halo != 0 pass 1 additionally renders the one row above and below every owned band, so
+ * rtx_sobel needs no exchange of pass-1 results.  band_height == 0 restores "all rows" (the default). */
+int rtx_set_row_ownership(rtx_scene* scene, uint32_t band_height, uint32_t n_parts, uint32_t part, int halo);
 
 /* Probe rays (host buffers, synchronous): for each of n rays {orig xyz, dir xyz} runs Render::trace
  * (scene.cpp:724-756) and Render::castRay at depth 0 (scene.cpp:758-946).

@@ -36,7 +36,7 @@ RTX_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_set_view",
     "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_quantize_bgr8", "rtx_render_frame_host",
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
-    "rtx_cast_rays",
+    "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_set_row_ownership",
 ]
 
 
@@ -70,6 +70,9 @@ def load():
     rtx.rtx_last_kernel_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     rtx.rtx_math_probe.argtypes = [i32, i32, u32, vp, vp, vp]
     rtx.rtx_cast_rays.argtypes = [vp, u32, vp, vp, vp]
+    rtx.rtx_kernel_time_reset.argtypes = [vp]
+    rtx.rtx_kernel_time_stats.argtypes = [vp, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    rtx.rtx_set_row_ownership.argtypes = [vp, u32, u32, u32, i32]
     host.rah_scene_load.restype = vp
     host.rah_scene_load.argtypes = [C.c_char_p, C.c_char_p, i32, i32]
     host.rah_scene_free.argtypes = [vp]
@@ -256,6 +259,18 @@ class Scene:
         ms = C.c_float(0)
         _check(self.rtx.rtx_last_kernel_ms(self.gpu(), which, C.byref(ms)), "rtx_last_kernel_ms")
         return ms.value
+
+    def kernel_time_reset(self):
+        _check(self.rtx.rtx_kernel_time_reset(self.gpu()), "rtx_kernel_time_reset")
+
+    def kernel_time_stats(self, which=0):
+        """(launches, total_ms) of kernel `which` (0 pass 1, 1 sobel, 2 ssaa) since kernel_time_reset()."""
+        n, ms = C.c_uint32(0), C.c_double(0)
+        _check(self.rtx.rtx_kernel_time_stats(self.gpu(), which, C.byref(n), C.byref(ms)), "rtx_kernel_time_stats")
+        return n.value, ms.value
+
+    def set_row_ownership(self, band_height, n_parts, part, halo=True):
+        _check(self.rtx.rtx_set_row_ownership(self.gpu(), band_height, n_parts, part, int(halo)), "rtx_set_row_ownership")
 
     def save_bmp(self, fb, name_no_ext):
         fb = np.ascontiguousarray(fb, np.float32)

@@ -60,8 +60,9 @@ struct rtx_scene {
 	uint32_t* work = nullptr;     // [0] pass-1 queue head, [1] ssaa queue head, [2] ssaa list length
 	unsigned long long* counters = nullptr;
 	int blocksPass1 = 0, blocksSsaa = 0;
-	hipEvent_t ev[3][2];
-	bool evValid[3] = { false, false, false };
+	// HIP-event pairs around every launch of {pass 1, sobel, ssaa} since the last rtx_kernel_time_reset
+	std::vector<hipEvent_t> evPool[3];
+	size_t evUsed[3] = { 0, 0, 0 };
 };
 
 namespace {
@@ -89,7 +90,6 @@ int ensureWork(rtx_scene* s)
 		HIPCHK(hipMemset(s->work, 0, 16 * sizeof(uint32_t)));
 		HIPCHK(hipMalloc((void**)&s->counters, 3 * sizeof(unsigned long long)));
 		HIPCHK(hipMemset(s->counters, 0, 3 * sizeof(unsigned long long)));
-		for (int i = 0; i < 3; i++) { HIPCHK(hipEventCreate(&s->ev[i][0])); HIPCHK(hipEventCreate(&s->ev[i][1])); }
 		int b = 0;
 		HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxPass1Kernel<false>, 256, 0));
 		if (b < 1) b = 1;
@@ -112,6 +112,18 @@ int ensureWork(rtx_scene* s)
 	s->params.totalLanes = totalLanes;
 	s->params.workCounter = s->work;
 	s->params.counters = s->counters;
+	return RTX_OK;
+}
+
+// Records an event on `st`; events come in (start, stop) pairs per launch.
+int stamp(rtx_scene* s, int which, hipStream_t st)
+{
+	if (s->evUsed[which] == s->evPool[which].size()) {
+		hipEvent_t e;
+		HIPCHK(hipEventCreate(&e));
+		s->evPool[which].push_back(e);
+	}
+	HIPCHK(hipEventRecord(s->evPool[which][s->evUsed[which]++], st));
 	return RTX_OK;
 }
 
@@ -266,7 +278,7 @@ void rtx_scene_destroy(rtx_scene* s)
 	if (s->list) (void)hipFree(s->list);
 	if (s->work) {
 		(void)hipFree(s->work); (void)hipFree(s->counters);
-		for (int i = 0; i < 3; i++) { (void)hipEventDestroy(s->ev[i][0]); (void)hipEventDestroy(s->ev[i][1]); }
+		for (int i = 0; i < 3; i++) for (hipEvent_t e : s->evPool[i]) (void)hipEventDestroy(e);
 	}
 	delete s;
 }
@@ -302,12 +314,11 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	uint32_t blocks = (uint32_t)s->blocksPass1;
 	const uint32_t wavesNeeded = (p.nTiles + 3) / 4;
 	if (blocks > wavesNeeded) blocks = wavesNeeded ? wavesNeeded : 1;
-	HIPCHK(hipEventRecord(s->ev[0][0], st));
+	if ((rc = stamp(s, 0, st))) return rc;
 	if (s->stats) hipLaunchKernelGGL(rtxPass1Kernel<true>, dim3(blocks), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxPass1Kernel<false>, dim3(blocks), dim3(256), 0, st, p);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(s->ev[0][1], st));
-	s->evValid[0] = true;
+	if ((rc = stamp(s, 0, st))) return rc;
 	return RTX_OK;
 }
 
@@ -320,12 +331,12 @@ int rtx_sobel(rtx_scene* s, const float* fb_dev, uint32_t rowBegin, uint32_t row
 	int rc = ensureWork(s);
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream;
-	HIPCHK(hipEventRecord(s->ev[1][0], st));
+	if ((rc = stamp(s, 1, st))) return rc;
 	dim3 grid((W + 63) / 64, (rowEnd - rowBegin + 3) / 4);
-	hipLaunchKernelGGL(rtxSobelKernel, grid, dim3(256), 0, st, fb_dev, mask_dev, (uint32_t*)nullptr, (uint32_t*)nullptr, W, H, rowBegin, rowEnd);
+	hipLaunchKernelGGL(rtxSobelKernel, grid, dim3(256), 0, st, fb_dev, mask_dev, (uint32_t*)nullptr, (uint32_t*)nullptr, W, H, rowBegin, rowEnd,
+	                   s->params.bandH, s->params.nParts, s->params.part);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(s->ev[1][1], st));
-	s->evValid[1] = true;
+	if ((rc = stamp(s, 1, st))) return rc;
 	return RTX_OK;
 }
 
@@ -340,9 +351,10 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	if ((rc = ensureList(s))) return rc;
 	hipStream_t st = (hipStream_t)stream;
 	HIPCHK(hipMemsetAsync(s->work + 1, 0, 2 * sizeof(uint32_t), st));
-	HIPCHK(hipEventRecord(s->ev[2][0], st));
+	if ((rc = stamp(s, 2, st))) return rc;
 	dim3 grid((W + 63) / 64, (rowEnd - rowBegin + 3) / 4);
-	hipLaunchKernelGGL(rtxMaskListKernel, grid, dim3(256), 0, st, mask_dev, s->list, s->work + 2, W, H, rowBegin, rowEnd);
+	hipLaunchKernelGGL(rtxMaskListKernel, grid, dim3(256), 0, st, mask_dev, s->list, s->work + 2, W, H, rowBegin, rowEnd,
+	                   s->params.bandH, s->params.nParts, s->params.part);
 	HIPCHK(hipGetLastError());
 	Params p = s->params;
 	p.fb = fb_dev;
@@ -352,8 +364,7 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	if (s->stats) hipLaunchKernelGGL(rtxSsaaKernel<true>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxSsaaKernel<false>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(s->ev[2][1], st));
-	s->evValid[2] = true;
+	if ((rc = stamp(s, 2, st))) return rc;
 	return RTX_OK;
 }
 
@@ -421,10 +432,40 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 int rtx_last_kernel_ms(rtx_scene* s, int which, float* ms)
 {
 	if (!s || !ms || which < 0 || which > 2) return fail(RTX_ERR_ARG, "bad argument");
-	if (!s->evValid[which]) return fail(RTX_ERR_ARG, "no such launch recorded yet");
+	const size_t n = s->evUsed[which];
+	if (n < 2) return fail(RTX_ERR_ARG, "no such launch recorded yet");
 	HIPCHK(hipSetDevice(s->device));
-	HIPCHK(hipEventSynchronize(s->ev[which][1]));
-	HIPCHK(hipEventElapsedTime(ms, s->ev[which][0], s->ev[which][1]));
+	HIPCHK(hipEventSynchronize(s->evPool[which][n - 1]));
+	HIPCHK(hipEventElapsedTime(ms, s->evPool[which][n - 2], s->evPool[which][n - 1]));
+	return RTX_OK;
+}
+
+int rtx_kernel_time_reset(rtx_scene* s)
+{
+	if (!s) return fail(RTX_ERR_ARG, "scene is NULL");
+	for (int i = 0; i < 3; i++) s->evUsed[i] = 0;
+	return RTX_OK;
+}
+
+int rtx_kernel_time_stats(rtx_scene* s, int which, uint32_t* launches, double* total_ms)
+{
+	if (!s || !launches || !total_ms || which < 0 || which > 2) return fail(RTX_ERR_ARG, "bad argument");
+	HIPCHK(hipSetDevice(s->device));
+	*launches = 0; *total_ms = 0;
+	for (size_t i = 0; i + 1 < s->evUsed[which]; i += 2) {
+		float ms = 0;
+		HIPCHK(hipEventSynchronize(s->evPool[which][i + 1]));
+		HIPCHK(hipEventElapsedTime(&ms, s->evPool[which][i], s->evPool[which][i + 1]));
+		*total_ms += ms; (*launches)++;
+	}
+	return RTX_OK;
+}
+
+int rtx_set_row_ownership(rtx_scene* s, uint32_t band_height, uint32_t n_parts, uint32_t part, int halo)
+{
+	if (!s) return fail(RTX_ERR_ARG, "scene is NULL");
+	if (band_height != 0 && (n_parts == 0 || part >= n_parts)) return fail(RTX_ERR_ARG, "bad ownership");
+	s->params.bandH = band_height; s->params.nParts = n_parts ? n_parts : 1; s->params.part = part; s->params.halo = halo ? 1u : 0u;
 	return RTX_OK;
 }
 

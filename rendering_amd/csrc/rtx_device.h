@@ -88,6 +88,8 @@ struct Params {
 	// work distribution
 	uint32_t rowBegin, rowEnd;      // pass 1: image rows [rowBegin,rowEnd)
 	uint32_t tilesX, tileRow0, nTiles;
+	// multi-GPU row ownership: row y belongs to this device iff (y / bandH) % nParts == part (bandH == 0: all rows)
+	uint32_t bandH, nParts, part, halo;
 	uint32_t* workCounter;          // persistent-wave work queue head
 	// SSAA work list
 	const uint32_t* ssaaList;       // flagged pixel indices y*W+x

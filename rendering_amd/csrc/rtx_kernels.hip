@@ -645,6 +645,20 @@ __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 
 	return s.col;
 }
 
+// Row ownership for the pixel-sharded multi-GPU path (bands of bandH rows dealt round-robin to nParts devices).
+__device__ __forceinline__ bool rowOwned(uint32_t bandH, uint32_t nParts, uint32_t part, uint32_t y)
+{
+	return bandH == 0 || (y / bandH) % nParts == part;
+}
+// Pass 1 also renders `halo` rows either side of every owned band so the Sobel mask of the owned rows can be
+// computed without exchanging pass-1 results between devices (scene.cpp:554-568 reads a 3x3 neighbourhood).
+__device__ __forceinline__ bool rowRendered(const Params& P, uint32_t y)
+{
+	if (rowOwned(P.bandH, P.nParts, P.part, y)) return true;
+	if (!P.halo) return false;
+	return (y > 0 && rowOwned(P.bandH, P.nParts, P.part, y - 1)) || rowOwned(P.bandH, P.nParts, P.part, y + 1);
+}
+
 __device__ __forceinline__ uint32_t nextWork(uint32_t* counter)
 {
 	uint32_t w = 0;
@@ -679,7 +693,8 @@ __global__ void __launch_bounds__(256) rtxPass1Kernel(const Params P)
 		const uint32_t ty = tile / P.tilesX, tx = tile - ty * P.tilesX;
 		const uint32_t x = tx * 8 + (lane & 7), y = (P.tileRow0 + ty) * 8 + (lane >> 3);
 		// x1/y1 are clamped to W-1/H-1: the last column and row are never rendered (scene.cpp:369-372)
-		const bool valid = x < W - 1 && y < H - 1 && y >= P.rowBegin && y < P.rowEnd;
+		const bool valid = x < W - 1 && y < H - 1 && y >= P.rowBegin && y < P.rowEnd && rowRendered(P, y);
+		if (ballot(valid) == 0) continue;
 		V3 o, d;
 		primaryRay(P, (float)x + 0.5f, (float)y + 0.5f, o, d);
 		const V3 c = castRayWave<STATS>(P, valid, o, d, gl, cnt);
@@ -764,12 +779,13 @@ __global__ void __launch_bounds__(256) rtxProbeKernel(const Params P)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) rtxSobelKernel(const float* __restrict__ fb, uint8_t* __restrict__ mask,
                                                       uint32_t* __restrict__ list, uint32_t* __restrict__ count,
-                                                      uint32_t W, uint32_t H, uint32_t rowBegin, uint32_t rowEnd)
+                                                      uint32_t W, uint32_t H, uint32_t rowBegin, uint32_t rowEnd,
+                                                      uint32_t bandH, uint32_t nParts, uint32_t part)
 {
 	const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
 	const uint32_t y = rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
 	bool flag = false;
-	const bool inImage = x < W && y < rowEnd && y < H;
+	const bool inImage = x < W && y < rowEnd && y < H && rowOwned(bandH, nParts, part, y);
 	if (inImage && x >= 1 && x + 1 < W && y >= 1 && y + 1 < H) {
 		V3 gx = mk(0, 0, 0), gy = mk(0, 0, 0);
 		const float op[3][3] = { { -1, 0, 1 }, { -2, 0, 2 }, { -1, 0, 1 } };
@@ -800,12 +816,12 @@ __global__ void __launch_bounds__(256) rtxSobelKernel(const float* __restrict__ 
 // Builds the SSAA work list from an externally supplied mask (rtx_render_ssaa takes the mask, not the list).
 __global__ void __launch_bounds__(256) rtxMaskListKernel(const uint8_t* __restrict__ mask, uint32_t* __restrict__ list,
                                                          uint32_t* __restrict__ count, uint32_t W, uint32_t H,
-                                                         uint32_t rowBegin, uint32_t rowEnd)
+                                                         uint32_t rowBegin, uint32_t rowEnd, uint32_t bandH, uint32_t nParts, uint32_t part)
 {
 	const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
 	const uint32_t y = rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
 	// the workers only visit x < W-1, y < H-1 (scene.cpp:369-372, 523-525)
-	const bool flag = x + 1 < W && y + 1 < H && y < rowEnd && mask[(size_t)y * W + x] != 0;
+	const bool flag = x + 1 < W && y + 1 < H && y < rowEnd && rowOwned(bandH, nParts, part, y) && mask[(size_t)y * W + x] != 0;
 	const uint64_t m = ballot(flag);
 	if (m) {
 		uint32_t base = 0;
