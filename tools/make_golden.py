@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz from the REAL reference (oracle/_ref/libref_harness.so, built from
+/root/reference by oracle/Makefile).  Runs in the build container only; the vectors are data (inputs +
+expected outputs), nothing of the reference's source travels.
+
+    python tools/make_golden.py
+
+One scene per subprocess: the reference keeps process-global option flags.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# scene, width, height
+SCENES = [
+    ("cfg1_simple_shapes", 128, 128),
+    ("cfg2_smooth_4k", 128, 96),
+    ("cfg2_smooth_25k", 96, 64),
+    ("cfg3_reflective_refractive", 160, 96),
+    ("cfg4_textured_256", 128, 128),
+    ("mixed_materials", 128, 96),
+]
+ASSETS_OF = {
+    "cfg2_smooth_4k": ["bumpy_4k.obj"], "cfg2_smooth_25k": ["bumpy_25k.obj"],
+    "cfg3_reflective_refractive": ["sky_left.bmp", "sky_front.bmp", "sky_right.bmp", "sky_back.bmp", "sky_top.bmp", "sky_bottom.bmp"],
+    "cfg4_textured_256": ["torus_1536.obj", "diffuse_256.bmp", "normal_256.bmp", "specular_256.bmp"],
+    "mixed_materials": ["quad.obj", "bumpy_4k.obj", "torus_1536.obj"], "cfg1_simple_shapes": [],
+}
+
+
+def sha(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def one_scene(name, w, h):
+    from rendering_amd import assets
+    from tests.util_rays import probe_rays
+    from tools import ref_harness as R
+    assets.ensure()
+    s = R.RefScene("scenes/%s.scene" % name, w, h)
+    out = {"width": w, "height": h}
+    scale, aspect, m, pos = s.camera()
+    out["cam_scale"] = np.float32(scale); out["cam_aspect"] = np.float32(aspect); out["cam_matrix"] = m; out["cam_pos"] = pos
+    fb1, st = s.stats(lambda: s.pass1())
+    out["pass1"] = fb1
+    out["pass1_stats"] = st
+    out["ssaa"] = s.ssaa(fb1)     # row 0 / column 0 depend on uninitialised heap in the reference: tests mask them
+    rays = probe_rays(1024)
+    hits, col = s.probe(rays)
+    out["probe_hits"] = hits; out["probe_colours"] = col
+    for i in range(s.n_objects):
+        b = s.bvh(i)
+        if b is None:
+            continue
+        out["bvh%d_counts" % i] = np.array([b["n_nodes"], b["n_leaves"], b["n_refs"], b["max_depth"], b["n_tris"]], np.int64)
+        for k in ("bounds", "skip", "leaf_begin", "leaf_count", "refs", "tris"):
+            out["bvh%d_%s_sha1" % (i, k)] = np.array(sha(b[k]))
+    for li in range(s.n_lights):
+        pts = (rays[:64, 0:3] * 4).astype(np.float32)
+        try:
+            out["illuminate%d" % li] = s.illuminate(li, pts)
+        except Exception:
+            pass
+    if name == "cfg3_reflective_refractive":
+        d = rays[:512, 3:6].copy()
+        d[:6] = np.eye(3, dtype=np.float32).repeat(2, 0) * np.array([1, -1] * 3, np.float32)[:, None]
+        d[6] = [1, 1, 1]; d[7] = [-1, -1, -1]; d[8] = [1, 1, -1]      # ties between faces
+        out["sky_dirs"] = d; out["sky_colours"] = s.skybox(d)
+    out["assets_md5"] = np.array(";".join("%s=%s" % (a, assets.md5(a)) for a in ASSETS_OF[name]))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, w, h, "pass1 stats", st)
+
+
+def units():
+    """Known-answer vectors of the shading helpers, powf and the BMP quantiser."""
+    from tests.util_rays import probe_rays
+    from tools import ref_harness as R
+    rays = probe_rays(512)
+    d = rays[:, 3:6].copy()
+    n = np.roll(rays[:, 3:6], 7, axis=0).copy()
+    n[:8] = [[0, 1, 0], [0, -1, 0], [1, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 0], [0, 0, 0], [0, 2, 0]]
+    d[4] = [0, -1, 0]; d[5] = [0, 1, 0]
+    out = {"d": d, "n": n}
+    out["reflect"] = np.stack([R.reflect(a, b) for a, b in zip(d, n)])
+    for ior in (1.4, 1.0, 0.7, 2.5):
+        out["refract_%g" % ior] = np.stack([R.refract(a, b, ior) for a, b in zip(d, n)])
+        out["fresnel_%g" % ior] = np.array([R.fresnel(a, b, ior) for a, b in zip(d, n)], np.float32)
+    v = np.concatenate([rays[:, 0:3] * 3, np.array([[0, 0, 0], [1e-20, 0, 0], [1e-30, 1e-30, 0], [3e18, 1, 1], [1, 1, 1]], np.float32)])
+    out["normalize_in"] = v.astype(np.float32)
+    out["normalize_out"] = np.stack([R.normalize(a) for a in v.astype(np.float32)])
+    u = (np.arange(4096, dtype=np.float64) + 0.5) / 4096
+    xs = np.concatenate([u, 1 - u * 1e-3, u * 1e-5, [0.0, 1.0, 1.0000001, 2.0, 1e-38, 1e-44]]).astype(np.float32)
+    out["powf_x"] = xs
+    for y in (5.0, 10.0, 2.0, 0.5, 20.0, 64.0, 3.7, 0.0, 1.0):
+        out["powf_y%g" % y] = np.array([R.powf(float(a), y) for a in xs], np.float32)
+    # quantiser / BMP writer: the reference's saveImage on a small frame with special values
+    s = R.RefScene("scenes/cfg1_simple_shapes.scene", 8, 4)
+    fb = np.linspace(-0.25, 1.25, 8 * 4 * 3, dtype=np.float32).reshape(4, 8, 3)
+    fb[0, 0] = [np.nan, np.inf, -np.inf]; fb[0, 1] = [1.0, 0.0, -0.0]; fb[0, 2] = [0.999999, 0.5, 1 / 255]
+    out["quant_fb"] = fb
+    os.makedirs(os.path.join(ROOT, "output"), exist_ok=True)
+    s.save(fb, "output/_golden_quant")
+    out["quant_bmp"] = np.frombuffer(open(os.path.join(ROOT, "output", "_golden_quant.bmp"), "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "units.npz"), **out)
+    print("units ok")
+
+
+def big_digest():
+    """BVH digest + reference-semantics statistics of the north-star scene (synthetic 250k-triangle mesh)."""
+    import json
+    from rendering_amd import assets
+    from tools import ref_harness as R
+    assets.ensure(["bumpy_250k.obj"])
+    s = R.RefScene("scenes/cfg2_smooth_250k.scene", 128, 128)
+    b = s.bvh(1)
+    fb, st = s.stats(lambda: s.pass1())
+    d = {"scene": "cfg2_smooth_250k", "asset_md5": assets.md5("bumpy_250k.obj"),
+         "counts": [b["n_nodes"], b["n_leaves"], b["n_refs"], b["max_depth"], b["n_tris"]],
+         "sha1": {k: sha(b[k]) for k in ("bounds", "skip", "leaf_begin", "leaf_count", "refs", "tris")},
+         "pass1_128x128_stats": [int(x) for x in st], "pass1_128x128_sha1": sha(fb)}
+    json.dump(d, open(os.path.join(GOLD, "cfg2_smooth_250k_digest.json"), "w"), indent=1)
+    print("250k digest", d["counts"], d["pass1_128x128_stats"])
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    os.chdir(ROOT)
+    if len(sys.argv) == 1:
+        for name, w, h in SCENES:
+            subprocess.check_call([sys.executable, __file__, name, str(w), str(h)], stdout=None, stderr=subprocess.DEVNULL)
+        subprocess.check_call([sys.executable, __file__, "units"], stderr=subprocess.DEVNULL)
+        subprocess.check_call([sys.executable, __file__, "big"], stderr=subprocess.DEVNULL)
+    elif sys.argv[1] == "units":
+        units()
+    elif sys.argv[1] == "big":
+        big_digest()
+    else:
+        one_scene(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))
