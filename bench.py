@@ -145,7 +145,9 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s @%dx%d, pass 1%s" % (os.path.basename(args.scene), W, H, " + Sobel-adaptive SSAA" if ssaa else ""),
                    "rays_per_frame": rays_per_frame, "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.BAND, world, ", RCCL gather to rank 0" if world > 1 else ""),
-                   "pass1_ms": round(avg_ms, 3), "ssaa_ms": round(ms2 / max(n2, 1), 3)},
+                   "pass1_ms": round(avg_ms, 3), "ssaa_ms": round(ms2 / max(n2, 1), 3),
+                   "pass1_rays_rank0": int(c1[0]), "ssaa_rays_rank0": int(c2[0]), "ssaa_pixels_rank0": int(mask.sum()),
+                   "ssaa_box_tests": int(c2[1]), "ssaa_tri_tests": int(c2[2])},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "rtxPass1Kernel", "avg_launch_ms": round(avg_ms, 3),

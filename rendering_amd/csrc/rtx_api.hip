@@ -56,8 +56,7 @@ struct rtx_scene {
 	bool stats = false;
 	// lazily sized work buffers
 	float* frames = nullptr; size_t framesBytes = 0;
-	uint32_t* list = nullptr; size_t listCount = 0;
-	uint32_t* work = nullptr;     // [0] pass-1 queue head, [1] ssaa queue head, [2] ssaa list length
+	uint32_t* work = nullptr;     // [0] pass-1 queue head, [1] ssaa queue head, [3] probe queue head
 	unsigned long long* counters = nullptr;
 	int blocksPass1 = 0, blocksSsaa = 0;
 	// HIP-event pairs around every launch of {pass 1, sobel, ssaa} since the last rtx_kernel_time_reset
@@ -88,8 +87,8 @@ int ensureWork(rtx_scene* s)
 	if (!s->work) {
 		HIPCHK(hipMalloc((void**)&s->work, 16 * sizeof(uint32_t)));
 		HIPCHK(hipMemset(s->work, 0, 16 * sizeof(uint32_t)));
-		HIPCHK(hipMalloc((void**)&s->counters, 3 * sizeof(unsigned long long)));
-		HIPCHK(hipMemset(s->counters, 0, 3 * sizeof(unsigned long long)));
+		HIPCHK(hipMalloc((void**)&s->counters, 8 * sizeof(unsigned long long)));
+		HIPCHK(hipMemset(s->counters, 0, 8 * sizeof(unsigned long long)));
 		int b = 0;
 		HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxPass1Kernel<false>, 256, 0));
 		if (b < 1) b = 1;
@@ -124,18 +123,6 @@ int stamp(rtx_scene* s, int which, hipStream_t st)
 		s->evPool[which].push_back(e);
 	}
 	HIPCHK(hipEventRecord(s->evPool[which][s->evUsed[which]++], st));
-	return RTX_OK;
-}
-
-int ensureList(rtx_scene* s)
-{
-	const size_t need = (size_t)s->params.view.width * s->params.view.height;
-	if (need > s->listCount) {
-		if (s->list) HIPCHK(hipFree(s->list));
-		s->list = nullptr; s->listCount = 0;
-		HIPCHK(hipMalloc((void**)&s->list, need * sizeof(uint32_t)));
-		s->listCount = need;
-	}
 	return RTX_OK;
 }
 
@@ -194,7 +181,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 				nd.link = ~m.leaf_count[i]; nd.first = m.leaf_begin[i];
 			}
 		}
-		std::vector<LeafTri> leaf(m.n_refs);
+		std::vector<LeafTri> leaf((size_t)m.n_refs + 2);   // +2: the walk's prefetch may read past the last record
+		memset(leaf.data(), 0, leaf.size() * sizeof(LeafTri));
 		for (uint32_t r = 0; r < m.n_refs; r++) {
 			const uint32_t t = m.refs[r];
 			if (t >= m.n_tris) return bail(fail(RTX_ERR_ARG, "leaf reference out of range"));
@@ -275,7 +263,6 @@ void rtx_scene_destroy(rtx_scene* s)
 	(void)hipDeviceSynchronize();
 	for (void* p : s->owned) (void)hipFree(p);
 	if (s->frames) (void)hipFree(s->frames);
-	if (s->list) (void)hipFree(s->list);
 	if (s->work) {
 		(void)hipFree(s->work); (void)hipFree(s->counters);
 		for (int i = 0; i < 3; i++) for (hipEvent_t e : s->evPool[i]) (void)hipEventDestroy(e);
@@ -333,7 +320,7 @@ int rtx_sobel(rtx_scene* s, const float* fb_dev, uint32_t rowBegin, uint32_t row
 	hipStream_t st = (hipStream_t)stream;
 	if ((rc = stamp(s, 1, st))) return rc;
 	dim3 grid((W + 63) / 64, (rowEnd - rowBegin + 3) / 4);
-	hipLaunchKernelGGL(rtxSobelKernel, grid, dim3(256), 0, st, fb_dev, mask_dev, (uint32_t*)nullptr, (uint32_t*)nullptr, W, H, rowBegin, rowEnd,
+	hipLaunchKernelGGL(rtxSobelKernel, grid, dim3(256), 0, st, fb_dev, mask_dev, W, H, rowBegin, rowEnd,
 	                   s->params.bandH, s->params.nParts, s->params.part);
 	HIPCHK(hipGetLastError());
 	if ((rc = stamp(s, 1, st))) return rc;
@@ -348,19 +335,19 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	if (rowBegin >= rowEnd) return RTX_OK;
 	int rc = ensureWork(s);
 	if (rc) return rc;
-	if ((rc = ensureList(s))) return rc;
 	hipStream_t st = (hipStream_t)stream;
-	HIPCHK(hipMemsetAsync(s->work + 1, 0, 2 * sizeof(uint32_t), st));
+	HIPCHK(hipMemsetAsync(s->work + 1, 0, sizeof(uint32_t), st));
 	if ((rc = stamp(s, 2, st))) return rc;
-	dim3 grid((W + 63) / 64, (rowEnd - rowBegin + 3) / 4);
-	hipLaunchKernelGGL(rtxMaskListKernel, grid, dim3(256), 0, st, mask_dev, s->list, s->work + 2, W, H, rowBegin, rowEnd,
-	                   s->params.bandH, s->params.nParts, s->params.part);
-	HIPCHK(hipGetLastError());
 	Params p = s->params;
 	p.fb = fb_dev;
 	p.workCounter = s->work + 1;
-	p.ssaaList = s->list;
-	p.ssaaCount = s->work + 2;
+	p.ssaaMask = mask_dev;
+	p.rowBegin = rowBegin; p.rowEnd = rowEnd;
+	p.tilesX = (W - 1 + 7) / 8;
+	p.tileRow0 = rowBegin / 8;
+	const uint32_t lastRow = (rowEnd < H - 1 ? rowEnd : H - 1);
+	if (lastRow <= rowBegin) return RTX_OK;
+	p.nTiles = p.tilesX * ((lastRow + 7) / 8 - p.tileRow0);
 	if (s->stats) hipLaunchKernelGGL(rtxSsaaKernel<true>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxSsaaKernel<false>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	HIPCHK(hipGetLastError());
@@ -413,7 +400,7 @@ int rtx_counters_reset(rtx_scene* s)
 	int rc = ensureWork(s);
 	if (rc) return rc;
 	HIPCHK(hipDeviceSynchronize());
-	HIPCHK(hipMemset(s->counters, 0, 3 * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(s->counters, 0, 8 * sizeof(unsigned long long)));
 	return RTX_OK;
 }
 
@@ -423,9 +410,10 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	int rc = ensureWork(s);
 	if (rc) return rc;
 	HIPCHK(hipDeviceSynchronize());
-	unsigned long long c[3];
+	unsigned long long c[8];
 	HIPCHK(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
 	out->rays = c[0]; out->box_tests = c[1]; out->tri_tests = c[2];
+	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] slowest work item %.3f ms, sum of items %.3f ms (100 MHz wall clock)\n", c[3] * 1e-5, c[4] * 1e-5);
 	return RTX_OK;
 }
 

@@ -91,9 +91,7 @@ struct Params {
 	// multi-GPU row ownership: row y belongs to this device iff (y / bandH) % nParts == part (bandH == 0: all rows)
 	uint32_t bandH, nParts, part, halo;
 	uint32_t* workCounter;          // persistent-wave work queue head
-	// SSAA work list
-	const uint32_t* ssaaList;       // flagged pixel indices y*W+x
-	const uint32_t* ssaaCount;
+	const uint8_t* ssaaMask;        // Sobel mask consumed by the SSAA kernel
 	// recursion frames: [slot][field][lane]
 	float* frames;
 	uint32_t totalLanes;

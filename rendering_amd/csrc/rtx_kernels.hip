@@ -26,6 +26,10 @@
 
 using namespace rtxd;
 
+#ifndef RTX_WAVES
+#define RTX_WAVES 8   // target waves per SIMD of the two ray kernels (register budget = 512 / RTX_WAVES VGPRs)
+#endif
+
 namespace {
 
 #define RTX_AS4 __attribute__((address_space(4)))
@@ -267,6 +271,125 @@ __device__ __forceinline__ float attenuation(float intensity, float l2)
 struct Hit { int obj; float t; uint32_t tri; float u, v; };
 struct Counts { unsigned long long rays, box, tri; };
 
+// Software-pipelined scalar loads.  SMEM returns out of order, so lgkmcnt can only be waited down to zero: if
+// the load of the NEXT record is issued before the first use of the CURRENT one, the compiler's wait covers
+// both and nothing overlaps.  opaqueZero() makes the next record's address depend on a dword of the current
+// record (s_and_b32 x, x, 0 -- invisible to the optimiser), which forces the order
+//     wait(current) -> issue(next) -> compute(current)
+// so the next record's latency hides behind the current record's arithmetic (and behind the other waves).
+// The loads stay ordinary IR loads: every s_waitcnt is still placed by the compiler.
+__device__ __forceinline__ uint32_t opaqueZero(uint32_t v)
+{
+	asm("s_and_b32 %0, %0, 0" : "+s"(v));
+	return v;
+}
+
+struct MeshHit { float t, u, v; uint32_t tri; };
+
+// Triangle::rayTriangleIntersect (objects.cpp:59-95) for the lanes in `pass` (passMask = its ballot), triangle
+// record in SGPRs.  The wave leaves a stage as soon as no lane survives it (uniform branch on the lane mask).
+__device__ __forceinline__ void triTest(const u32x16& td, bool pass, uint64_t passMask, bool cull, const V3& o, const V3& d,
+                                        float& bt, float& bu, float& bv, uint32_t& btri, bool& found)
+{
+	const float e1x = F(td[3]), e1y = F(td[4]), e1z = F(td[5]);
+	const float e2x = F(td[6]), e2y = F(td[7]), e2z = F(td[8]);
+	const float px = d.y * e2z - d.z * e2y, py = d.z * e2x - d.x * e2z, pz = d.x * e2y - d.y * e2x;
+	const float det = e1x * px + e1y * py + e1z * pz;
+	// culling on:  reject iff det < 1e-8 (then |det| < 1e-8 is implied);  off: reject iff |det| < 1e-8.
+	// Both compares are false for NaN, exactly like the reference's two ifs (objects.cpp:75-79).
+	const float dd = cull ? det : fabsf(det);
+	const bool c1 = !(dd < RTX_EPS8);
+	const uint64_t m1 = passMask & ballot(c1);
+	if (m1 != 0) {
+		const float inv = 1 / det;
+		const float tx = o.x - F(td[0]), ty = o.y - F(td[1]), tz = o.z - F(td[2]);
+		const float u = (tx * px + ty * py + tz * pz) * inv;
+		const bool c2 = !(u < 0), c3 = !(u > 1);
+		const uint64_t m2 = m1 & ballot(c2) & ballot(c3);
+		if (m2 != 0) {
+			const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+			const float v = (d.x * qx + d.y * qy + d.z * qz) * inv;
+			const bool c4 = !(v < 0), c5 = !(u + v > 1);
+			const uint64_t m3 = m2 & ballot(c4) & ballot(c5);
+			if (m3 != 0) {
+				const float t = (e2x * qx + e2y * qy + e2z * qz) * inv;
+				const bool ok = pass && c1 && c2 && c3 && c4 && c5 && !(t < 0) && (t < bt);     // objects.cpp:91, 623
+				if (ok) { bt = t; bu = u; bv = v; btri = td[9]; found = true; }
+			}
+		}
+	}
+}
+
+// AccelerationStructure::intersectAccelStruct (objects.cpp:587-631) for a whole wave: stackless pre-order walk.
+template <bool STATS>
+__device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shadow, bool cull, const V3& o, const V3& d,
+                                         float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
+                                         float& bt, float& bu, float& bv, uint32_t& btri, bool& found, Counts& cnt)
+{
+	const Node* nodes = uni((const Node*)sloadp(&M->nodes));
+	const LeafTri* leaf = uni((const LeafTri*)sloadp(&M->leaf));
+	const uint32_t nN = uni(sload1(&M->nNodes));
+	bt = kFltMax; bu = 0; bv = 0; btri = 0; found = false;
+	if (nN == 0) return;
+	uint32_t resume = consider ? 0u : kNever;
+	uint32_t i = 0;
+	const uint32_t last = nN - 1;
+	u32x8 nd = sload8(nodes);
+	while (i < nN) {
+		const int32_t link = (int32_t)nd[6];
+		const uint32_t next = uni(i + 1);
+		const uint32_t after = link > 0 ? (uint32_t)link : next;
+		// speculative prefetch of both possible successors (clamped to the array), issued after nd has arrived
+		const uint32_t z = opaqueZero(nd[7]);
+		const u32x8 nxA = sload8(nodes + (next < last ? next : last) + z);
+		u32x8 nxB = nxA;
+		if (after != next) nxB = sload8(nodes + (after < last ? after : last));
+		const bool act = i >= resume;
+		// slab test, objects.cpp:546-567: (bounds[sign] - orig) * invdir per axis, sequential compares
+		const float xlo = (F(nd[0]) - o.x) * ix, xhi = (F(nd[3]) - o.x) * ix;
+		const float ylo = (F(nd[1]) - o.y) * iy, yhi = (F(nd[4]) - o.y) * iy;
+		const float zlo = (F(nd[2]) - o.z) * iz, zhi = (F(nd[5]) - o.z) * iz;
+		float tmin = sx ? xhi : xlo, tmx = sx ? xlo : xhi;
+		const float tymin = sy ? yhi : ylo, tymax = sy ? ylo : yhi;
+		bool fail = (tmin > tymax) || (tymin > tmx);
+		if (tymin > tmin) tmin = tymin;
+		if (tymax < tmx) tmx = tymax;
+		const float tzmin = sz ? zhi : zlo, tzmax = sz ? zlo : zhi;
+		fail = fail || (tmin > tzmax) || (tzmin > tmx);
+		const bool pass = act && !fail;
+		if (act && fail) resume = after;
+		if (STATS) cnt.box += __popcll(ballot(act));
+		const uint64_t m = ballot(pass);
+		if (m == 0) {
+			nd = nxB;
+			i = uni(after);
+			continue;
+		}
+		if (link < 0) {
+			const uint32_t n = (uint32_t)~link;
+			if (STATS) cnt.tri += (unsigned long long)__popcll(m) * n;
+			if (n != 0) {
+				// two records per trip; the record after the leaf's last one may be fetched and ignored (the array
+				// is padded by two records on upload), so the pointer simply advances by 64 bytes per load
+				const LeafTri* p = leaf + nd[7];
+				u32x16 t0 = sload16(p);
+				for (uint32_t k = 0; k < n; k = uni(k + 2)) {
+					const u32x16 t1 = sload16(p + 1 + opaqueZero(t0[9]));
+					triTest(t0, pass, m, cull, o, d, bt, bu, bv, btri, found);
+					p += 2;
+					t0 = sload16(p + opaqueZero(t1[9]));
+					if (k + 1 < n) triTest(t1, pass, m, cull, o, d, bt, bu, bv, btri, found);
+				}
+			}
+			// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is true
+			// for this lane no later triangle or object can change the answer.
+			if (!STATS) { if (shadow && found && bt < tLimit) resume = kNever; }
+		}
+		nd = nxA;
+		i = next;
+	}
+}
+
 template <bool STATS>
 __device__ __forceinline__ void traceWave(const Params& P, bool active, bool shadow, V3 o, V3 d, float tmax,
                                           Hit& h, Counts& cnt)
@@ -288,68 +411,8 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 		if (ballot(consider) == 0) continue;
 		if (type == 3) {
 			const Mesh* M = uni(P.meshes + (int)sload1(&ob->mesh));
-			const Node* nodes = uni((const Node*)sloadp(&M->nodes));
-			const LeafTri* leaf = uni((const LeafTri*)sloadp(&M->leaf));
-			const uint32_t nN = uni(sload1(&M->nNodes));
-			// objects.cpp:587-631 as a stackless pre-order walk
-			uint32_t resume = consider ? 0u : kNever;
-			float bt = kFltMax, bu = 0, bv = 0; uint32_t btri = 0; bool found = false;
-			uint32_t i = 0;
-			while (i < nN) {
-				const u32x8 nd = sload8(nodes + i);
-				const int32_t link = (int32_t)nd[6];
-				const uint32_t after = link > 0 ? (uint32_t)link : i + 1;
-				const bool act = i >= resume;
-				// slab test, objects.cpp:546-567 (sign-indexed bounds, sequential compares)
-				const float bx0 = sx ? F(nd[3]) : F(nd[0]), bx1 = sx ? F(nd[0]) : F(nd[3]);
-				const float by0 = sy ? F(nd[4]) : F(nd[1]), by1 = sy ? F(nd[1]) : F(nd[4]);
-				const float bz0 = sz ? F(nd[5]) : F(nd[2]), bz1 = sz ? F(nd[2]) : F(nd[5]);
-				float tmin = (bx0 - o.x) * ix, tmx = (bx1 - o.x) * ix;
-				const float tymin = (by0 - o.y) * iy, tymax = (by1 - o.y) * iy;
-				bool fail = (tmin > tymax) || (tymin > tmx);
-				if (tymin > tmin) tmin = tymin;
-				if (tymax < tmx) tmx = tymax;
-				const float tzmin = (bz0 - o.z) * iz, tzmax = (bz1 - o.z) * iz;
-				fail = fail || (tmin > tzmax) || (tzmin > tmx);
-				bool pass = act && !fail;
-				if (act && fail) resume = after;
-				if (STATS) cnt.box += __popcll(ballot(act));
-				const uint64_t m = ballot(pass);
-				if (m == 0) { i = uni(after); continue; }
-				if (link < 0) {
-					const uint32_t n = (uint32_t)~link;
-					const uint32_t first = nd[7];
-					if (STATS) cnt.tri += (unsigned long long)__popcll(m) * n;
-					for (uint32_t k = 0; k < n; ++k) {
-						const u32x16 td = sload16(leaf + first + k);
-						// Triangle::rayTriangleIntersect, objects.cpp:59-95
-						const float e1x = F(td[3]), e1y = F(td[4]), e1z = F(td[5]);
-						const float e2x = F(td[6]), e2y = F(td[7]), e2z = F(td[8]);
-						const float px = d.y * e2z - d.z * e2y, py = d.z * e2x - d.x * e2z, pz = d.x * e2y - d.y * e2x;
-						const float det = e1x * px + e1y * py + e1z * pz;
-						bool ok = pass;
-						if (cull) ok = ok && !(det < RTX_EPS8);
-						ok = ok && !(fabsf(det) < RTX_EPS8);
-						if (ballot(ok) == 0) continue;
-						const float inv = 1 / det;
-						const float tx = o.x - F(td[0]), ty = o.y - F(td[1]), tz = o.z - F(td[2]);
-						const float u = (tx * px + ty * py + tz * pz) * inv;
-						ok = ok && !(u < 0 || u > 1);
-						if (ballot(ok) == 0) continue;
-						const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
-						const float v = (d.x * qx + d.y * qy + d.z * qz) * inv;
-						ok = ok && !(v < 0 || u + v > 1);
-						if (ballot(ok) == 0) continue;
-						const float t = (e2x * qx + e2y * qy + e2z * qz) * inv;
-						ok = ok && !(t < 0) && (t < bt);     // objects.cpp:91, 623
-						if (ok) { bt = t; bu = u; bv = v; btri = td[9]; found = true; }
-					}
-					// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is
-					// true for this lane no later triangle or object can change the answer.
-					if (!STATS) { if (shadow && found && bt < h.t) resume = kNever; }
-				}
-				i = uni(i + 1);
-			}
+			float bt, bu, bv; uint32_t btri; bool found;
+			meshWalk<STATS>(M, consider, shadow, cull, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, found, cnt);
 			if (found && bt < h.t) { h.obj = (int)oi; h.t = bt; h.tri = btri; h.u = bu; h.v = bv; }   // scene.cpp:740-745
 		}
 		else {
@@ -681,7 +744,7 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 // Pass 1: Scene::renderWorker over 8x8 pixel tiles (scene.cpp:444-468)
 // ------------------------------------------------------------------------------------------------
 template <bool STATS>
-__global__ void __launch_bounds__(256) rtxPass1Kernel(const Params P)
+__global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 {
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
@@ -697,7 +760,9 @@ __global__ void __launch_bounds__(256) rtxPass1Kernel(const Params P)
 		if (ballot(valid) == 0) continue;
 		V3 o, d;
 		primaryRay(P, (float)x + 0.5f, (float)y + 0.5f, o, d);
+		const unsigned long long t0 = STATS ? wall_clock64() : 0;
 		const V3 c = castRayWave<STATS>(P, valid, o, d, gl, cnt);
+		if (STATS && lane == 0) { atomicMax(P.counters + 3, wall_clock64() - t0); atomicAdd(P.counters + 4, wall_clock64() - t0); }
 		if (valid) {
 			float* px = P.fb + ((size_t)y * W + x) * 3;
 			px[0] = c.x; px[1] = c.y; px[2] = c.z;
@@ -708,36 +773,64 @@ __global__ void __launch_bounds__(256) rtxPass1Kernel(const Params P)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pass 2: SSAAworker (scene.cpp:523-537): 16 flagged pixels x 4 sub-samples per wave
+// Pass 2: SSAAworker (scene.cpp:523-537).  Work item = one 8x8 pixel tile; the flagged pixels of the tile are
+// re-rendered 16 at a time, 4 lanes (= the 4 sub-samples) per pixel, so the 64 rays of a trace stay coherent.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t nthSetBit(uint64_t m, uint32_t n)   // position of the n-th (0-based) set bit
+{
+	uint32_t pos = 0;
+	uint32_t lo = (uint32_t)m, c = __popc(lo);
+	if (n >= c) { pos = 32; n -= c; lo = (uint32_t)(m >> 32); }
+	c = __popc(lo & 0xffffu); if (n >= c) { pos += 16; n -= c; lo >>= 16; }
+	c = __popc(lo & 0xffu); if (n >= c) { pos += 8; n -= c; lo >>= 8; }
+	c = __popc(lo & 0xfu); if (n >= c) { pos += 4; n -= c; lo >>= 4; }
+	c = __popc(lo & 0x3u); if (n >= c) { pos += 2; n -= c; lo >>= 2; }
+	if (n >= (lo & 1u)) pos += 1;
+	return pos;
+}
+
 template <bool STATS>
-__global__ void __launch_bounds__(256) rtxSsaaKernel(const Params P)
+__global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
 {
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
-	const uint32_t W = P.view.width;
-	const uint32_t n = sload1(P.ssaaCount);
-	const uint32_t nWork = (n + 15) / 16;
+	const uint32_t W = P.view.width, H = P.view.height;
 	Counts cnt = { 0, 0, 0 };
 	for (;;) {
+		// work item = (tile, chunk): chunk c re-renders flagged pixels 16c .. 16c+15 of the tile, so the up to four
+		// chunks of a heavy (silhouette) tile run on different waves
 		const uint32_t work = nextWork(P.workCounter);
-		if (work >= nWork) break;
-		const uint32_t item = work * 16 + (lane >> 2), sub = lane & 3;
-		const bool valid = item < n;
-		const uint32_t pix = valid ? P.ssaaList[item] : 0;
-		const uint32_t y = pix / W, x = pix - y * W;
+		if (work >= P.nTiles * 4) break;
+		const uint32_t tile = work >> 2, chunk = work & 3;
+		const uint32_t ty = tile / P.tilesX, tx = tile - ty * P.tilesX;
+		const uint32_t x0 = tx * 8, y0 = (P.tileRow0 + ty) * 8;
+		uint64_t flagged;
+		{
+			const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3);
+			// the workers only visit x < W-1, y < H-1 (scene.cpp:369-372, 523-525)
+			const bool in = x < W - 1 && y < H - 1 && y >= P.rowBegin && y < P.rowEnd && rowOwned(P.bandH, P.nParts, P.part, y);
+			flagged = ballot(in && P.ssaaMask[(size_t)y * W + x] != 0);
+		}
+		const uint32_t nf = (uint32_t)__popcll(flagged);
+		if (nf <= chunk * 16) continue;
+		const uint32_t g = chunk * 16 + (lane >> 2), sub = lane & 3;
+		const bool valid = g < nf;
+		const uint32_t pos = nthSetBit(flagged, valid ? g : 0);
+		const uint32_t x = x0 + (pos & 7), y = y0 + (pos >> 3);
 		// offsets in the reference's order: (.25,.25) (.25,.75) (.75,.25) (.75,.75)  (scene.cpp:527-534)
 		const float fx = (float)x + ((sub & 2) ? 0.75f : 0.25f), fy = (float)y + ((sub & 1) ? 0.75f : 0.25f);
 		V3 o, d;
 		primaryRay(P, fx, fy, o, d);
+		const unsigned long long t0 = STATS ? wall_clock64() : 0;
 		const V3 c = castRayWave<STATS>(P, valid, o, d, gl, cnt);
+		if (STATS && lane == 0) { atomicMax(P.counters + 3, wall_clock64() - t0); atomicAdd(P.counters + 4, wall_clock64() - t0); }
 		// color = 0; color += c0; += c1; += c2; += c3; fb = color / 4
 		const int base = (int)(lane & ~3u);
 		V3 sum = mk(0, 0, 0);
 		for (int k = 0; k < 4; ++k)
 			sum = sum + mk(__shfl(c.x, base + k), __shfl(c.y, base + k), __shfl(c.z, base + k));
 		if (valid && sub == 0) {
-			float* px = P.fb + (size_t)pix * 3;
+			float* px = P.fb + ((size_t)y * W + x) * 3;
 			px[0] = sum.x / 4; px[1] = sum.y / 4; px[2] = sum.z / 4;
 		}
 	}
@@ -775,10 +868,9 @@ __global__ void __launch_bounds__(256) rtxProbeKernel(const Params P)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sobel mask + compaction of the flagged pixels (scene.cpp:547-568)
+// Sobel mask (scene.cpp:547-568)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) rtxSobelKernel(const float* __restrict__ fb, uint8_t* __restrict__ mask,
-                                                      uint32_t* __restrict__ list, uint32_t* __restrict__ count,
                                                       uint32_t W, uint32_t H, uint32_t rowBegin, uint32_t rowEnd,
                                                       uint32_t bandH, uint32_t nParts, uint32_t part)
 {
@@ -802,33 +894,6 @@ __global__ void __launch_bounds__(256) rtxSobelKernel(const float* __restrict__ 
 		flag = val > 0.5f;
 	}
 	if (inImage) mask[(size_t)y * W + x] = flag ? 1 : 0;       // borders are defined as 0 (reference: uninitialised)
-	if (list) {
-		const uint64_t m = ballot(flag);
-		if (m) {
-			uint32_t base = 0;
-			if (__lane_id() == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
-			base = __builtin_amdgcn_readfirstlane(base);
-			if (flag) list[base + __popcll(m & ((1ull << __lane_id()) - 1))] = y * W + x;
-		}
-	}
-}
-
-// Builds the SSAA work list from an externally supplied mask (rtx_render_ssaa takes the mask, not the list).
-__global__ void __launch_bounds__(256) rtxMaskListKernel(const uint8_t* __restrict__ mask, uint32_t* __restrict__ list,
-                                                         uint32_t* __restrict__ count, uint32_t W, uint32_t H,
-                                                         uint32_t rowBegin, uint32_t rowEnd, uint32_t bandH, uint32_t nParts, uint32_t part)
-{
-	const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-	const uint32_t y = rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
-	// the workers only visit x < W-1, y < H-1 (scene.cpp:369-372, 523-525)
-	const bool flag = x + 1 < W && y + 1 < H && y < rowEnd && rowOwned(bandH, nParts, part, y) && mask[(size_t)y * W + x] != 0;
-	const uint64_t m = ballot(flag);
-	if (m) {
-		uint32_t base = 0;
-		if (__lane_id() == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
-		base = __builtin_amdgcn_readfirstlane(base);
-		if (flag) list[base + __popcll(m & ((1ull << __lane_id()) - 1))] = y * W + x;
-	}
 }
 
 // saveImage's quantiser (util.cpp:46-58)
