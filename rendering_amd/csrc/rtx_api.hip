@@ -56,6 +56,7 @@ struct rtx_scene {
 	bool stats = false;
 	// lazily sized work buffers
 	float* frames = nullptr; size_t framesBytes = 0;
+	uint32_t* tileCost = nullptr; uint32_t* items = nullptr; size_t tileCap = 0;   // per-tile pass-1 cost, SSAA work lists
 	uint32_t* work = nullptr;     // [0] pass-1 queue head, [1] ssaa queue head, [3] probe queue head
 	unsigned long long* counters = nullptr;
 	int blocksPass1 = 0, blocksSsaa = 0;
@@ -107,6 +108,18 @@ int ensureWork(rtx_scene* s)
 		HIPCHK(hipMalloc((void**)&s->frames, need));
 		s->framesBytes = need;
 	}
+	const uint32_t txFull = (s->params.view.width + 7) / 8, tyFull = (s->params.view.height + 7) / 8;
+	const size_t tiles = (size_t)txFull * tyFull;
+	if (tiles > s->tileCap) {
+		if (s->tileCost) { HIPCHK(hipFree(s->tileCost)); HIPCHK(hipFree(s->items)); }
+		s->tileCost = nullptr; s->items = nullptr; s->tileCap = 0;
+		HIPCHK(hipMalloc((void**)&s->tileCost, tiles * sizeof(uint32_t)));
+		HIPCHK(hipMalloc((void**)&s->items, tiles * 8 * sizeof(uint32_t)));
+		HIPCHK(hipMemset(s->tileCost, 0, tiles * sizeof(uint32_t)));
+		s->tileCap = tiles;
+	}
+	s->params.tileCost = s->tileCost;
+	s->params.tilesXFull = txFull;
 	s->params.frames = s->frames;
 	s->params.totalLanes = totalLanes;
 	s->params.workCounter = s->work;
@@ -188,7 +201,6 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			if (t >= m.n_tris) return bail(fail(RTX_ERR_ARG, "leaf reference out of range"));
 			const float* p = m.tri_pos + (size_t)t * 9;
 			LeafTri& lt = leaf[r];
-			memset(&lt, 0, sizeof(lt));
 			for (int k = 0; k < 3; k++) {
 				lt.v0[k] = p[k];
 				lt.e1[k] = p[3 + k] - p[k];      // v0v1 = v1 - v0 (objects.cpp:70)
@@ -263,6 +275,7 @@ void rtx_scene_destroy(rtx_scene* s)
 	(void)hipDeviceSynchronize();
 	for (void* p : s->owned) (void)hipFree(p);
 	if (s->frames) (void)hipFree(s->frames);
+	if (s->tileCost) { (void)hipFree(s->tileCost); (void)hipFree(s->items); }
 	if (s->work) {
 		(void)hipFree(s->work); (void)hipFree(s->counters);
 		for (int i = 0; i < 3; i++) for (hipEvent_t e : s->evPool[i]) (void)hipEventDestroy(e);
@@ -337,17 +350,19 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream;
 	HIPCHK(hipMemsetAsync(s->work + 1, 0, sizeof(uint32_t), st));
+	HIPCHK(hipMemsetAsync(s->work + 4, 0, 2 * sizeof(uint32_t), st));
 	if ((rc = stamp(s, 2, st))) return rc;
 	Params p = s->params;
 	p.fb = fb_dev;
 	p.workCounter = s->work + 1;
 	p.ssaaMask = mask_dev;
 	p.rowBegin = rowBegin; p.rowEnd = rowEnd;
-	p.tilesX = (W - 1 + 7) / 8;
-	p.tileRow0 = rowBegin / 8;
-	const uint32_t lastRow = (rowEnd < H - 1 ? rowEnd : H - 1);
-	if (lastRow <= rowBegin) return RTX_OK;
-	p.nTiles = p.tilesX * ((lastRow + 7) / 8 - p.tileRow0);
+	p.nTiles = (uint32_t)s->tileCap >= p.tilesXFull * ((H + 7) / 8) ? p.tilesXFull * ((H + 7) / 8) : 0;
+	p.ssaaItems = s->items;
+	p.ssaaCounts = s->work + 4;
+	// tiles on which pass 1 spent more than 0.25 ms go first (wall clock = 100 MHz)
+	hipLaunchKernelGGL(rtxSsaaListKernel, dim3((p.nTiles + 255) / 256), dim3(256), 0, st, p, s->items, s->work + 4, 25000u);
+	HIPCHK(hipGetLastError());
 	if (s->stats) hipLaunchKernelGGL(rtxSsaaKernel<true>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxSsaaKernel<false>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	HIPCHK(hipGetLastError());

@@ -20,7 +20,8 @@ struct Node {
 };
 static_assert(sizeof(Node) == 32, "node must be one s_load_dwordx8");
 
-// One leaf reference, duplicated per leaf in the reference's DFS-left-first order (objects.cpp:622-629).
+// One leaf reference, duplicated per leaf in the reference's DFS-left-first order (objects.cpp:622-629): one
+// cache-line-aligned 64-byte record = one s_load_dwordx16.
 // e1 = b - a and e2 = c - a are the fp32 differences the reference recomputes per test (objects.cpp:70-71);
 // they are ray-independent, so computing them once on upload is bit-identical.
 struct LeafTri {
@@ -34,7 +35,7 @@ static_assert(sizeof(LeafTri) == 64, "leaf triangle must be one 64-byte line");
 
 struct Mesh {
 	const Node* nodes;
-	const LeafTri* leaf;
+	const LeafTri* leaf;    // nRefs + 2 records (the walk's prefetch may run two records past a leaf)
 	const float* nrm;      // n_tris x 9
 	const float* uv;       // n_tris x 6
 	const float* tb;       // n_tris x 6 (tangent, bitangent) or null
@@ -91,7 +92,11 @@ struct Params {
 	// multi-GPU row ownership: row y belongs to this device iff (y / bandH) % nParts == part (bandH == 0: all rows)
 	uint32_t bandH, nParts, part, halo;
 	uint32_t* workCounter;          // persistent-wave work queue head
-	const uint8_t* ssaaMask;        // Sobel mask consumed by the SSAA kernel
+	const uint8_t* ssaaMask;        // Sobel mask consumed by the SSAA kernels
+	const uint32_t* ssaaItems;      // (tile << 2 | chunk) work items: heavy tiles first ([0,nTiles*4) heavy, then normal)
+	const uint32_t* ssaaCounts;     // [0] heavy items, [1] normal items
+	uint32_t* tileCost;             // pass 1: wall-clock ticks (100 MHz) spent on each 8x8 tile of the frame
+	uint32_t tilesXFull, pad2;      // tiles per row of the whole frame (tileCost indexing)
 	// recursion frames: [slot][field][lane]
 	float* frames;
 	uint32_t totalLanes;

@@ -271,25 +271,22 @@ __device__ __forceinline__ float attenuation(float intensity, float l2)
 struct Hit { int obj; float t; uint32_t tri; float u, v; };
 struct Counts { unsigned long long rays, box, tri; };
 
-// Software-pipelined scalar loads.  SMEM returns out of order, so lgkmcnt can only be waited down to zero: if
-// the load of the NEXT record is issued before the first use of the CURRENT one, the compiler's wait covers
-// both and nothing overlaps.  opaqueZero() makes the next record's address depend on a dword of the current
-// record (s_and_b32 x, x, 0 -- invisible to the optimiser), which forces the order
+// Ordering of scalar loads.  SMEM returns out of order, so lgkmcnt can only be waited down to zero: a load issued
+// before the first use of the previous one is covered by the same wait and nothing overlaps.  after(x, v) is an
+// empty asm that makes x depend on the value v having ARRIVED; deriving the next record's address from it forces
 //     wait(current) -> issue(next) -> compute(current)
-// so the next record's latency hides behind the current record's arithmetic (and behind the other waves).
-// The loads stay ordinary IR loads: every s_waitcnt is still placed by the compiler.
-__device__ __forceinline__ uint32_t opaqueZero(uint32_t v)
+// without emitting an instruction.  The loads stay ordinary IR loads: every s_waitcnt is placed by the compiler.
+template <typename T> __device__ __forceinline__ T after(T x, uint32_t v)
 {
-	asm("s_and_b32 %0, %0, 0" : "+s"(v));
-	return v;
+	asm("" : "+s"(x) : "s"(v));
+	return x;
 }
 
-struct MeshHit { float t, u, v; uint32_t tri; };
-
-// Triangle::rayTriangleIntersect (objects.cpp:59-95) for the lanes in `pass` (passMask = its ballot), triangle
-// record in SGPRs.  The wave leaves a stage as soon as no lane survives it (uniform branch on the lane mask).
-__device__ __forceinline__ void triTest(const u32x16& td, bool pass, uint64_t passMask, bool cull, const V3& o, const V3& d,
-                                        float& bt, float& bu, float& bv, uint32_t& btri, bool& found)
+// Triangle::rayTriangleIntersect (objects.cpp:59-95), triangle record in SGPRs.  Runs with exec = the lanes that
+// passed the leaf's box, so the ballots below are the surviving lanes; the wave leaves a stage as soon as no lane
+// survives it (uniform branch on the lane mask).
+template <bool CULL>
+__device__ __forceinline__ void triTest(const u32x16& td, const V3& o, const V3& d, float& bt, float& bu, float& bv, uint32_t& btri)
 {
 	const float e1x = F(td[3]), e1y = F(td[4]), e1z = F(td[5]);
 	const float e2x = F(td[6]), e2y = F(td[7]), e2z = F(td[8]);
@@ -297,39 +294,36 @@ __device__ __forceinline__ void triTest(const u32x16& td, bool pass, uint64_t pa
 	const float det = e1x * px + e1y * py + e1z * pz;
 	// culling on:  reject iff det < 1e-8 (then |det| < 1e-8 is implied);  off: reject iff |det| < 1e-8.
 	// Both compares are false for NaN, exactly like the reference's two ifs (objects.cpp:75-79).
-	const float dd = cull ? det : fabsf(det);
+	const float dd = CULL ? det : fabsf(det);
 	const bool c1 = !(dd < RTX_EPS8);
-	const uint64_t m1 = passMask & ballot(c1);
-	if (m1 != 0) {
+	if (ballot(c1) != 0) {
 		const float inv = 1 / det;
 		const float tx = o.x - F(td[0]), ty = o.y - F(td[1]), tz = o.z - F(td[2]);
 		const float u = (tx * px + ty * py + tz * pz) * inv;
-		const bool c2 = !(u < 0), c3 = !(u > 1);
-		const uint64_t m2 = m1 & ballot(c2) & ballot(c3);
-		if (m2 != 0) {
+		const bool c2 = c1 && !(u < 0 || u > 1);
+		if (ballot(c2) != 0) {
 			const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
 			const float v = (d.x * qx + d.y * qy + d.z * qz) * inv;
-			const bool c4 = !(v < 0), c5 = !(u + v > 1);
-			const uint64_t m3 = m2 & ballot(c4) & ballot(c5);
-			if (m3 != 0) {
+			const bool c3 = c2 && !(v < 0 || u + v > 1);
+			if (ballot(c3) != 0) {
 				const float t = (e2x * qx + e2y * qy + e2z * qz) * inv;
-				const bool ok = pass && c1 && c2 && c3 && c4 && c5 && !(t < 0) && (t < bt);     // objects.cpp:91, 623
-				if (ok) { bt = t; bu = u; bv = v; btri = td[9]; found = true; }
+				if (c3 && !(t < 0) && (t < bt)) { bt = t; bu = u; bv = v; btri = td[9]; }     // objects.cpp:91, 623
 			}
 		}
 	}
 }
 
 // AccelerationStructure::intersectAccelStruct (objects.cpp:587-631) for a whole wave: stackless pre-order walk.
-template <bool STATS>
-__device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shadow, bool cull, const V3& o, const V3& d,
+// A hit exists iff bt < FLT_MAX on return (the first accepted t is < FLT_MAX by objects.cpp:598,623).
+template <bool STATS, bool CULL>
+__device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shadow, const V3& o, const V3& d,
                                          float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
-                                         float& bt, float& bu, float& bv, uint32_t& btri, bool& found, Counts& cnt)
+                                         float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
 {
 	const Node* nodes = uni((const Node*)sloadp(&M->nodes));
 	const LeafTri* leaf = uni((const LeafTri*)sloadp(&M->leaf));
 	const uint32_t nN = uni(sload1(&M->nNodes));
-	bt = kFltMax; bu = 0; bv = 0; btri = 0; found = false;
+	bt = kFltMax; bu = 0; bv = 0; btri = 0;
 	if (nN == 0) return;
 	uint32_t resume = consider ? 0u : kNever;
 	uint32_t i = 0;
@@ -338,12 +332,11 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 	while (i < nN) {
 		const int32_t link = (int32_t)nd[6];
 		const uint32_t next = uni(i + 1);
-		const uint32_t after = link > 0 ? (uint32_t)link : next;
+		const uint32_t nxt = link > 0 ? (uint32_t)link : next;
 		// speculative prefetch of both possible successors (clamped to the array), issued after nd has arrived
-		const uint32_t z = opaqueZero(nd[7]);
-		const u32x8 nxA = sload8(nodes + (next < last ? next : last) + z);
+		const u32x8 nxA = sload8(after(nodes, nd[7]) + (next < last ? next : last));
 		u32x8 nxB = nxA;
-		if (after != next) nxB = sload8(nodes + (after < last ? after : last));
+		if (nxt != next) nxB = sload8(nodes + (nxt < last ? nxt : last));
 		const bool act = i >= resume;
 		// slab test, objects.cpp:546-567: (bounds[sign] - orig) * invdir per axis, sequential compares
 		const float xlo = (F(nd[0]) - o.x) * ix, xhi = (F(nd[3]) - o.x) * ix;
@@ -357,33 +350,34 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 		const float tzmin = sz ? zhi : zlo, tzmax = sz ? zlo : zhi;
 		fail = fail || (tmin > tzmax) || (tzmin > tmx);
 		const bool pass = act && !fail;
-		if (act && fail) resume = after;
+		if (act && fail) resume = nxt;
 		if (STATS) cnt.box += __popcll(ballot(act));
 		const uint64_t m = ballot(pass);
 		if (m == 0) {
 			nd = nxB;
-			i = uni(after);
+			i = uni(nxt);
 			continue;
 		}
 		if (link < 0) {
 			const uint32_t n = (uint32_t)~link;
 			if (STATS) cnt.tri += (unsigned long long)__popcll(m) * n;
-			if (n != 0) {
-				// two records per trip; the record after the leaf's last one may be fetched and ignored (the array
-				// is padded by two records on upload), so the pointer simply advances by 64 bytes per load
+			if (n != 0 && pass) {
+				// exec = the lanes that passed this leaf's box.  Two records per trip; the records after the leaf's
+				// last one may be fetched and ignored (the array is padded by two records on upload).
 				const LeafTri* p = leaf + nd[7];
+				const LeafTri* const pe = p + n;
 				u32x16 t0 = sload16(p);
-				for (uint32_t k = 0; k < n; k = uni(k + 2)) {
-					const u32x16 t1 = sload16(p + 1 + opaqueZero(t0[9]));
-					triTest(t0, pass, m, cull, o, d, bt, bu, bv, btri, found);
+				do {
+					const u32x16 t1 = sload16(after(p, t0[9]) + 1);
+					triTest<CULL>(t0, o, d, bt, bu, bv, btri);
+					t0 = sload16(after(p, t1[9]) + 2);
+					if (p + 1 < pe) triTest<CULL>(t1, o, d, bt, bu, bv, btri);
 					p += 2;
-					t0 = sload16(p + opaqueZero(t1[9]));
-					if (k + 1 < n) triTest(t1, pass, m, cull, o, d, bt, bu, bv, btri, found);
-				}
+				} while (p < pe);
 			}
 			// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is true
 			// for this lane no later triangle or object can change the answer.
-			if (!STATS) { if (shadow && found && bt < tLimit) resume = kNever; }
+			if (!STATS) { if (shadow && bt < tLimit) resume = kNever; }
 		}
 		nd = nxA;
 		i = next;
@@ -396,7 +390,7 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 {
 	h.obj = -1; h.t = tmax; h.tri = 0; h.u = 0; h.v = 0;
 	if (STATS) cnt.rays += __popcll(ballot(active));
-	const bool cull = (P.view.flags & 1u) != 0;
+	const bool cull = (uni(P.view.flags) & 1u) != 0;
 	// AccelerationStructure::intersectBox's per-ray part (objects.cpp:543-544), hoisted out of the walk
 	const float ix = 1 / d.x, iy = 1 / d.y, iz = 1 / d.z;
 	const bool sx = ix < 0, sy = iy < 0, sz = iz < 0;
@@ -411,9 +405,10 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 		if (ballot(consider) == 0) continue;
 		if (type == 3) {
 			const Mesh* M = uni(P.meshes + (int)sload1(&ob->mesh));
-			float bt, bu, bv; uint32_t btri; bool found;
-			meshWalk<STATS>(M, consider, shadow, cull, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, found, cnt);
-			if (found && bt < h.t) { h.obj = (int)oi; h.t = bt; h.tri = btri; h.u = bu; h.v = bv; }   // scene.cpp:740-745
+			float bt, bu, bv; uint32_t btri;
+			if (cull) meshWalk<STATS, true>(M, consider, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+			else meshWalk<STATS, false>(M, consider, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+			if (bt < kFltMax && bt < h.t) { h.obj = (int)oi; h.t = bt; h.tri = btri; h.u = bu; h.v = bv; }   // scene.cpp:740-745
 		}
 		else {
 			const V3 c = mk(sloadf(&ob->pos[0]), sloadf(&ob->pos[1]), sloadf(&ob->pos[2]));
@@ -753,23 +748,27 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 	for (;;) {
 		const uint32_t tile = nextWork(P.workCounter);
 		if (tile >= P.nTiles) break;
-		const uint32_t ty = tile / P.tilesX, tx = tile - ty * P.tilesX;
-		const uint32_t x = tx * 8 + (lane & 7), y = (P.tileRow0 + ty) * 8 + (lane >> 3);
+		const uint32_t ty0 = tile / P.tilesX, tx = tile - ty0 * P.tilesX, ty = P.tileRow0 + ty0;
+		const uint32_t x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
 		// x1/y1 are clamped to W-1/H-1: the last column and row are never rendered (scene.cpp:369-372)
 		const bool valid = x < W - 1 && y < H - 1 && y >= P.rowBegin && y < P.rowEnd && rowRendered(P, y);
 		if (ballot(valid) == 0) continue;
 		V3 o, d;
 		primaryRay(P, (float)x + 0.5f, (float)y + 0.5f, o, d);
-		const unsigned long long t0 = STATS ? wall_clock64() : 0;
+		const unsigned long long t0 = wall_clock64();
 		const V3 c = castRayWave<STATS>(P, valid, o, d, gl, cnt);
-		if (STATS && lane == 0) { atomicMax(P.counters + 3, wall_clock64() - t0); atomicAdd(P.counters + 4, wall_clock64() - t0); }
+		const unsigned long long dt = wall_clock64() - t0;
+		if (lane == 0) {
+			// remembered per tile: the SSAA pass starts with the tiles that were expensive here (longest job first)
+			P.tileCost[ty * P.tilesXFull + tx] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
+			if (STATS) { atomicMax(P.counters + 3, dt); atomicAdd(P.counters + 4, dt); }
+		}
 		if (valid) {
 			float* px = P.fb + ((size_t)y * W + x) * 3;
 			px[0] = c.x; px[1] = c.y; px[2] = c.z;
 		}
 	}
 	if (STATS) flushCounts(P, cnt);
-	else if (lane == 0 && P.counters) { /* rays are counted by the STATS variant only */ }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -797,13 +796,15 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
 	const uint32_t W = P.view.width, H = P.view.height;
 	Counts cnt = { 0, 0, 0 };
 	for (;;) {
-		// work item = (tile, chunk): chunk c re-renders flagged pixels 16c .. 16c+15 of the tile, so the up to four
-		// chunks of a heavy (silhouette) tile run on different waves
+		// work item = (tile, chunk) from the list built by rtxSsaaListKernel: chunk c re-renders flagged pixels
+		// 16c .. 16c+15 of the tile; tiles that were expensive in pass 1 come first (longest-job-first)
 		const uint32_t work = nextWork(P.workCounter);
-		if (work >= P.nTiles * 4) break;
-		const uint32_t tile = work >> 2, chunk = work & 3;
-		const uint32_t ty = tile / P.tilesX, tx = tile - ty * P.tilesX;
-		const uint32_t x0 = tx * 8, y0 = (P.tileRow0 + ty) * 8;
+		const uint32_t nHeavy = sload1(P.ssaaCounts), nNormal = sload1(P.ssaaCounts + 1);
+		if (work >= nHeavy + nNormal) break;
+		const uint32_t item = work < nHeavy ? P.ssaaItems[work] : P.ssaaItems[(size_t)P.nTiles * 4 + (work - nHeavy)];
+		const uint32_t tile = uni(item) >> 2, chunk = uni(item) & 3;
+		const uint32_t ty = tile / P.tilesXFull, tx = tile - ty * P.tilesXFull;
+		const uint32_t x0 = tx * 8, y0 = ty * 8;
 		uint64_t flagged;
 		{
 			const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3);
@@ -812,7 +813,6 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
 			flagged = ballot(in && P.ssaaMask[(size_t)y * W + x] != 0);
 		}
 		const uint32_t nf = (uint32_t)__popcll(flagged);
-		if (nf <= chunk * 16) continue;
 		const uint32_t g = chunk * 16 + (lane >> 2), sub = lane & 3;
 		const bool valid = g < nf;
 		const uint32_t pos = nthSetBit(flagged, valid ? g : 0);
@@ -835,6 +835,43 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
 		}
 	}
 	if (STATS) flushCounts(P, cnt);
+}
+
+// Builds the SSAA work list: one thread per 8x8 tile counts the tile's flagged pixels and appends one item per
+// started group of 16 to the heavy or the normal list (heavy = pass 1 spent more than `heavyTicks` on the tile).
+__global__ void __launch_bounds__(256) rtxSsaaListKernel(const Params P, uint32_t* __restrict__ items,
+                                                         uint32_t* __restrict__ counts, uint32_t heavyTicks)
+{
+	const uint32_t W = P.view.width, H = P.view.height;
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t tilesY = (H + 7) / 8;
+	const bool inGrid = t < P.tilesXFull * tilesY;
+	const uint32_t ty = t / P.tilesXFull, tx = t - ty * P.tilesXFull;
+	uint32_t nf = 0;
+	if (inGrid) {
+		for (uint32_t r = 0; r < 8; ++r) {
+			const uint32_t y = ty * 8 + r;
+			// the workers only visit x < W-1, y < H-1 (scene.cpp:369-372, 523-525)
+			if (!(y < H - 1 && y >= P.rowBegin && y < P.rowEnd && rowOwned(P.bandH, P.nParts, P.part, y))) continue;
+			for (uint32_t c = 0; c < 8; ++c) {
+				const uint32_t x = tx * 8 + c;
+				if (x < W - 1 && P.ssaaMask[(size_t)y * W + x] != 0) nf++;
+			}
+		}
+	}
+	const uint32_t chunks = (nf + 15) / 16;
+	const bool heavy = inGrid && P.tileCost[t] > heavyTicks;
+	for (uint32_t c = 0; c < 4; ++c) {
+		for (int h = 0; h < 2; ++h) {
+			const bool mine = chunks > c && (heavy ? h == 0 : h == 1);
+			const uint64_t m = ballot(mine);
+			if (m == 0) continue;
+			uint32_t base = 0;
+			if (__lane_id() == 0) base = atomicAdd(counts + h, (uint32_t)__popcll(m));
+			base = __builtin_amdgcn_readfirstlane(base);
+			if (mine) items[(size_t)h * P.nTiles * 4 + base + __popcll(m & ((1ull << __lane_id()) - 1))] = (t << 2) | c;
+		}
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
