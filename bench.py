@@ -24,28 +24,57 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def cpu_baseline(scene_path, width, height, gpu_scene):
-    """Oracle (CPU restatement, thread per 128x128 tile, all host cores) on a bounded sample of the SAME frame:
-    every 8th 32-row band (1/8 of the rows, spread over the whole image).  Rays of those rows are counted by the
-    instrumented GPU kernel (tests prove the counts identical to the oracle's)."""
+def cpu_baseline(scene_path, width, height, gpu_scene, target_s=15.0):
+    """Oracle (CPU restatement: same exhaustive BVH walk, thread per 128x128 tile, all host cores) on a bounded
+    sample of the SAME frame: 32-row bands spread evenly over the image, as many as fit ~target_s seconds
+    (the whole frame when the host is fast enough).  The rays of the sampled rows are counted by the
+    instrumented GPU kernel (tests/test_gpu_parity.py proves those counts identical to the oracle's)."""
     from oracle import oracle as O
-    bands = [(y, min(y + 32, height)) for y in range(0, height, 256)]
     o = O.OracleScene(scene_path, width, height)
+    band = 32
+    all_bands = [(y, min(y + band, height)) for y in range(0, height, band)]
+    # probe: every 32nd band
+    probe = all_bands[::32]
     ms = 0.0
-    for y0, y1 in bands:
+    for y0, y1 in probe:
         o.pass1(rows=(y0, y1))
         ms += o.last_ms
+    est_full = ms * 1e-3 * len(all_bands) / max(len(probe), 1)
+    stride = max(1, int(round(est_full / target_s)))
+    bands = all_bands[::stride]
+    ms = 0.0
+    if stride == 1:
+        o.pass1()
+        ms = o.last_ms
+    else:
+        for y0, y1 in bands:
+            o.pass1(rows=(y0, y1))
+            ms += o.last_ms
     fb = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
     gpu_scene.set_row_ownership(0, 1, 0, False)
     gpu_scene.counters_enable(True)
     gpu_scene.counters_reset()
-    for y0, y1 in bands:
-        gpu_scene.render_pass1(fb, rows=(y0, y1))
+    if stride == 1:
+        gpu_scene.render_pass1(fb)
+    else:
+        for y0, y1 in bands:
+            gpu_scene.render_pass1(fb, rows=(y0, y1))
     rays = int(gpu_scene.counters()[0])
     gpu_scene.counters_enable(False)
     cores = os.cpu_count() or 1
+    what = "whole frame" if stride == 1 else "%d of %d 32-row bands (every %d-th)" % (len(bands), len(all_bands), stride)
     return {"value": round(rays / (ms * 1e-3) / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "pass 1 of %d x 32-row bands (1/8 of the %dx%d frame, %d rays) in %.1f s" % (len(bands), width, height, rays, ms * 1e-3)}
+            "sample": "pass 1 (Scene::launchWorkers) of the %dx%d frame, %s: %d rays in %.1f s" % (width, height, what, rays, ms * 1e-3)}
+
+
+def measured_traffic():
+    """HBM bytes per pass-1 launch from a separate rocprofv3 --pmc run of this same command (tools/pmc.sh,
+    FETCH_SIZE and WRITE_SIZE in separate passes, KB -> bytes); committed under profiles/.  None if absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pass1_traffic.json")))
+        return int(d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def main():
@@ -149,7 +178,7 @@ def main():
                    "pass1_rays_rank0": int(c1[0]), "ssaa_rays_rank0": int(c2[0]), "ssaa_pixels_rank0": int(mask.sum()),
                    "ssaa_box_tests": int(c2[1]), "ssaa_tri_tests": int(c2[2])},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
                      "kernel": "rtxPass1Kernel", "avg_launch_ms": round(avg_ms, 3),
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "box_tests": int(c1[1]), "tri_tests": int(c1[2])},

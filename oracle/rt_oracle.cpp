@@ -1345,7 +1345,8 @@ void orc_normalize(const float* v, float* out)
 void orc_illuminate(const orc_scene* s, int li, const float* p, float* o)
 {
 	V3 L, I; float dist = 0;
-	illuminate(*s->lights[li], v3(p[0], p[1], p[2]), L, I, dist);
+	// AreaLight::illuminate is not callable in the reference (lights.cpp:65-69): outputs stay zero
+	if (s->lights[li]->type != LIGHT_AREA) illuminate(*s->lights[li], v3(p[0], p[1], p[2]), L, I, dist);
 	o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = I.x; o[4] = I.y; o[5] = I.z; o[6] = dist; o[7] = 0;
 }
 float orc_powf(float x, float y) { return powfRestated(x, y); }

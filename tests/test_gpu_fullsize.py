@@ -1,0 +1,134 @@
+"""Full-size (BASELINE.json) checks of the HIP path through size-independent properties, plus oracle spot
+checks on row bands the CPU finishes in seconds.  All through the C ABI, device-resident framebuffers."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def render(torch, scene, ssaa=True, parts=1, part=0, band=64):
+    H, W = scene.height, scene.width
+    fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    mask = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    scene.set_row_ownership(band if parts > 1 else 0, parts, part, True)
+    scene.render_pass1(fb)
+    if ssaa:
+        scene.sobel(fb, mask)
+        scene.render_ssaa(mask, fb)
+    torch.cuda.synchronize()
+    scene.set_row_ownership(0, 1, 0, False)
+    return fb, mask
+
+
+def test_north_star_4096_sharding_equals_whole_frame(ra, torch_cuda):
+    """250k-triangle scene at 4096x4096 (the headline workload): rows dealt to 2 and to 8 parts (64-row bands,
+    halo recomputed) assemble to exactly the unsharded frame, pass 1 + Sobel + SSAA; and the frame is deterministic."""
+    from rendering_amd import assets, parallel
+    torch = torch_cuda
+    assets.ensure(["bumpy_250k.obj"])
+    g = ra.Scene("scenes/cfg2_smooth_250k.scene", 4096, 4096)
+    full, _ = render(torch, g)
+    again, _ = render(torch, g)
+    assert torch.equal(full.view(torch.int32), again.view(torch.int32))
+    assert not full[-1].any() and not full[:, -1].any()          # last row / column never rendered
+    for parts in (2, 8):
+        acc = torch.zeros_like(full)
+        for part in range(parts):
+            fb, _ = render(torch, g, parts=parts, part=part)
+            rows = torch.as_tensor(parallel.owned_rows(4096, 64, parts, part), device="cuda")
+            acc.index_copy_(0, rows, fb.index_select(0, rows))
+        assert torch.equal(full.view(torch.int32), acc.view(torch.int32)), "%d-way sharded frame differs" % parts
+
+
+def test_north_star_4096_oracle_bands(ra, oracle, torch_cuda):
+    """Same frame against the CPU oracle on 8-row bands through the silhouette, the poles and the floor."""
+    torch = torch_cuda
+    g = ra.Scene("scenes/cfg2_smooth_250k.scene", 4096, 4096)
+    fb, _ = render(torch, g, ssaa=False)
+    got = fb.cpu().numpy()
+    o = oracle.OracleScene("scenes/cfg2_smooth_250k.scene", 4096, 4096)
+    for y0 in (8, 1000, 1180, 2048, 2900, 3400, 4080):
+        ref = o.pass1(rows=(y0, y0 + 8))
+        assert np.array_equal(bits(ref[y0:y0 + 8]), bits(got[y0:y0 + 8])), "rows %d..%d" % (y0, y0 + 8)
+
+
+def test_cfg2_1080p_and_cfg3_oracle_full_frame(ra, oracle, torch_cuda):
+    """BASELINE cfg3 at its full 1920x1080 (recursive reflect/refract + skybox, depth 5): whole frame vs oracle."""
+    torch = torch_cuda
+    g = ra.Scene("scenes/cfg3_reflective_refractive.scene")
+    assert (g.width, g.height) == (1920, 1080)
+    fb, _ = render(torch, g)
+    o = oracle.OracleScene("scenes/cfg3_reflective_refractive.scene")
+    ref = o.ssaa(o.pass1())
+    assert np.array_equal(bits(ref), bits(fb.cpu().numpy()))
+
+
+def test_cfg4_textured_4096_rmse_and_bands(ra, oracle, torch_cuda):
+    """BASELINE cfg4 (diffuse + normal + specular maps, Phong, rotated mesh) at 4096x4096: row bands against the
+    oracle.  The reference itself is only reproducible to ~1 ULP here (normal-map race); the oracle
+    defines the lookup deterministically, and against it the HIP path is still bit-exact."""
+    torch = torch_cuda
+    from rendering_amd import assets
+    assets.ensure()
+    g = ra.Scene("scenes/cfg4_textured_1024.scene")
+    assert (g.width, g.height) == (4096, 4096)
+    fb, _ = render(torch, g, ssaa=False)
+    got = fb.cpu().numpy()
+    o = oracle.OracleScene("scenes/cfg4_textured_1024.scene")
+    for y0 in (1024, 2040, 2600):
+        ref = o.pass1(rows=(y0, y0 + 16))
+        d = ref[y0:y0 + 16].astype(np.float64) - got[y0:y0 + 16].astype(np.float64)
+        assert np.sqrt((d * d).mean()) <= 1e-4
+        assert np.array_equal(bits(ref[y0:y0 + 16]), bits(got[y0:y0 + 16]))
+
+
+def test_quantize_kernel_matches_bmp_writer(ra, oracle, torch_cuda):
+    torch = torch_cuda
+    g = ra.Scene("scenes/cfg1_simple_shapes.scene", 512, 512)
+    fb, _ = render(torch, g)
+    fb[0, 0] = torch.tensor([float("nan"), float("inf"), -1.0])
+    out = torch.zeros(512 * 512 * 3, dtype=torch.uint8, device="cuda")
+    g.quantize(fb, out)
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == oracle.encode_bmp(fb.cpu().numpy())[54:]
+
+
+def test_ragged_sizes_and_row_ranges(ra, oracle, torch_cuda):
+    """Width/height that are not multiples of the 8x8 wave tile, and arbitrary row ranges of rtx_render_pass1."""
+    torch = torch_cuda
+    g = ra.Scene("scenes/mixed_materials.scene", 316, 203)
+    o = oracle.OracleScene("scenes/mixed_materials.scene", 316, 203)
+    ref = o.pass1()
+    fb = torch.zeros((203, 316, 3), dtype=torch.float32, device="cuda")
+    for r0, r1 in ((0, 13), (13, 100), (100, 101), (101, 203)):
+        g.render_pass1(fb, rows=(r0, r1))
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(ref), bits(fb.cpu().numpy()))
+    fb.zero_()
+    g.render_pass1(fb, rows=(50, 60))
+    torch.cuda.synchronize()
+    got = fb.cpu().numpy()
+    assert not got[:50].any() and not got[60:].any() and np.array_equal(bits(ref[50:60]), bits(got[50:60]))
+
+
+def test_error_paths(ra):
+    import ctypes as C
+    rtx, _ = ra.load()
+    assert rtx.rtx_scene_create(None, 0, None) == -1                    # RTX_ERR_ARG
+    assert b"NULL" in rtx.rtx_last_error()
+    assert rtx.rtx_render_pass1(None, 0, 1, None, None) == -1
+    g = ra.Scene("scenes/cfg1_simple_shapes.scene", 64, 64)
+    with pytest.raises(ra.RtxError):
+        g.last_kernel_ms(1)                                             # nothing launched yet
+    assert rtx.rtx_set_row_ownership(g.gpu(), 64, 2, 5, 1) == -1       # part >= n_parts

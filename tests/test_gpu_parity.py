@@ -18,6 +18,7 @@ BITEXACT = [
     ("cfg2_smooth_25k", 200, 160),
     ("mixed_materials", 320, 240),
     ("cfg4_textured_256", 256, 256),
+    ("area_light", 320, 240),
 ]
 
 
@@ -54,7 +55,7 @@ def test_cfg1_bmp_md5_matches_reference_cli(ra, oracle):
 
 
 @pytest.mark.parametrize("name", ["cfg1_simple_shapes", "cfg2_smooth_4k", "mixed_materials", "cfg4_textured_256",
-                                  "cfg3_reflective_refractive"])
+                                  "cfg3_reflective_refractive", "area_light"])
 def test_probe_rays_bit_exact(ra, oracle, name):
     """4k pseudo-random + grazing rays: hit record {hit, object, triangle, t, u, v} and castRay colour."""
     from tests.util_rays import probe_rays

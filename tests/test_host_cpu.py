@@ -38,7 +38,7 @@ def test_no_gpu_fails_loudly(ra):
 
 
 @pytest.mark.parametrize("name", ["cfg1_simple_shapes", "cfg2_smooth_4k", "cfg2_smooth_25k", "cfg3_reflective_refractive",
-                                  "cfg4_textured_256", "mixed_materials"])
+                                  "cfg4_textured_256", "mixed_materials", "area_light"])
 def test_host_loader_and_bvh_match_reference_golden(ra, name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     w, h = int(g["width"]), int(g["height"])
