@@ -88,8 +88,8 @@ int ensureWork(rtx_scene* s)
 	if (!s->work) {
 		HIPCHK(hipMalloc((void**)&s->work, 16 * sizeof(uint32_t)));
 		HIPCHK(hipMemset(s->work, 0, 16 * sizeof(uint32_t)));
-		HIPCHK(hipMalloc((void**)&s->counters, 8 * sizeof(unsigned long long)));
-		HIPCHK(hipMemset(s->counters, 0, 8 * sizeof(unsigned long long)));
+		HIPCHK(hipMalloc((void**)&s->counters, 16 * sizeof(unsigned long long)));
+		HIPCHK(hipMemset(s->counters, 0, 16 * sizeof(unsigned long long)));
 		int b = 0;
 		HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxPass1Kernel<false>, 256, 0));
 		if (b < 1) b = 1;
@@ -415,7 +415,7 @@ int rtx_counters_reset(rtx_scene* s)
 	int rc = ensureWork(s);
 	if (rc) return rc;
 	HIPCHK(hipDeviceSynchronize());
-	HIPCHK(hipMemset(s->counters, 0, 8 * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(s->counters, 0, 16 * sizeof(unsigned long long)));
 	return RTX_OK;
 }
 
@@ -425,10 +425,11 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	int rc = ensureWork(s);
 	if (rc) return rc;
 	HIPCHK(hipDeviceSynchronize());
-	unsigned long long c[8];
+	unsigned long long c[16];
 	HIPCHK(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
 	out->rays = c[0]; out->box_tests = c[1]; out->tri_tests = c[2];
 	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] slowest work item %.3f ms, sum of items %.3f ms (100 MHz wall clock)\n", c[3] * 1e-5, c[4] * 1e-5);
+	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] wave-level: node visits %llu, triangle iterations %llu (lane utilisation %.3f), reached u-stage %llu, division %llu, v-stage %llu\n", c[5], c[6], c[6] ? (double)c[2] / (64.0 * c[6]) : 0.0, c[7], c[8], c[9]);
 	return RTX_OK;
 }
 

@@ -269,7 +269,7 @@ __device__ __forceinline__ float attenuation(float intensity, float l2)
 // Render::trace for a whole wave (scene.cpp:724-756)
 // ------------------------------------------------------------------------------------------------
 struct Hit { int obj; float t; uint32_t tri; float u, v; };
-struct Counts { unsigned long long rays, box, tri; };
+struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4; };
 
 // Ordering of scalar loads.  SMEM returns out of order, so lgkmcnt can only be waited down to zero: a load issued
 // before the first use of the previous one is covered by the same wait and nothing overlaps.  after(x, v) is an
@@ -283,10 +283,11 @@ template <typename T> __device__ __forceinline__ T after(T x, uint32_t v)
 }
 
 // Triangle::rayTriangleIntersect (objects.cpp:59-95), triangle record in SGPRs.  Runs with exec = the lanes that
-// passed the leaf's box, so the ballots below are the surviving lanes; the wave leaves a stage as soon as no lane
-// survives it (uniform branch on the lane mask).
-template <bool CULL>
-__device__ __forceinline__ void triTest(const u32x16& td, const V3& o, const V3& d, float& bt, float& bu, float& bv, uint32_t& btri)
+// passed the leaf's box, so every ballot below is already restricted to them; the wave leaves a stage as soon as
+// no lane survives it (uniform branch on the lane mask).  Ballots are taken of the raw compares and combined with
+// scalar mask arithmetic (a ballot of a compound bool costs two extra VALU instructions).
+template <bool CULL, bool STATS>
+__device__ __forceinline__ void triTest(const u32x16& td, const V3& o, const V3& d, float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
 {
 	const float e1x = F(td[3]), e1y = F(td[4]), e1z = F(td[5]);
 	const float e2x = F(td[6]), e2y = F(td[7]), e2z = F(td[8]);
@@ -295,22 +296,35 @@ __device__ __forceinline__ void triTest(const u32x16& td, const V3& o, const V3&
 	// culling on:  reject iff det < 1e-8 (then |det| < 1e-8 is implied);  off: reject iff |det| < 1e-8.
 	// Both compares are false for NaN, exactly like the reference's two ifs (objects.cpp:75-79).
 	const float dd = CULL ? det : fabsf(det);
-	const bool c1 = !(dd < RTX_EPS8);
-	if (ballot(c1) != 0) {
-		const float inv = 1 / det;
-		const float tx = o.x - F(td[0]), ty = o.y - F(td[1]), tz = o.z - F(td[2]);
-		const float u = (tx * px + ty * py + tz * pz) * inv;
-		const bool c2 = c1 && !(u < 0 || u > 1);
-		if (ballot(c2) != 0) {
-			const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
-			const float v = (d.x * qx + d.y * qy + d.z * qz) * inv;
-			const bool c3 = c2 && !(v < 0 || u + v > 1);
-			if (ballot(c3) != 0) {
-				const float t = (e2x * qx + e2y * qy + e2z * qz) * inv;
-				if (c3 && !(t < 0) && (t < bt)) { bt = t; bu = u; bv = v; btri = td[9]; }     // objects.cpp:91, 623
-			}
-		}
+	const uint64_t m1 = ballot(!(dd < RTX_EPS8));
+	if (STATS) cnt.wTri++;
+	if (m1 == 0) return;
+	if (STATS) cnt.wS2++;
+	const float tx = o.x - F(td[0]), ty = o.y - F(td[1]), tz = o.z - F(td[2]);
+	const float nu = tx * px + ty * py + tz * pz;
+	if (CULL) {
+		// Exact-safe rejection before the IEEE division.  Here 1e-8 <= det, so inv = RN(1/det) > 0 and
+		// u = RN(nu * inv).  For det < 2^100 (inv >= 2^-100, normal):
+		//   nu < -2^-20            =>  nu*inv <= -2^-120, no underflow to -0   =>  u < 0;
+		//   nu > RN(det*(1+2^-20)) =>  nu/det > 1+2^-21, and two roundings lose < 2^-22  =>  u > 1.
+		// Lanes outside these sure cases (and every lane of the !CULL variant) take the division below, which
+		// then re-derives the same verdict for the sure cases, so the result is bit-identical either way.
+		const uint64_t sure = ballot(det < 0x1p100f) & (ballot(nu < -0x1p-20f) | ballot(nu > det * (1.0f + 0x1p-20f)));
+		if ((m1 & ~sure) == 0) return;
 	}
+	if (STATS) cnt.wS3++;
+	const float inv = 1 / det;
+	const float u = nu * inv;
+	const uint64_t m2 = m1 & ballot(!(u < 0)) & ballot(!(u > 1));
+	if (m2 == 0) return;
+	if (STATS) cnt.wS4++;
+	const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+	const float v = (d.x * qx + d.y * qy + d.z * qz) * inv;
+	const uint64_t m3 = m2 & ballot(!(v < 0)) & ballot(!(u + v > 1));
+	if (m3 == 0) return;
+	const float t = (e2x * qx + e2y * qy + e2z * qz) * inv;
+	const uint64_t m4 = m3 & ballot(!(t < 0)) & ballot(t < bt);     // objects.cpp:91, 623
+	if ((m4 >> __lane_id()) & 1ull) { bt = t; bu = u; bv = v; btri = td[9]; }
 }
 
 // AccelerationStructure::intersectAccelStruct (objects.cpp:587-631) for a whole wave: stackless pre-order walk.
@@ -351,7 +365,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 		fail = fail || (tmin > tzmax) || (tzmin > tmx);
 		const bool pass = act && !fail;
 		if (act && fail) resume = nxt;
-		if (STATS) cnt.box += __popcll(ballot(act));
+		if (STATS) { cnt.box += __popcll(ballot(act)); cnt.wNodes++; }
 		const uint64_t m = ballot(pass);
 		if (m == 0) {
 			nd = nxB;
@@ -365,15 +379,19 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 				// exec = the lanes that passed this leaf's box.  Two records per trip; the records after the leaf's
 				// last one may be fetched and ignored (the array is padded by two records on upload).
 				const LeafTri* p = leaf + nd[7];
-				const LeafTri* const pe = p + n;
 				u32x16 t0 = sload16(p);
-				do {
-					const u32x16 t1 = sload16(after(p, t0[9]) + 1);
-					triTest<CULL>(t0, o, d, bt, bu, bv, btri);
-					t0 = sload16(after(p, t1[9]) + 2);
-					if (p + 1 < pe) triTest<CULL>(t1, o, d, bt, bu, bv, btri);
+				for (uint32_t left = n;;) {
+					p = after(p, t0[9]);
+					const u32x16 t1 = sload16(p + 1);
+					triTest<CULL, STATS>(t0, o, d, bt, bu, bv, btri, cnt);
+					if (left == 1) break;
+					p = after(p, t1[9]);
+					t0 = sload16(p + 2);
+					triTest<CULL, STATS>(t1, o, d, bt, bu, bv, btri, cnt);
+					if (left == 2) break;
+					left = uni(left - 2);
 					p += 2;
-				} while (p < pe);
+				}
 			}
 			// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is true
 			// for this lane no later triangle or object can change the answer.
@@ -730,6 +748,8 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 		atomicAdd(P.counters + 0, c.rays);
 		atomicAdd(P.counters + 1, c.box);
 		atomicAdd(P.counters + 2, c.tri);
+		atomicAdd(P.counters + 5, c.wNodes); atomicAdd(P.counters + 6, c.wTri); atomicAdd(P.counters + 7, c.wS2);
+		atomicAdd(P.counters + 8, c.wS3); atomicAdd(P.counters + 9, c.wS4);
 	}
 }
 
@@ -744,7 +764,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
-	Counts cnt = { 0, 0, 0 };
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	for (;;) {
 		const uint32_t tile = nextWork(P.workCounter);
 		if (tile >= P.nTiles) break;
@@ -794,7 +814,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
-	Counts cnt = { 0, 0, 0 };
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	for (;;) {
 		// work item = (tile, chunk) from the list built by rtxSsaaListKernel: chunk c re-renders flagged pixels
 		// 16c .. 16c+15 of the tile; tiles that were expensive in pass 1 come first (longest-job-first)
@@ -882,7 +902,7 @@ __global__ void __launch_bounds__(256) rtxProbeKernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t nWork = (P.nProbe + 63) / 64;
-	Counts cnt = { 0, 0, 0 };
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	for (;;) {
 		const uint32_t work = nextWork(P.workCounter);
 		if (work >= nWork) break;
