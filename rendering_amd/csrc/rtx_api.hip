@@ -86,8 +86,8 @@ int ensureWork(rtx_scene* s)
 {
 	HIPCHK(hipSetDevice(s->device));
 	if (!s->work) {
-		HIPCHK(hipMalloc((void**)&s->work, 16 * sizeof(uint32_t)));
-		HIPCHK(hipMemset(s->work, 0, 16 * sizeof(uint32_t)));
+		HIPCHK(hipMalloc((void**)&s->work, 256 * sizeof(uint32_t)));
+		HIPCHK(hipMemset(s->work, 0, 256 * sizeof(uint32_t)));
 		HIPCHK(hipMalloc((void**)&s->counters, 16 * sizeof(unsigned long long)));
 		HIPCHK(hipMemset(s->counters, 0, 16 * sizeof(unsigned long long)));
 		int b = 0;
@@ -309,8 +309,9 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	if (lastRow <= rowBegin) return RTX_OK;
 	const uint32_t tilesY = (lastRow + 7) / 8 - p.tileRow0;
 	p.nTiles = p.tilesX * tilesY;
-	p.workCounter = s->work + 0;
-	HIPCHK(hipMemsetAsync(s->work + 0, 0, sizeof(uint32_t), st));
+	p.tilesY = tilesY;
+	p.workCounter = s->work + 128;            // eight per-XCD queue heads, 64 bytes apart
+	HIPCHK(hipMemsetAsync(s->work + 128, 0, 128 * sizeof(uint32_t), st));
 	uint32_t blocks = (uint32_t)s->blocksPass1;
 	const uint32_t wavesNeeded = (p.nTiles + 3) / 4;
 	if (blocks > wavesNeeded) blocks = wavesNeeded ? wavesNeeded : 1;

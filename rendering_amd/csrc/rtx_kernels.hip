@@ -765,27 +765,42 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
 	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	for (;;) {
-		const uint32_t tile = nextWork(P.workCounter);
-		if (tile >= P.nTiles) break;
-		const uint32_t ty0 = tile / P.tilesX, tx = tile - ty0 * P.tilesX, ty = P.tileRow0 + ty0;
-		const uint32_t x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
-		// x1/y1 are clamped to W-1/H-1: the last column and row are never rendered (scene.cpp:369-372)
-		const bool valid = x < W - 1 && y < H - 1 && y >= P.rowBegin && y < P.rowEnd && rowRendered(P, y);
-		if (ballot(valid) == 0) continue;
-		V3 o, d;
-		primaryRay(P, (float)x + 0.5f, (float)y + 0.5f, o, d);
-		const unsigned long long t0 = wall_clock64();
-		const V3 c = castRayWave<STATS>(P, valid, o, d, gl, cnt);
-		const unsigned long long dt = wall_clock64() - t0;
-		if (lane == 0) {
-			// remembered per tile: the SSAA pass starts with the tiles that were expensive here (longest job first)
-			P.tileCost[ty * P.tilesXFull + tx] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
-			if (STATS) { atomicMax(P.counters + 3, dt); atomicAdd(P.counters + 4, dt); }
-		}
-		if (valid) {
-			float* px = P.fb + ((size_t)y * W + x) * 3;
-			px[0] = c.x; px[1] = c.y; px[2] = c.z;
+	// XCD-affine work distribution.  Each XCD has its own 4 MB L2; if consecutive tiles went to different XCDs
+	// (one global queue) every L2 would have to hold the triangles of the whole sweep.  Instead the frame is cut
+	// into bands of 8 tile rows (64 pixel rows), band b belongs to queue b % 8, and a wave first drains the queue
+	// of the XCD it runs on (s_getreg XCC_ID), then helps the others (work stealing, for load balance only --
+	// any wave may render any tile).
+	const uint32_t xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
+	const uint32_t bandTiles = 8 * P.tilesX;
+	const uint32_t nBands = (P.tilesY + 7) / 8;
+	for (uint32_t attempt = 0; attempt < 8; attempt = uni(attempt + 1)) {
+		const uint32_t q = (xcd + attempt) & 7u;
+		const uint32_t qBands = nBands > q ? (nBands - q + 7) / 8 : 0;
+		const uint32_t qSize = qBands * bandTiles;
+		for (;;) {
+			const uint32_t j = nextWork(P.workCounter + q * 16);
+			if (j >= qSize) break;
+			const uint32_t lb = j / bandTiles, r = j - lb * bandTiles;
+			const uint32_t ty0 = (lb * 8 + q) * 8 + r / P.tilesX, tx = r % P.tilesX, ty = P.tileRow0 + ty0;
+			if (ty0 >= P.tilesY) continue;
+			const uint32_t x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+			// x1/y1 are clamped to W-1/H-1: the last column and row are never rendered (scene.cpp:369-372)
+			const bool valid = x < W - 1 && y < H - 1 && y >= P.rowBegin && y < P.rowEnd && rowRendered(P, y);
+			if (ballot(valid) == 0) continue;
+			V3 o, d;
+			primaryRay(P, (float)x + 0.5f, (float)y + 0.5f, o, d);
+			const unsigned long long t0 = wall_clock64();
+			const V3 c = castRayWave<STATS>(P, valid, o, d, gl, cnt);
+			const unsigned long long dt = wall_clock64() - t0;
+			if (lane == 0) {
+				// remembered per tile: the SSAA pass starts with the tiles that were expensive here (longest job first)
+				P.tileCost[ty * P.tilesXFull + tx] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
+				if (STATS) { atomicMax(P.counters + 3, dt); atomicAdd(P.counters + 4, dt); }
+			}
+			if (valid) {
+				float* px = P.fb + ((size_t)y * W + x) * 3;
+				px[0] = c.x; px[1] = c.y; px[2] = c.z;
+			}
 		}
 	}
 	if (STATS) flushCounts(P, cnt);
