@@ -181,6 +181,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			return bail(fail(RTX_ERR_ARG, "mesh arrays missing"));
 		if (m.normal_map && !m.tri_tb) return bail(fail(RTX_ERR_ARG, "normal map without tangents"));
 		std::vector<Node> nodes(m.n_nodes);
+		std::vector<LeafPair> leaf;
+		leaf.reserve(m.n_refs / 2 + m.n_nodes / 2 + 2);
 		for (uint32_t i = 0; i < m.n_nodes; i++) {
 			Node& nd = nodes[i];
 			memcpy(nd.lo, m.node_bounds + (size_t)i * 6, 12);
@@ -188,26 +190,29 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			if (m.leaf_count[i] < 0) {
 				if (m.node_skip[i] <= (int32_t)i + 1 || m.node_skip[i] > (int32_t)m.n_nodes) return bail(fail(RTX_ERR_ARG, "bad skip index"));
 				nd.link = m.node_skip[i]; nd.first = 0;
+				continue;
 			}
-			else {
-				if ((uint32_t)m.leaf_begin[i] + (uint32_t)m.leaf_count[i] > m.n_refs) return bail(fail(RTX_ERR_ARG, "leaf range out of bounds"));
-				nd.link = ~m.leaf_count[i]; nd.first = m.leaf_begin[i];
+			const uint32_t begin = (uint32_t)m.leaf_begin[i], count = (uint32_t)m.leaf_count[i];
+			if (begin + count > m.n_refs) return bail(fail(RTX_ERR_ARG, "leaf range out of bounds"));
+			nd.link = ~m.leaf_count[i]; nd.first = (int32_t)leaf.size();
+			for (uint32_t k = 0; k < count; k += 2) {
+				LeafPair lp;
+				memset(&lp, 0, sizeof(lp));          // odd leaf: second record stays degenerate (det == 0)
+				for (uint32_t j = 0; j < 2 && k + j < count; j++) {
+					const uint32_t t = m.refs[begin + k + j];
+					if (t >= m.n_tris) return bail(fail(RTX_ERR_ARG, "leaf reference out of range"));
+					const float* p = m.tri_pos + (size_t)t * 9;
+					LeafTri& lt = lp.t[j];
+					// v0v1 = v1 - v0, v0v2 = v2 - v0 (objects.cpp:70-71)
+					lt.e1x = p[3] - p[0]; lt.e1y = p[4] - p[1]; lt.e1z = p[5] - p[2];
+					lt.e2x = p[6] - p[0]; lt.e2y = p[7] - p[1]; lt.e2z = p[8] - p[2];
+					lt.v0x = p[0]; lt.v0y = p[1]; lt.v0z = p[2];
+					lt.tri = t;
+				}
+				leaf.push_back(lp);
 			}
 		}
-		std::vector<LeafTri> leaf((size_t)m.n_refs + 2);   // +2: the walk's prefetch may read past the last record
-		memset(leaf.data(), 0, leaf.size() * sizeof(LeafTri));
-		for (uint32_t r = 0; r < m.n_refs; r++) {
-			const uint32_t t = m.refs[r];
-			if (t >= m.n_tris) return bail(fail(RTX_ERR_ARG, "leaf reference out of range"));
-			const float* p = m.tri_pos + (size_t)t * 9;
-			LeafTri& lt = leaf[r];
-			for (int k = 0; k < 3; k++) {
-				lt.v0[k] = p[k];
-				lt.e1[k] = p[3 + k] - p[k];      // v0v1 = v1 - v0 (objects.cpp:70)
-				lt.e2[k] = p[6 + k] - p[k];      // v0v2 = v2 - v0 (objects.cpp:71)
-			}
-			lt.tri = t;
-		}
+		{ LeafPair z; memset(&z, 0, sizeof(z)); leaf.push_back(z); leaf.push_back(z); }
 		Mesh& dm = meshes[mi];
 		memset(&dm, 0, sizeof(dm));
 		int rc;

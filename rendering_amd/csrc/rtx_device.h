@@ -1,7 +1,7 @@
 // Device-side data layout of the flattened scene (gfx950).  Shared by the kernels and the upload code.
 //
 // Everything the traversal touches is laid out so that a WAVE reads it through the scalar unit: one BVH
-// node is one 32-byte s_load_dwordx8, one leaf triangle is one cache-line-aligned 64-byte s_load_dwordx16.
+// node is one 32-byte s_load_dwordx8, two leaf triangles are one 80-byte s_load_dwordx16 + s_load_dwordx4.
 // The 64 lanes of a wave hold 64 different rays (an 8x8 pixel tile or 16 SSAA pixels x 4 samples); node and
 // triangle operands sit in SGPRs, so the VALU does nothing but the reference's own arithmetic.
 #pragma once
@@ -11,7 +11,7 @@ namespace rtxd {
 
 // Pre-order BVH node (reference: AccelerationStructure, objects.h:125-164).
 //   link  > 0 : inner node; link = pre-order index of the first node after this subtree ("skip")
-//   link  < 0 : leaf with ~link triangles starting at leaf-triangle index `first`
+//   link  < 0 : leaf with ~link triangles starting at leaf PAIR index `first`
 struct Node {
 	float lo[3];
 	float hi[3];
@@ -20,22 +20,29 @@ struct Node {
 };
 static_assert(sizeof(Node) == 32, "node must be one s_load_dwordx8");
 
-// One leaf reference, duplicated per leaf in the reference's DFS-left-first order (objects.cpp:622-629): one
-// cache-line-aligned 64-byte record = one s_load_dwordx16.
+// Leaf references, duplicated per leaf in the reference's DFS-left-first order (objects.cpp:622-629), stored in
+// PAIRS: 80 bytes = two 10-dword records, fetched with one s_load_dwordx16 + one s_load_dwordx4.  A leaf with an
+// odd number of references is padded with a degenerate record (all zero: det = 0 is rejected by the reference's
+// own epsilon test, objects.cpp:76-79), so a leaf always starts on a pair boundary.
+// The dword order puts the operands of the packed-f32 VALU ops (v_pk_mul_f32 / v_pk_add_f32: two IEEE fp32
+// operations per instruction at the issue cost of one -- measured, tools/ubench/pk_rate.hip) in even-aligned
+// SGPR pairs.
 // e1 = b - a and e2 = c - a are the fp32 differences the reference recomputes per test (objects.cpp:70-71);
 // they are ray-independent, so computing them once on upload is bit-identical.
 struct LeafTri {
-	float v0[3];
-	float e1[3];
-	float e2[3];
-	uint32_t tri;     // index into the per-triangle shading arrays
-	uint32_t pad[6];
+	float e2x, e2y;
+	float e1x, e1y;
+	float e2z, e1z;
+	float v0x, v0y;
+	float v0z;
+	uint32_t tri;        // index into the per-triangle shading arrays
 };
-static_assert(sizeof(LeafTri) == 64, "leaf triangle must be one 64-byte line");
+struct LeafPair { LeafTri t[2]; };
+static_assert(sizeof(LeafPair) == 80, "leaf pair must be 20 dwords");
 
 struct Mesh {
 	const Node* nodes;
-	const LeafTri* leaf;    // nRefs + 2 records (the walk's prefetch may run two records past a leaf)
+	const LeafPair* leaf;   // pairs of leaf references (+1 pair: the walk's prefetch may run one pair past a leaf)
 	const float* nrm;      // n_tris x 9
 	const float* uv;       // n_tris x 6
 	const float* tb;       // n_tris x 6 (tangent, bitangent) or null

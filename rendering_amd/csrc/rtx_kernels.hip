@@ -37,11 +37,21 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+struct TriPair { u32x16 a; u32x4 b; };   // 20 dwords: two 10-dword leaf records (rtxd::LeafPair)
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Wave-uniform loads through the constant address space -> SMEM instructions.
 __device__ __forceinline__ uint32_t sload1(const void* p) { return *(const RTX_AS4 uint32_t*)(uintptr_t)p; }
 __device__ __forceinline__ u32x8 sload8(const void* p) { return *(const RTX_AS4 u32x8*)(uintptr_t)p; }
 __device__ __forceinline__ u32x16 sload16(const void* p) { return *(const RTX_AS4 u32x16*)(uintptr_t)p; }
+__device__ __forceinline__ u32x4 sload4(const void* p) { return *(const RTX_AS4 u32x4*)(uintptr_t)p; }
+__device__ __forceinline__ TriPair sloadPair(const void* p)
+{
+	TriPair t;
+	t.a = sload16(p);
+	t.b = sload4((const char*)p + 64);
+	return t;
+}
 __device__ __forceinline__ float sloadf(const float* p) { return __uint_as_float(sload1(p)); }
 __device__ __forceinline__ const void* sloadp(const void* p)
 {
@@ -286,13 +296,27 @@ template <typename T> __device__ __forceinline__ T after(T x, uint32_t v)
 // passed the leaf's box, so every ballot below is already restricted to them; the wave leaves a stage as soon as
 // no lane survives it (uniform branch on the lane mask).  Ballots are taken of the raw compares and combined with
 // scalar mask arithmetic (a ballot of a compound bool costs two extra VALU instructions).
+// The ray in the operand arrangement of the packed ops.
+struct PackedRay { f2 dyx, dxy, dzz, oxy; float dx, dy, dz, oz; };
+
 template <bool CULL, bool STATS>
-__device__ __forceinline__ void triTest(const u32x16& td, const V3& o, const V3& d, float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
+__device__ __forceinline__ void triTest(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7,
+                                        uint32_t w8, uint32_t w9, const PackedRay& r,
+                                        float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
 {
-	const float e1x = F(td[3]), e1y = F(td[4]), e1z = F(td[5]);
-	const float e2x = F(td[6]), e2y = F(td[7]), e2z = F(td[8]);
-	const float px = d.y * e2z - d.z * e2y, py = d.z * e2x - d.x * e2z, pz = d.x * e2y - d.y * e2x;
-	const float det = e1x * px + e1y * py + e1z * pz;
+	// record dwords: e2x e2y | e1x e1y | e2z e1z | v0x v0y | v0z tri
+	const f2 e2xy = { F(w0), F(w1) }, e2yx = { F(w1), F(w0) }, e1xy = { F(w2), F(w3) }, e2zz = { F(w4), F(w4) }, v0xy = { F(w6), F(w7) };
+	const float e2x = F(w0), e2y = F(w1), e2z = F(w4), e1x = F(w2), e1y = F(w3), e1z = F(w5), v0z = F(w8);
+	// pvec = dir x v0v2 (objects.cpp:72) with packed fp32 ops; every component is the same IEEE mul / mul / sub as
+	// the scalar form.  a = (dy*e2z, dx*e2z), b = (dz*e2y, dz*e2x):  a - b = (px, -py).  Only px, -py and pz are
+	// ever needed: e1x*px + e1y*py = e1x*px - e1y*(-py) (negating a product is exact).
+	const f2 a = r.dyx * e2zz, b = r.dzz * e2yx;
+	const f2 pxn = a - b;                                                     // (px, -py)
+	const f2 c = r.dxy * e2yx;                                                // (dx*e2y, dy*e2x)
+	const float pz = c.x - c.y;
+	const f2 dp = e1xy * pxn;                                                 // (e1x*px, -(e1y*py))
+	const float det = dp.x - dp.y + e1z * pz;                                 // objects.cpp:73
+	(void)e2xy;
 	// culling on:  reject iff det < 1e-8 (then |det| < 1e-8 is implied);  off: reject iff |det| < 1e-8.
 	// Both compares are false for NaN, exactly like the reference's two ifs (objects.cpp:75-79).
 	const float dd = CULL ? det : fabsf(det);
@@ -300,8 +324,10 @@ __device__ __forceinline__ void triTest(const u32x16& td, const V3& o, const V3&
 	if (STATS) cnt.wTri++;
 	if (m1 == 0) return;
 	if (STATS) cnt.wS2++;
-	const float tx = o.x - F(td[0]), ty = o.y - F(td[1]), tz = o.z - F(td[2]);
-	const float nu = tx * px + ty * py + tz * pz;
+	const f2 txy = r.oxy - v0xy;                                              // tvec = orig - v0 (objects.cpp:82)
+	const float tz = r.oz - v0z;
+	const f2 np = txy * pxn;                                                  // (tx*px, -(ty*py))
+	const float nu = np.x - np.y + tz * pz;                                   // tvec . pvec (objects.cpp:83)
 	if (CULL) {
 		// Exact-safe rejection before the IEEE division.  Here 1e-8 <= det, so inv = RN(1/det) > 0 and
 		// u = RN(nu * inv).  For det < 2^100 (inv >= 2^-100, normal):
@@ -318,13 +344,14 @@ __device__ __forceinline__ void triTest(const u32x16& td, const V3& o, const V3&
 	const uint64_t m2 = m1 & ballot(!(u < 0)) & ballot(!(u > 1));
 	if (m2 == 0) return;
 	if (STATS) cnt.wS4++;
-	const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
-	const float v = (d.x * qx + d.y * qy + d.z * qz) * inv;
+	const float tx = txy.x, ty = txy.y;
+	const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;   // tvec x v0v1
+	const float v = (r.dx * qx + r.dy * qy + r.dz * qz) * inv;
 	const uint64_t m3 = m2 & ballot(!(v < 0)) & ballot(!(u + v > 1));
 	if (m3 == 0) return;
 	const float t = (e2x * qx + e2y * qy + e2z * qz) * inv;
 	const uint64_t m4 = m3 & ballot(!(t < 0)) & ballot(t < bt);     // objects.cpp:91, 623
-	if ((m4 >> __lane_id()) & 1ull) { bt = t; bu = u; bv = v; btri = td[9]; }
+	if ((m4 >> __lane_id()) & 1ull) { bt = t; bu = u; bv = v; btri = w9; }
 }
 
 // AccelerationStructure::intersectAccelStruct (objects.cpp:587-631) for a whole wave: stackless pre-order walk.
@@ -335,13 +362,16 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
                                          float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
 {
 	const Node* nodes = uni((const Node*)sloadp(&M->nodes));
-	const LeafTri* leaf = uni((const LeafTri*)sloadp(&M->leaf));
+	const LeafPair* leaf = uni((const LeafPair*)sloadp(&M->leaf));
 	const uint32_t nN = uni(sload1(&M->nNodes));
 	bt = kFltMax; bu = 0; bv = 0; btri = 0;
 	if (nN == 0) return;
 	uint32_t resume = consider ? 0u : kNever;
 	uint32_t i = 0;
 	const uint32_t last = nN - 1;
+	PackedRay pr;
+	pr.dyx = f2{ d.y, d.x }; pr.dxy = f2{ d.x, d.y }; pr.dzz = f2{ d.z, d.z }; pr.oxy = f2{ o.x, o.y };
+	pr.dx = d.x; pr.dy = d.y; pr.dz = d.z; pr.oz = o.z;
 	u32x8 nd = sload8(nodes);
 	while (i < nN) {
 		const int32_t link = (int32_t)nd[6];
@@ -378,19 +408,27 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 			if (n != 0 && pass) {
 				// exec = the lanes that passed this leaf's box.  Two records per trip; the records after the leaf's
 				// last one may be fetched and ignored (the array is padded by two records on upload).
-				const LeafTri* p = leaf + nd[7];
-				u32x16 t0 = sload16(p);
-				for (uint32_t left = n;;) {
-					p = after(p, t0[9]);
-					const u32x16 t1 = sload16(p + 1);
-					triTest<CULL, STATS>(t0, o, d, bt, bu, bv, btri, cnt);
+				// one PAIR of references per trip: wait(pair) -> issue(next pair) -> test both.  The pair after the
+				// leaf's last one may be fetched and ignored (the array is padded on upload).
+				const LeafPair* p = leaf + nd[7];
+				TriPair t0 = sloadPair(p);
+				for (uint32_t left = (n + 1) / 2;;) {
+					p = after(p, t0.b[3]);
+#ifdef RTX_EXP_SAMEPAIR
+					const TriPair t1 = sloadPair(p);
+#else
+					const TriPair t1 = sloadPair(p + 1);
+#endif
+					triTest<CULL, STATS>(t0.a[0], t0.a[1], t0.a[2], t0.a[3], t0.a[4], t0.a[5], t0.a[6], t0.a[7], t0.a[8], t0.a[9],
+					                     pr, bt, bu, bv, btri, cnt);
+					triTest<CULL, STATS>(t0.a[10], t0.a[11], t0.a[12], t0.a[13], t0.a[14], t0.a[15], t0.b[0], t0.b[1], t0.b[2], t0.b[3],
+					                     pr, bt, bu, bv, btri, cnt);
 					if (left == 1) break;
-					p = after(p, t1[9]);
-					t0 = sload16(p + 2);
-					triTest<CULL, STATS>(t1, o, d, bt, bu, bv, btri, cnt);
-					if (left == 2) break;
-					left = uni(left - 2);
-					p += 2;
+					left = uni(left - 1);
+#ifndef RTX_EXP_SAMEPAIR
+					p += 1;
+#endif
+					t0 = t1;
 				}
 			}
 			// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is true
