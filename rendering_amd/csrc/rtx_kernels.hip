@@ -378,9 +378,11 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 		const uint32_t next = uni(i + 1);
 		const uint32_t nxt = link > 0 ? (uint32_t)link : next;
 		// speculative prefetch of both possible successors (clamped to the array), issued after nd has arrived
-		const u32x8 nxA = sload8(after(nodes, nd[7]) + (next < last ? next : last));
-		u32x8 nxB = nxA;
-		if (nxt != next) nxB = sload8(nodes + (nxt < last ? nxt : last));
+		// (written as two unconditional loads; the compiler sinks each into the branch that consumes it, so one
+		// node record is fetched per visit -- measured faster than keeping both speculative loads in flight)
+		const Node* nb = after(nodes, nd[7]);
+		const u32x8 nxA = sload8(nb + (next < last ? next : last));
+		const u32x8 nxB = sload8(nb + (nxt < last ? nxt : last));
 		const bool act = i >= resume;
 		// slab test, objects.cpp:546-567: (bounds[sign] - orig) * invdir per axis, sequential compares
 		const float xlo = (F(nd[0]) - o.x) * ix, xhi = (F(nd[3]) - o.x) * ix;
@@ -414,20 +416,14 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 				TriPair t0 = sloadPair(p);
 				for (uint32_t left = (n + 1) / 2;;) {
 					p = after(p, t0.b[3]);
-#ifdef RTX_EXP_SAMEPAIR
-					const TriPair t1 = sloadPair(p);
-#else
 					const TriPair t1 = sloadPair(p + 1);
-#endif
 					triTest<CULL, STATS>(t0.a[0], t0.a[1], t0.a[2], t0.a[3], t0.a[4], t0.a[5], t0.a[6], t0.a[7], t0.a[8], t0.a[9],
 					                     pr, bt, bu, bv, btri, cnt);
 					triTest<CULL, STATS>(t0.a[10], t0.a[11], t0.a[12], t0.a[13], t0.a[14], t0.a[15], t0.b[0], t0.b[1], t0.b[2], t0.b[3],
 					                     pr, bt, bu, bv, btri, cnt);
 					if (left == 1) break;
 					left = uni(left - 1);
-#ifndef RTX_EXP_SAMEPAIR
 					p += 1;
-#endif
 					t0 = t1;
 				}
 			}
