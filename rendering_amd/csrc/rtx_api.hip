@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -195,6 +197,9 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			const uint32_t begin = (uint32_t)m.leaf_begin[i], count = (uint32_t)m.leaf_count[i];
 			if (begin + count > m.n_refs) return bail(fail(RTX_ERR_ARG, "leaf range out of bounds"));
 			nd.link = ~m.leaf_count[i]; nd.first = (int32_t)leaf.size();
+			const size_t hdrAt = leaf.size();
+			{ LeafPair z; memset(&z, 0, sizeof(z)); leaf.push_back(z); }     // header slot, filled below
+			double mlo[3] = { 1e300, 1e300, 1e300 }, mhi[3] = { -1e300, -1e300, -1e300 }, qmax = 0;
 			for (uint32_t k = 0; k < count; k += 2) {
 				LeafPair lp;
 				memset(&lp, 0, sizeof(lp));          // odd leaf: second record stays degenerate (det == 0)
@@ -208,8 +213,39 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 					lt.e2x = p[6] - p[0]; lt.e2y = p[7] - p[1]; lt.e2z = p[8] - p[2];
 					lt.v0x = p[0]; lt.v0y = p[1]; lt.v0z = p[2];
 					lt.tri = t;
+					// header statistics: m = e2 x e1 and the det error scale, in fp64 from the fp32 edges
+					const double e1[3] = { lt.e1x, lt.e1y, lt.e1z }, e2[3] = { lt.e2x, lt.e2y, lt.e2z };
+					const double mm[3] = { e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0] };
+					double q = 0;
+					for (int c = 0; c < 3; c++) {
+						mlo[c] = std::min(mlo[c], mm[c]); mhi[c] = std::max(mhi[c], mm[c]);
+						q += std::fabs(e1[c]) * (std::fabs(e2[(c + 1) % 3]) + std::fabs(e2[(c + 2) % 3]));
+					}
+					qmax = std::max(qmax, q);
 				}
 				leaf.push_back(lp);
+			}
+			{
+				LeafHeader h;
+				memset(&h, 0, sizeof(h));
+				double mabs = 0;
+				bool finite = count > 0;
+				for (int c = 0; c < 3 && finite; c++) {
+					if (!std::isfinite(mlo[c]) || !std::isfinite(mhi[c]) || std::fabs(mlo[c]) > 1e30 || std::fabs(mhi[c]) > 1e30) finite = false;
+					else {
+						// outward rounding to fp32 (one extra ulp absorbs the fp64 rounding of mm)
+						float lo = (float)mlo[c], hi = (float)mhi[c];
+						lo = std::nextafterf(std::nextafterf(lo, -INFINITY), -INFINITY);
+						hi = std::nextafterf(std::nextafterf(hi, INFINITY), INFINITY);
+						h.mlo[c] = lo; h.mhi[c] = hi;
+						mabs += std::max(std::fabs((double)lo), std::fabs((double)hi));
+					}
+				}
+				const double u = 5.9604644775390625e-08;      // 2^-24
+				const double err = (8 * u * qmax + 4 * u * mabs) * 1.001 + 1e-30;
+				if (!finite || !(err < 1e30)) { h.mlo[0] = h.mlo[1] = h.mlo[2] = -INFINITY; h.mhi[0] = h.mhi[1] = h.mhi[2] = INFINITY; h.err = INFINITY; }
+				else h.err = std::nextafterf((float)err, INFINITY);
+				memcpy(&leaf[hdrAt], &h, sizeof(h));
 			}
 		}
 		{ LeafPair z; memset(&z, 0, sizeof(z)); leaf.push_back(z); leaf.push_back(z); }
@@ -435,7 +471,7 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	HIPCHK(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
 	out->rays = c[0]; out->box_tests = c[1]; out->tri_tests = c[2];
 	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] slowest work item %.3f ms, sum of items %.3f ms (100 MHz wall clock)\n", c[3] * 1e-5, c[4] * 1e-5);
-	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] wave-level: node visits %llu, triangle iterations %llu (lane utilisation %.3f), reached u-stage %llu, division %llu, v-stage %llu\n", c[5], c[6], c[6] ? (double)c[2] / (64.0 * c[6]) : 0.0, c[7], c[8], c[9]);
+	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] wave-level: node visits %llu, triangle iterations %llu (lane utilisation %.3f), reached u-stage %llu, division %llu, v-stage %llu; leaf visits %llu, skipped by the back-face header %llu\n", c[5], c[6], c[6] ? (double)c[2] / (64.0 * c[6]) : 0.0, c[7], c[8], c[9], c[10], c[11]);
 	return RTX_OK;
 }
 

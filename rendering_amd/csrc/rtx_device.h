@@ -11,7 +11,7 @@ namespace rtxd {
 
 // Pre-order BVH node (reference: AccelerationStructure, objects.h:125-164).
 //   link  > 0 : inner node; link = pre-order index of the first node after this subtree ("skip")
-//   link  < 0 : leaf with ~link triangles starting at leaf PAIR index `first`
+//   link  < 0 : leaf with ~link triangles; `first` = index of its LeafHeader in the pair array, pairs follow
 struct Node {
 	float lo[3];
 	float hi[3];
@@ -38,6 +38,22 @@ struct LeafTri {
 	uint32_t tri;        // index into the per-triangle shading arrays
 };
 struct LeafPair { LeafTri t[2]; };
+
+// Every leaf's pairs are preceded by one header of the same size.  It lets a wave skip the whole leaf when the
+// reference's back-face test (det < 1e-8, objects.cpp:75-77) is CERTAIN to reject every triangle of the leaf for
+// every active ray -- the reference rejects those triangles before doing anything else, so skipping them is exact.
+//   det = v0v1 . (dir x v0v2) = dir . m  with m = v0v2 x v0v1.   [mlo, mhi] bounds m component-wise over the leaf
+//   (computed in fp64 from the fp32 edges and rounded outwards), so U = sum_i max(dir_i*mlo_i, dir_i*mhi_i) >= dir . m.
+//   err bounds, per unit of max|dir_i|, the fp32 rounding error of the reference's det (8u * sum_i |e1_i|(|e2_j|+|e2_k|),
+//   u = 2^-24: gamma_2 for the cross product, gamma_3 for the dot product, with slack) plus the error of evaluating U
+//   in fp32 (4u * sum_i max|m_i|), rounded up.  If U < -err * max|dir_i| then det_computed < 0 < 1e-8 for every
+//   triangle of the leaf.
+struct LeafHeader {
+	float mlo[3], mhi[3];
+	float err;
+	uint32_t pad[13];
+};
+static_assert(sizeof(LeafHeader) == sizeof(LeafPair), "header occupies one pair slot");
 static_assert(sizeof(LeafPair) == 80, "leaf pair must be 20 dwords");
 
 struct Mesh {

@@ -279,7 +279,7 @@ __device__ __forceinline__ float attenuation(float intensity, float l2)
 // Render::trace for a whole wave (scene.cpp:724-756)
 // ------------------------------------------------------------------------------------------------
 struct Hit { int obj; float t; uint32_t tri; float u, v; };
-struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4; };
+struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips; };
 
 // Ordering of scalar loads.  SMEM returns out of order, so lgkmcnt can only be waited down to zero: a load issued
 // before the first use of the previous one is covered by the same wait and nothing overlaps.  after(x, v) is an
@@ -372,6 +372,8 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 	PackedRay pr;
 	pr.dyx = f2{ d.y, d.x }; pr.dxy = f2{ d.x, d.y }; pr.dzz = f2{ d.z, d.z }; pr.oxy = f2{ o.x, o.y };
 	pr.dx = d.x; pr.dy = d.y; pr.dz = d.z; pr.oz = o.z;
+	// max |dir_i|, rounded up a little: scales the leaf headers' error bound
+	const float dmax = fmaxf(fabsf(d.x), fmaxf(fabsf(d.y), fabsf(d.z))) * (1.0f + 0x1p-20f);
 	u32x8 nd = sload8(nodes);
 	while (i < nN) {
 		const int32_t link = (int32_t)nd[6];
@@ -408,23 +410,37 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 			const uint32_t n = (uint32_t)~link;
 			if (STATS) cnt.tri += (unsigned long long)__popcll(m) * n;
 			if (n != 0 && pass) {
-				// exec = the lanes that passed this leaf's box.  Two records per trip; the records after the leaf's
-				// last one may be fetched and ignored (the array is padded by two records on upload).
-				// one PAIR of references per trip: wait(pair) -> issue(next pair) -> test both.  The pair after the
-				// leaf's last one may be fetched and ignored (the array is padded on upload).
+				// exec = the lanes that passed this leaf's box
 				const LeafPair* p = leaf + nd[7];
-				TriPair t0 = sloadPair(p);
-				for (uint32_t left = (n + 1) / 2;;) {
-					p = after(p, t0.b[3]);
-					const TriPair t1 = sloadPair(p + 1);
-					triTest<CULL, STATS>(t0.a[0], t0.a[1], t0.a[2], t0.a[3], t0.a[4], t0.a[5], t0.a[6], t0.a[7], t0.a[8], t0.a[9],
-					                     pr, bt, bu, bv, btri, cnt);
-					triTest<CULL, STATS>(t0.a[10], t0.a[11], t0.a[12], t0.a[13], t0.a[14], t0.a[15], t0.b[0], t0.b[1], t0.b[2], t0.b[3],
-					                     pr, bt, bu, bv, btri, cnt);
-					if (left == 1) break;
-					left = uni(left - 1);
-					p += 1;
-					t0 = t1;
+				bool skip = false;
+				if (CULL) {
+					// leaf header (rtxd::LeafHeader): is the reference's back-face test certain to reject every
+					// triangle of this leaf for this ray?  U >= dir . (v0v2 x v0v1) = det for all of them.
+					const u32x8 hd = sload8(p);
+					const float ux = fmaxf(d.x * F(hd[0]), d.x * F(hd[3]));
+					const float uy = fmaxf(d.y * F(hd[1]), d.y * F(hd[4]));
+					const float uz = fmaxf(d.z * F(hd[2]), d.z * F(hd[5]));
+					skip = ux + uy + uz < -(F(hd[6]) * dmax);
+				}
+				p += 1;
+				if (STATS) { cnt.wLeaves++; if (ballot(!skip) == 0) cnt.wLeafSkips++; }
+				if (!skip) {
+					// exec = lanes for which some triangle of the leaf may survive the back-face test.
+					// one PAIR of references per trip: wait(pair) -> issue(next pair) -> test both.  The pair after
+					// the leaf's last one may be fetched and ignored (the array is padded on upload).
+					TriPair t0 = sloadPair(p);
+					for (uint32_t left = (n + 1) / 2;;) {
+						p = after(p, t0.b[3]);
+						const TriPair t1 = sloadPair(p + 1);
+						triTest<CULL, STATS>(t0.a[0], t0.a[1], t0.a[2], t0.a[3], t0.a[4], t0.a[5], t0.a[6], t0.a[7], t0.a[8], t0.a[9],
+						                     pr, bt, bu, bv, btri, cnt);
+						triTest<CULL, STATS>(t0.a[10], t0.a[11], t0.a[12], t0.a[13], t0.a[14], t0.a[15], t0.b[0], t0.b[1], t0.b[2], t0.b[3],
+						                     pr, bt, bu, bv, btri, cnt);
+						if (left == 1) break;
+						left = uni(left - 1);
+						p += 1;
+						t0 = t1;
+					}
 				}
 			}
 			// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is true
@@ -784,6 +800,7 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 		atomicAdd(P.counters + 2, c.tri);
 		atomicAdd(P.counters + 5, c.wNodes); atomicAdd(P.counters + 6, c.wTri); atomicAdd(P.counters + 7, c.wS2);
 		atomicAdd(P.counters + 8, c.wS3); atomicAdd(P.counters + 9, c.wS4);
+		atomicAdd(P.counters + 10, c.wLeaves); atomicAdd(P.counters + 11, c.wLeafSkips);
 	}
 }
 
@@ -798,7 +815,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	// XCD-affine work distribution.  Each XCD has its own 4 MB L2; if consecutive tiles went to different XCDs
 	// (one global queue) every L2 would have to hold the triangles of the whole sweep.  Instead the frame is cut
 	// into bands of 8 tile rows (64 pixel rows), band b belongs to queue b % 8, and a wave first drains the queue
@@ -863,7 +880,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	for (;;) {
 		// work item = (tile, chunk) from the list built by rtxSsaaListKernel: chunk c re-renders flagged pixels
 		// 16c .. 16c+15 of the tile; tiles that were expensive in pass 1 come first (longest-job-first)
@@ -951,7 +968,7 @@ __global__ void __launch_bounds__(256) rtxProbeKernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t nWork = (P.nProbe + 63) / 64;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	for (;;) {
 		const uint32_t work = nextWork(P.workCounter);
 		if (work >= nWork) break;
