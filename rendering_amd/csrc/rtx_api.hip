@@ -200,6 +200,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			const size_t hdrAt = leaf.size();
 			{ LeafPair z; memset(&z, 0, sizeof(z)); leaf.push_back(z); }     // header slot, filled below
 			double mlo[3] = { 1e300, 1e300, 1e300 }, mhi[3] = { -1e300, -1e300, -1e300 }, qmax = 0;
+			double blo[3] = { 1e300, 1e300, 1e300 }, bhi[3] = { -1e300, -1e300, -1e300 };
+			double q2max = 0, e1L1 = 0, e2L1 = 0, e1Len = 0, e2Len = 0;
 			for (uint32_t k = 0; k < count; k += 2) {
 				LeafPair lp;
 				memset(&lp, 0, sizeof(lp));          // odd leaf: second record stays degenerate (det == 0)
@@ -222,6 +224,16 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 						q += std::fabs(e1[c]) * (std::fabs(e2[(c + 1) % 3]) + std::fabs(e2[(c + 2) % 3]));
 					}
 					qmax = std::max(qmax, q);
+					double q2 = 0;
+					for (int c = 0; c < 3; c++) {
+						q2 += std::fabs(e2[c]) * (std::fabs(e1[(c + 1) % 3]) + std::fabs(e1[(c + 2) % 3]));
+						for (int v = 0; v < 3; v++) { blo[c] = std::min(blo[c], (double)p[v * 3 + c]); bhi[c] = std::max(bhi[c], (double)p[v * 3 + c]); }
+					}
+					q2max = std::max(q2max, q2);
+					e1L1 = std::max(e1L1, std::fabs(e1[0]) + std::fabs(e1[1]) + std::fabs(e1[2]));
+					e2L1 = std::max(e2L1, std::fabs(e2[0]) + std::fabs(e2[1]) + std::fabs(e2[2]));
+					e1Len = std::max(e1Len, std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]));
+					e2Len = std::max(e2Len, std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]));
 				}
 				leaf.push_back(lp);
 			}
@@ -245,6 +257,18 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 				const double err = (8 * u * qmax + 4 * u * mabs) * 1.001 + 1e-30;
 				if (!finite || !(err < 1e30)) { h.mlo[0] = h.mlo[1] = h.mlo[2] = -INFINITY; h.mhi[0] = h.mhi[1] = h.mhi[2] = INFINITY; h.err = INFINITY; }
 				else h.err = std::nextafterf((float)err, INFINITY);
+				// certificate (2): coefficients of the error budget, rounded up; disabled (inf) for
+				// leaves whose magnitudes leave the range the derivation assumes
+				const double r3 = 1.7320508075688772;
+				const double A1 = (r3 * 32 * u * (e2L1 * e1Len + e1L1 * e2Len) + 24 * u * q2max + 13 * u * mabs) * 1.05;
+				const double A2 = (r3 * (16 * u * qmax + 6 * u * mabs) * (e1Len + e2Len)) * 1.05 + 1e-30;
+				const bool ok2 = finite && std::isfinite(h.err) && qmax < 1048576.0 && q2max < 1048576.0 && A1 < 1e30 && A2 < 1e30;
+				for (int c = 0; c < 3; c++) {
+					h.blo[c] = ok2 ? std::nextafterf((float)blo[c], -INFINITY) : -INFINITY;
+					h.bhi[c] = ok2 ? std::nextafterf((float)bhi[c], INFINITY) : INFINITY;
+				}
+				h.a1 = ok2 ? std::nextafterf((float)A1, INFINITY) : INFINITY;
+				h.a2 = ok2 ? std::nextafterf((float)A2, INFINITY) : INFINITY;
 				memcpy(&leaf[hdrAt], &h, sizeof(h));
 			}
 		}
@@ -472,6 +496,7 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	out->rays = c[0]; out->box_tests = c[1]; out->tri_tests = c[2];
 	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] slowest work item %.3f ms, sum of items %.3f ms (100 MHz wall clock)\n", c[3] * 1e-5, c[4] * 1e-5);
 	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] wave-level: node visits %llu, triangle iterations %llu (lane utilisation %.3f), reached u-stage %llu, division %llu, v-stage %llu; leaf visits %llu, skipped by the back-face header %llu\n", c[5], c[6], c[6] ? (double)c[2] / (64.0 * c[6]) : 0.0, c[7], c[8], c[9], c[10], c[11]);
+	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] leaf certificates (lane-level): evaluated %llu, certainly facing %llu, facing and box behind %llu, skipped as behind %llu\n", c[12], c[13], c[14], c[15]);
 	return RTX_OK;
 }
 

@@ -39,22 +39,27 @@ struct LeafTri {
 };
 struct LeafPair { LeafTri t[2]; };
 
-// Every leaf's pairs are preceded by one header of the same size.  It lets a wave skip the whole leaf when the
-// reference's back-face test (det < 1e-8, objects.cpp:75-77) is CERTAIN to reject every triangle of the leaf for
-// every active ray -- the reference rejects those triangles before doing anything else, so skipping them is exact.
-//   det = v0v1 . (dir x v0v2) = dir . m  with m = v0v2 x v0v1.   [mlo, mhi] bounds m component-wise over the leaf
-//   (computed in fp64 from the fp32 edges and rounded outwards), so U = sum_i max(dir_i*mlo_i, dir_i*mhi_i) >= dir . m.
-//   err bounds, per unit of max|dir_i|, the fp32 rounding error of the reference's det (8u * sum_i |e1_i|(|e2_j|+|e2_k|),
-//   u = 2^-24: gamma_2 for the cross product, gamma_3 for the dot product, with slack) plus the error of evaluating U
-//   in fp32 (4u * sum_i max|m_i|), rounded up.  If U < -err * max|dir_i| then det_computed < 0 < 1e-8 for every
-//   triangle of the leaf.
+// Every leaf's pairs are preceded by one header of the same size (one s_load_dwordx16).  It lets a wave skip the
+// whole leaf for a ray when the reference is CERTAIN to reject every triangle of the leaf -- skipping is then
+// exact.  Two certificates, both with rigorous fp32 rounding-error bounds (derivation: DESIGN.md section 3.3):
+//   (1) back-face:  det = v0v1 . (dir x v0v2) = dir . m with m = v0v2 x v0v1.  [mlo, mhi] bounds m component-wise
+//       over the leaf, so U = sum_i max(dir_i*mlo_i, dir_i*mhi_i) >= det_exact and L = sum_i min(..) <= det_exact.
+//       `err` (per unit of max|dir_i|) bounds the reference's rounding error of det plus the error of evaluating
+//       U / L in fp32.  U < -err*dmax  =>  det_computed < 0 < 1e-8 for every triangle (objects.cpp:75-77, culling on).
+//   (2) behind the origin:  if every triangle certainly faces the ray (L >= 4*err*dmax, so det >= g = L - 2*err*dmax)
+//       and the leaf's true AABB [blo, bhi] lies behind the ray origin by more than the error budget
+//       (-boxdot * g > dmax^2 * (Dinf*a1 + a2)), then any triangle that passes the reference's det / u / v tests gets
+//       a computed t < 0 and is rejected by objects.cpp:91.  (The reference's box test has no t range, so e.g. every
+//       shadow ray leaving the mesh walks all the leaves behind it.)
 struct LeafHeader {
 	float mlo[3], mhi[3];
 	float err;
-	uint32_t pad[13];
+	float a1;
+	float blo[3], bhi[3];
+	float a2;
+	uint32_t pad[5];
 };
 static_assert(sizeof(LeafHeader) == sizeof(LeafPair), "header occupies one pair slot");
-static_assert(sizeof(LeafPair) == 80, "leaf pair must be 20 dwords");
 
 struct Mesh {
 	const Node* nodes;

@@ -279,7 +279,7 @@ __device__ __forceinline__ float attenuation(float intensity, float l2)
 // Render::trace for a whole wave (scene.cpp:724-756)
 // ------------------------------------------------------------------------------------------------
 struct Hit { int obj; float t; uint32_t tri; float u, v; };
-struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips; };
+struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips, dbg[4]; };
 
 // Ordering of scalar loads.  SMEM returns out of order, so lgkmcnt can only be waited down to zero: a load issued
 // before the first use of the previous one is covered by the same wait and nothing overlaps.  after(x, v) is an
@@ -413,14 +413,33 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 				// exec = the lanes that passed this leaf's box
 				const LeafPair* p = leaf + nd[7];
 				bool skip = false;
-				if (CULL) {
-					// leaf header (rtxd::LeafHeader): is the reference's back-face test certain to reject every
-					// triangle of this leaf for this ray?  U >= dir . (v0v2 x v0v1) = det for all of them.
-					const u32x8 hd = sload8(p);
-					const float ux = fmaxf(d.x * F(hd[0]), d.x * F(hd[3]));
-					const float uy = fmaxf(d.y * F(hd[1]), d.y * F(hd[4]));
-					const float uz = fmaxf(d.z * F(hd[2]), d.z * F(hd[5]));
-					skip = ux + uy + uz < -(F(hd[6]) * dmax);
+				{
+					// leaf header (rtxd::LeafHeader): can the reference accept ANY triangle of this leaf for this ray?
+					const u32x16 hd = sload16(p);
+					const float ax = d.x * F(hd[0]), bx = d.x * F(hd[3]);
+					const float ay = d.y * F(hd[1]), by = d.y * F(hd[4]);
+					const float az = d.z * F(hd[2]), bz = d.z * F(hd[5]);
+					const float errd = F(hd[6]) * dmax;
+					// (1) certainly back-facing: U >= dir . (v0v2 x v0v1) = det for every triangle
+					if (CULL) skip = fmaxf(ax, bx) + fmaxf(ay, by) + fmaxf(az, bz) < -errd;
+					// (2) certainly front-facing and entirely behind the ray origin: computed t < 0 for every triangle
+					const float lc = fminf(ax, bx) + fminf(ay, by) + fminf(az, bz);
+					const bool facing = lc >= 4 * errd;
+					if (STATS) cnt.dbg[0] += __popcll(ballot(true));
+					if (STATS) cnt.dbg[1] += __popcll(ballot(facing));
+					if (ballot(facing) != 0) {
+						const float lox = F(hd[8]) - o.x, hix = F(hd[11]) - o.x;
+						const float loy = F(hd[9]) - o.y, hiy = F(hd[12]) - o.y;
+						const float loz = F(hd[10]) - o.z, hiz = F(hd[13]) - o.z;
+						const float boxdot = fmaxf(lox * d.x, hix * d.x) + fmaxf(loy * d.y, hiy * d.y) + fmaxf(loz * d.z, hiz * d.z);
+						const float dinf = fmaxf(fmaxf(fmaxf(fabsf(lox), fabsf(hix)), fmaxf(fabsf(loy), fabsf(hiy))), fmaxf(fabsf(loz), fabsf(hiz)));
+						const float g = lc - 2 * errd;
+						const float need = dmax * dmax * (dinf * F(hd[7]) + F(hd[14])) * 1.02f + 1e-30f;
+						const bool behind = facing && dmax < 1048576.0f && -boxdot * g > need;
+						if (STATS) cnt.dbg[2] += __popcll(ballot(facing && boxdot < 0));
+						if (STATS) cnt.dbg[3] += __popcll(ballot(behind));
+						skip = skip || behind;
+					}
 				}
 				p += 1;
 				if (STATS) { cnt.wLeaves++; if (ballot(!skip) == 0) cnt.wLeafSkips++; }
@@ -801,6 +820,7 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 		atomicAdd(P.counters + 5, c.wNodes); atomicAdd(P.counters + 6, c.wTri); atomicAdd(P.counters + 7, c.wS2);
 		atomicAdd(P.counters + 8, c.wS3); atomicAdd(P.counters + 9, c.wS4);
 		atomicAdd(P.counters + 10, c.wLeaves); atomicAdd(P.counters + 11, c.wLeafSkips);
+		for (int k = 0; k < 4; ++k) atomicAdd(P.counters + 12 + k, c.dbg[k]);
 	}
 }
 
@@ -815,7 +835,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, { 0, 0, 0, 0 } };
 	// XCD-affine work distribution.  Each XCD has its own 4 MB L2; if consecutive tiles went to different XCDs
 	// (one global queue) every L2 would have to hold the triangles of the whole sweep.  Instead the frame is cut
 	// into bands of 8 tile rows (64 pixel rows), band b belongs to queue b % 8, and a wave first drains the queue
@@ -880,7 +900,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, { 0, 0, 0, 0 } };
 	for (;;) {
 		// work item = (tile, chunk) from the list built by rtxSsaaListKernel: chunk c re-renders flagged pixels
 		// 16c .. 16c+15 of the tile; tiles that were expensive in pass 1 come first (longest-job-first)
@@ -968,7 +988,7 @@ __global__ void __launch_bounds__(256) rtxProbeKernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t nWork = (P.nProbe + 63) / 64;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, { 0, 0, 0, 0 } };
 	for (;;) {
 		const uint32_t work = nextWork(P.workCounter);
 		if (work >= nWork) break;
