@@ -187,8 +187,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		leaf.reserve(m.n_refs / 2 + m.n_nodes / 2 + 2);
 		for (uint32_t i = 0; i < m.n_nodes; i++) {
 			Node& nd = nodes[i];
-			memcpy(nd.lo, m.node_bounds + (size_t)i * 6, 12);
-			memcpy(nd.hi, m.node_bounds + (size_t)i * 6 + 3, 12);
+			for (int c = 0; c < 3; c++) { nd.b[2 * c] = m.node_bounds[(size_t)i * 6 + c]; nd.b[2 * c + 1] = m.node_bounds[(size_t)i * 6 + 3 + c]; }
 			if (m.leaf_count[i] < 0) {
 				if (m.node_skip[i] <= (int32_t)i + 1 || m.node_skip[i] > (int32_t)m.n_nodes) return bail(fail(RTX_ERR_ARG, "bad skip index"));
 				nd.link = m.node_skip[i]; nd.first = 0;

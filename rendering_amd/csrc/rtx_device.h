@@ -13,8 +13,7 @@ namespace rtxd {
 //   link  > 0 : inner node; link = pre-order index of the first node after this subtree ("skip")
 //   link  < 0 : leaf with ~link triangles; `first` = index of its LeafHeader in the pair array, pairs follow
 struct Node {
-	float lo[3];
-	float hi[3];
+	float b[6];      // lo.x hi.x | lo.y hi.y | lo.z hi.z : (lo_i, hi_i) pairs are the operands of the packed slab test
 	int32_t link;
 	int32_t first;
 };

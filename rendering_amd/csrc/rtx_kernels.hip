@@ -329,13 +329,13 @@ __device__ __forceinline__ void triTest(uint32_t w0, uint32_t w1, uint32_t w2, u
 	const f2 np = txy * pxn;                                                  // (tx*px, -(ty*py))
 	const float nu = np.x - np.y + tz * pz;                                   // tvec . pvec (objects.cpp:83)
 	if (CULL) {
-		// Exact-safe rejection before the IEEE division.  Here 1e-8 <= det, so inv = RN(1/det) > 0 and
-		// u = RN(nu * inv).  For det < 2^100 (inv >= 2^-100, normal):
-		//   nu < -2^-20            =>  nu*inv <= -2^-120, no underflow to -0   =>  u < 0;
-		//   nu > RN(det*(1+2^-20)) =>  nu/det > 1+2^-21, and two roundings lose < 2^-22  =>  u > 1.
+		// Exact-safe rejection before the IEEE division.  Here 1e-8 <= det, so inv = RN(1/det) > 0 with relative
+		// error <= 2^-22 (2^-24 while 1/det is normal, <= 2^-22 in the denormal range det > 2^126), and u = RN(nu*inv):
+		//   nu < -2^-20            =>  |nu*inv| >= 2^-20 * 2^-128 * (1 - 2^-3) > 2^-149: no underflow to -0  =>  u < 0;
+		//   nu > RN(det*(1+2^-20)) =>  nu/det > 1+2^-21, and the roundings lose < 2^-21                    =>  u > 1.
 		// Lanes outside these sure cases (and every lane of the !CULL variant) take the division below, which
 		// then re-derives the same verdict for the sure cases, so the result is bit-identical either way.
-		const uint64_t sure = ballot(det < 0x1p100f) & (ballot(nu < -0x1p-20f) | ballot(nu > det * (1.0f + 0x1p-20f)));
+		const uint64_t sure = ballot(nu < -0x1p-20f) | ballot(nu > det * (1.0f + 0x1p-20f));
 		if ((m1 & ~sure) == 0) return;
 	}
 	if (STATS) cnt.wS3++;
@@ -372,6 +372,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 	PackedRay pr;
 	pr.dyx = f2{ d.y, d.x }; pr.dxy = f2{ d.x, d.y }; pr.dzz = f2{ d.z, d.z }; pr.oxy = f2{ o.x, o.y };
 	pr.dx = d.x; pr.dy = d.y; pr.dz = d.z; pr.oz = o.z;
+	const f2 oxx = { o.x, o.x }, oyy = { o.y, o.y }, ozz = { o.z, o.z }, ixx = { ix, ix }, iyy = { iy, iy }, izz = { iz, iz };
 	// max |dir_i|, rounded up a little: scales the leaf headers' error bound
 	const float dmax = fmaxf(fabsf(d.x), fmaxf(fabsf(d.y), fabsf(d.z))) * (1.0f + 0x1p-20f);
 	u32x8 nd = sload8(nodes);
@@ -386,10 +387,12 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 		const u32x8 nxA = sload8(nb + (next < last ? next : last));
 		const u32x8 nxB = sload8(nb + (nxt < last ? nxt : last));
 		const bool act = i >= resume;
-		// slab test, objects.cpp:546-567: (bounds[sign] - orig) * invdir per axis, sequential compares
-		const float xlo = (F(nd[0]) - o.x) * ix, xhi = (F(nd[3]) - o.x) * ix;
-		const float ylo = (F(nd[1]) - o.y) * iy, yhi = (F(nd[4]) - o.y) * iy;
-		const float zlo = (F(nd[2]) - o.z) * iz, zhi = (F(nd[5]) - o.z) * iz;
+		// slab test, objects.cpp:546-567: (bounds[sign] - orig) * invdir per axis, sequential compares.
+		// ((lo_i, hi_i) - orig_i) * invdir_i as one packed subtract + one packed multiply per axis
+		const f2 bx = (f2{ F(nd[0]), F(nd[1]) } - oxx) * ixx;
+		const f2 by = (f2{ F(nd[2]), F(nd[3]) } - oyy) * iyy;
+		const f2 bz = (f2{ F(nd[4]), F(nd[5]) } - ozz) * izz;
+		const float xlo = bx.x, xhi = bx.y, ylo = by.x, yhi = by.y, zlo = bz.x, zhi = bz.y;
 		float tmin = sx ? xhi : xlo, tmx = sx ? xlo : xhi;
 		const float tymin = sy ? yhi : ylo, tymax = sy ? ylo : yhi;
 		bool fail = (tmin > tymax) || (tymin > tmx);
