@@ -495,7 +495,6 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	out->rays = c[0]; out->box_tests = c[1]; out->tri_tests = c[2];
 	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] slowest work item %.3f ms, sum of items %.3f ms (100 MHz wall clock)\n", c[3] * 1e-5, c[4] * 1e-5);
 	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] wave-level: node visits %llu, triangle iterations %llu (lane utilisation %.3f), reached u-stage %llu, division %llu, v-stage %llu; leaf visits %llu, skipped by the back-face header %llu\n", c[5], c[6], c[6] ? (double)c[2] / (64.0 * c[6]) : 0.0, c[7], c[8], c[9], c[10], c[11]);
-	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] leaf certificates (lane-level): evaluated %llu, certainly facing %llu, facing and box behind %llu, skipped as behind %llu\n", c[12], c[13], c[14], c[15]);
 	return RTX_OK;
 }
 

@@ -26,6 +26,9 @@
 
 using namespace rtxd;
 
+#ifndef RTX_DBG
+#define RTX_DBG 0     // 1: the instrumented variant also gathers wave-level stage counters (RTX_DEBUG_ITEMS=1 prints them)
+#endif
 #ifndef RTX_WAVES
 #define RTX_WAVES 8   // target waves per SIMD of the two ray kernels (register budget = 512 / RTX_WAVES VGPRs)
 #endif
@@ -279,7 +282,7 @@ __device__ __forceinline__ float attenuation(float intensity, float l2)
 // Render::trace for a whole wave (scene.cpp:724-756)
 // ------------------------------------------------------------------------------------------------
 struct Hit { int obj; float t; uint32_t tri; float u, v; };
-struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips, dbg[4]; };
+struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips; };
 
 // Ordering of scalar loads.  SMEM returns out of order, so lgkmcnt can only be waited down to zero: a load issued
 // before the first use of the previous one is covered by the same wait and nothing overlaps.  after(x, v) is an
@@ -321,9 +324,9 @@ __device__ __forceinline__ void triTest(uint32_t w0, uint32_t w1, uint32_t w2, u
 	// Both compares are false for NaN, exactly like the reference's two ifs (objects.cpp:75-79).
 	const float dd = CULL ? det : fabsf(det);
 	const uint64_t m1 = ballot(!(dd < RTX_EPS8));
-	if (STATS) cnt.wTri++;
+	if (STATS && RTX_DBG) cnt.wTri++;
 	if (m1 == 0) return;
-	if (STATS) cnt.wS2++;
+	if (STATS && RTX_DBG) cnt.wS2++;
 	const f2 txy = r.oxy - v0xy;                                              // tvec = orig - v0 (objects.cpp:82)
 	const float tz = r.oz - v0z;
 	const f2 np = txy * pxn;                                                  // (tx*px, -(ty*py))
@@ -338,12 +341,12 @@ __device__ __forceinline__ void triTest(uint32_t w0, uint32_t w1, uint32_t w2, u
 		const uint64_t sure = ballot(nu < -0x1p-20f) | ballot(nu > det * (1.0f + 0x1p-20f));
 		if ((m1 & ~sure) == 0) return;
 	}
-	if (STATS) cnt.wS3++;
+	if (STATS && RTX_DBG) cnt.wS3++;
 	const float inv = 1 / det;
 	const float u = nu * inv;
 	const uint64_t m2 = m1 & ballot(!(u < 0)) & ballot(!(u > 1));
 	if (m2 == 0) return;
-	if (STATS) cnt.wS4++;
+	if (STATS && RTX_DBG) cnt.wS4++;
 	const float tx = txy.x, ty = txy.y;
 	const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;   // tvec x v0v1
 	const float v = (r.dx * qx + r.dy * qy + r.dz * qz) * inv;
@@ -402,7 +405,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 		fail = fail || (tmin > tzmax) || (tzmin > tmx);
 		const bool pass = act && !fail;
 		if (act && fail) resume = nxt;
-		if (STATS) { cnt.box += __popcll(ballot(act)); cnt.wNodes++; }
+		if (STATS) { cnt.box += __popcll(ballot(act)); if (RTX_DBG) cnt.wNodes++; }
 		const uint64_t m = ballot(pass);
 		if (m == 0) {
 			nd = nxB;
@@ -428,8 +431,6 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 					// (2) certainly front-facing and entirely behind the ray origin: computed t < 0 for every triangle
 					const float lc = fminf(ax, bx) + fminf(ay, by) + fminf(az, bz);
 					const bool facing = lc >= 4 * errd;
-					if (STATS) cnt.dbg[0] += __popcll(ballot(true));
-					if (STATS) cnt.dbg[1] += __popcll(ballot(facing));
 					if (ballot(facing) != 0) {
 						const float lox = F(hd[8]) - o.x, hix = F(hd[11]) - o.x;
 						const float loy = F(hd[9]) - o.y, hiy = F(hd[12]) - o.y;
@@ -439,13 +440,11 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 						const float g = lc - 2 * errd;
 						const float need = dmax * dmax * (dinf * F(hd[7]) + F(hd[14])) * 1.02f + 1e-30f;
 						const bool behind = facing && dmax < 1048576.0f && -boxdot * g > need;
-						if (STATS) cnt.dbg[2] += __popcll(ballot(facing && boxdot < 0));
-						if (STATS) cnt.dbg[3] += __popcll(ballot(behind));
 						skip = skip || behind;
 					}
 				}
 				p += 1;
-				if (STATS) { cnt.wLeaves++; if (ballot(!skip) == 0) cnt.wLeafSkips++; }
+				if (STATS && RTX_DBG) { cnt.wLeaves++; if (ballot(!skip) == 0) cnt.wLeafSkips++; }
 				if (!skip) {
 					// exec = lanes for which some triangle of the leaf may survive the back-face test.
 					// one PAIR of references per trip: wait(pair) -> issue(next pair) -> test both.  The pair after
@@ -823,7 +822,6 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 		atomicAdd(P.counters + 5, c.wNodes); atomicAdd(P.counters + 6, c.wTri); atomicAdd(P.counters + 7, c.wS2);
 		atomicAdd(P.counters + 8, c.wS3); atomicAdd(P.counters + 9, c.wS4);
 		atomicAdd(P.counters + 10, c.wLeaves); atomicAdd(P.counters + 11, c.wLeafSkips);
-		for (int k = 0; k < 4; ++k) atomicAdd(P.counters + 12 + k, c.dbg[k]);
 	}
 }
 
@@ -838,7 +836,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, { 0, 0, 0, 0 } };
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	// XCD-affine work distribution.  Each XCD has its own 4 MB L2; if consecutive tiles went to different XCDs
 	// (one global queue) every L2 would have to hold the triangles of the whole sweep.  Instead the frame is cut
 	// into bands of 8 tile rows (64 pixel rows), band b belongs to queue b % 8, and a wave first drains the queue
@@ -903,7 +901,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, { 0, 0, 0, 0 } };
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	for (;;) {
 		// work item = (tile, chunk) from the list built by rtxSsaaListKernel: chunk c re-renders flagged pixels
 		// 16c .. 16c+15 of the tile; tiles that were expensive in pass 1 come first (longest-job-first)
@@ -991,7 +989,7 @@ __global__ void __launch_bounds__(256) rtxProbeKernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t nWork = (P.nProbe + 63) / 64;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, { 0, 0, 0, 0 } };
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	for (;;) {
 		const uint32_t work = nextWork(P.workCounter);
 		if (work >= nWork) break;
