@@ -439,7 +439,8 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 						const float dinf = fmaxf(fmaxf(fmaxf(fabsf(lox), fabsf(hix)), fmaxf(fabsf(loy), fabsf(hiy))), fmaxf(fabsf(loz), fabsf(hiz)));
 						const float g = lc - 2 * errd;
 						const float need = dmax * dmax * (dinf * F(hd[7]) + F(hd[14])) * 1.02f + 1e-30f;
-						const bool behind = facing && dmax < 1048576.0f && -boxdot * g > need;
+						// (magnitude guards: the error budget assumes no overflow / NaN in the reference's intermediate products)
+						const bool behind = facing && dmax < 0x1p20f && dinf < 0x1p40f && -boxdot * g > need;
 						skip = skip || behind;
 					}
 				}
