@@ -26,8 +26,25 @@ public:
 	void ensureMatrix();          // the lazy part of Camera::getRay (scene.cpp:22-49), done before upload
 };
 
-// Result of one probe ray (Render::trace + Render::castRay at depth 0)
-struct ProbeResult { float hit, object, triangle, t, u, v, pad0, pad1; float colour[3]; };
+// Render::trace's result record (reference: scene.h:17-23)
+struct IntersectInfo {
+	const Object* hitObject = nullptr;
+	float tNear = 3.402823466e+38f;
+	const Triangle* triPtr = nullptr;
+	Vec2f uv{ -1, -1 };
+};
+
+class Scene;
+
+// Single-ray entry points of the reference (scene.h:31-48), evaluated on the GPU through rtx_cast_rays.
+// They take the Scene (which owns the uploaded GPU twin) instead of the bare ObjectVector; castRay supports
+// depth 0 only (deeper levels are internal to the kernel's recursion frames).  Meant for tools and tests --
+// frames go through Scene::launchWorkers.
+class Render {
+public:
+	static bool trace(const Ray& ray, Scene& scene, IntersectInfo& intrInfo);
+	static Vec3f castRay(const Ray& ray, Scene& scene, const int depth);
+};
 
 class Scene {
 public:

@@ -364,6 +364,37 @@ void gpuCheck(int rc, const char* what)
 
 void Scene::invalidateView() { viewDirty_ = true; }
 
+namespace {
+void probeOne(Scene& sc, const Ray& ray, float hit[8], float colour[3])
+{
+	const float r[6] = { ray.orig.x, ray.orig.y, ray.orig.z, ray.dir.x, ray.dir.y, ray.dir.z };
+	gpuCheck(rtx_cast_rays(sc.gpu(), 1, r, hit, colour), "rtx_cast_rays");
+}
+}
+
+bool Render::trace(const Ray& ray, Scene& scene, IntersectInfo& info)
+{
+	if (ray.rayType != RayType::PrimaryRay) { std::cout << "Render::trace: only primary rays can be probed\n"; LOG_ERROR(); }
+	float h[8], c[3];
+	probeOne(scene, ray, h, c);
+	info = IntersectInfo();
+	if (h[0] == 0.0f) return false;
+	info.hitObject = scene.objects[(size_t)h[1]].get();
+	info.tNear = h[3];
+	info.uv = Vec2f(h[4], h[5]);
+	if (info.hitObject->objectType == ObjectType::Mesh)
+		info.triPtr = &static_cast<const Mesh*>(info.hitObject)->allTris[(size_t)h[2]];
+	return true;
+}
+
+Vec3f Render::castRay(const Ray& ray, Scene& scene, const int depth)
+{
+	if (depth != 0) { std::cout << "Render::castRay: depth must be 0 at the API boundary\n"; LOG_ERROR(); }
+	float h[8], c[3];
+	probeOne(scene, ray, h, c);
+	return Vec3f(c[0], c[1], c[2]);
+}
+
 rtx_scene* Scene::gpu()
 {
 	if (!gpu_) {
