@@ -93,6 +93,7 @@ def load():
     host.rah_bvh_dump.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     host.rah_tris.argtypes = [vp, i32, vp]
     host.rah_camera.argtypes = [vp, vp, vp, vp, vp]
+    host.rah_scene_digest.argtypes = [vp, vp, i32]
     _rtx, _host = rtx, host
     return rtx, host
 
@@ -175,6 +176,12 @@ class Scene:
         pos = np.zeros(3, np.float32)
         self.host.rah_camera(self.h, C.byref(scale), C.byref(aspect), _np_ptr(m), _np_ptr(pos))
         return np.float32(scale.value), np.float32(aspect.value), m, pos
+
+    def digest(self):
+        """Numeric fields of all objects and lights as uploaded (loader tests)."""
+        out = np.zeros(4096, np.float32)
+        n = self.host.rah_scene_digest(self.h, _np_ptr(out), out.size)
+        return out[:n].copy()
 
     def bvh(self, obj_idx):
         cnt = np.zeros(5, np.int64)

@@ -244,6 +244,7 @@ __device__ __forceinline__ int toPixel(float v, int mx)               // scene.c
 {
 	int val = (int)((v + 1.0f) / 2.0f * mx);
 	if (val >= mx) val = mx - 1;
+	if (val < 0) val = 0;            // hardening only (NaN / degenerate directions index out of bounds in the reference)
 	return val;
 }
 __device__ __forceinline__ V3 load3(const float* p) { return mk(p[0], p[1], p[2]); }
@@ -270,7 +271,9 @@ __device__ __noinline__ V3 skyColor(const Params& P, V3 dir)           // scene.
 	return load3(P.sky[face] + ((size_t)i * W + j) * 3);
 }
 
-__device__ __forceinline__ int texel(int dim, float coord) { int v = (int)(dim * coord); if (v >= dim) v = dim - 1; return v; }
+// (int)(dim * coord), clamped on the high side like the reference (objects.cpp:144-147, 156-159).  The low-side clamp is
+// hardening only: negative / NaN coordinates are out-of-bounds reads (UB) in the reference.
+__device__ __forceinline__ int texel(int dim, float coord) { int v = (int)(dim * coord); if (v >= dim) v = dim - 1; if (v < 0) v = 0; return v; }
 
 // 4*M_PI*len2/1000 attenuation in fp64 (lights.cpp:35; scene.cpp:796,832,875,925)
 __device__ __forceinline__ float attenuation(float intensity, float l2)

@@ -105,6 +105,46 @@ void rah_camera(void* h, float* scale, float* aspect, float* m16, float* pos3)
 	freeFlatScene(f);
 }
 
+// loadBMP (util.h) into a caller buffer of `cap` bytes; returns the number of bytes the image needs (3*w*h).
+int rah_load_bmp(const char* path, int* w, int* h, unsigned char* out, int cap)
+{
+	unsigned char* d = loadBMP(path, *w, *h);
+	const int need = 3 * *w * *h;
+	if (out && cap >= need) memcpy(out, d, (size_t)need);
+	delete[] d;
+	return need;
+}
+
+// Numeric digest of objects and lights (for loader tests): per object 16 floats
+// [type, material, pos3, color3, ior, ambient, diffuse, specular, nSpecular, r2 | normal.x, ...], per light 12 floats.
+int rah_scene_digest(void* h, float* out, int maxFloats)
+{
+	Scene* s = (Scene*)h;
+	FlatScene* f = flattenScene(*s);
+	const rtx_scene_desc* d = flatDesc(f);
+	int n = 0;
+	auto put = [&](float v) { if (n < maxFloats) out[n] = v; n++; };
+	for (uint32_t i = 0; i < d->n_objects; i++) {
+		const rtx_object& o = d->objects[i];
+		put((float)o.type); put((float)o.material);
+		for (int k = 0; k < 3; k++) put(o.pos[k]);
+		for (int k = 0; k < 3; k++) put(o.color[k]);
+		put(o.ior); put(o.ambient); put(o.diffuse); put(o.specular); put(o.n_specular); put(o.radius2);
+		for (int k = 0; k < 3; k++) put(o.normal[k]);
+	}
+	for (uint32_t i = 0; i < d->n_lights; i++) {
+		const rtx_light& l = d->lights[i];
+		put((float)l.type);
+		for (int k = 0; k < 3; k++) put(l.color[k]);
+		put(l.intensity);
+		for (int k = 0; k < 3; k++) put(l.dir[k]);
+		for (int k = 0; k < 3; k++) put(l.pos[k]);
+		put((float)l.n_points);
+	}
+	freeFlatScene(f);
+	return n;
+}
+
 // The uploaded GPU scene (created on first use; exits through LOG_ERROR when no GPU is available).
 rtx_scene* rah_scene_gpu(void* h) { return ((Scene*)h)->gpu(); }
 

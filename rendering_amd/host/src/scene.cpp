@@ -58,7 +58,11 @@ void parseOption(Scene& sc, const KeyValue& kv)
 	else if (k == "width") sc.options.width = strToInt(v);
 	else if (k == "height") sc.options.height = strToInt(v);
 	else if (k == "fov") sc.camera.fov = strToFloat(v);
-	else if (k == "image_name") sc.options.imageName = v;
+	else if (k == "image_name") {
+		sc.options.imageName = v;
+		// legacy files quote the name
+		sc.options.imageName.erase(std::remove(sc.options.imageName.begin(), sc.options.imageName.end(), '"'), sc.options.imageName.end());
+	}
 	else if (k == "n_workers") sc.options.nWorkers = strToInt(v);
 	else if (k == "max_ray_depth") sc.options.maxRayDepth = strToInt(v);
 	else if (k == "ac_penalty") sc.options.acPenalty = strToInt(v);
@@ -145,6 +149,92 @@ void parseObject(Scene& sc, std::unique_ptr<Object>& object, const KeyValue& kv)
 	}
 }
 
+// ---- legacy dialect (hardening) ------------------------------------------------
+// The reference ships input/smooth_shading.scene in an older one-line-per-entity form that its current loader
+// rejects (LOG_ERROR at scene.cpp:200-201):
+//     [light]   name, point_light|distant_light, x,y,z, r,g,b, intensity
+//     [object]  name, plane,  px,py,pz, nx,ny,nz, r,g,b, material
+//               name, sphere, px,py,pz, radius,   r,g,b, material
+//               name, mesh, "file.obj", px,py,pz, sx,sy,sz [, r,g,b [, material]]
+// material = none | diffuse | reflective | transparent[:ior] | phong:ambient:diffuse:specular:n
+// A line without '=' inside [light]/[object] is read this way and becomes one entity.
+std::vector<std::string> legacyFields(const std::string& line)
+{
+	std::vector<std::string> out;
+	for (std::string cell : splitString(line, ',')) {
+		cell.erase(std::remove_if(cell.begin(), cell.end(), [](char c) { return c == ' ' || c == '\t' || c == '"' || c == '\r'; }), cell.end());
+		out.push_back(cell);
+	}
+	while (!out.empty() && out.back().empty()) out.pop_back();
+	return out;
+}
+
+Vec3f legacy3(const std::vector<std::string>& f, size_t at)
+{
+	if (at + 3 > f.size()) LOG_ERROR();
+	return Vec3f(strToFloat(f[at]), strToFloat(f[at + 1]), strToFloat(f[at + 2]));
+}
+
+void legacyMaterial(Object& o, const std::string& token)
+{
+	const auto parts = splitString(token, ':');
+	if (parts.empty() || parts[0] == "none" || parts[0] == "diffuse") return;
+	if (parts[0] == "reflective") o.materialType = MaterialType::Reflective;
+	else if (parts[0] == "transparent") {
+		o.materialType = MaterialType::Transparent;
+		if (parts.size() > 1) o.indexOfRefraction = strToFloat(parts[1]);
+	}
+	else if (parts[0] == "phong") {
+		if (parts.size() < 5) LOG_ERROR();
+		o.materialType = MaterialType::Phong;
+		o.ambient = strToFloat(parts[1]); o.diffuse = strToFloat(parts[2]); o.specular = strToFloat(parts[3]); o.nSpecular = strToFloat(parts[4]);
+	}
+	else LOG_ERROR();
+}
+
+void parseLegacyLight(Scene& sc, const std::string& line)
+{
+	const auto f = legacyFields(line);
+	if (f.size() < 9) LOG_ERROR();
+	std::unique_ptr<Light> l;
+	if (f[1] == "point_light" || f[1] == "point") { auto p = std::make_unique<PointLight>(); p->pos = legacy3(f, 2); l = std::move(p); }
+	else if (f[1] == "distant_light" || f[1] == "distant") { auto p = std::make_unique<DistantLight>(); p->dir = legacy3(f, 2); l = std::move(p); }
+	else LOG_ERROR();
+	l->color = legacy3(f, 5);
+	l->intensity = strToFloat(f[8]);
+	sc.lights.push_back(std::move(l));
+}
+
+void parseLegacyObject(Scene& sc, const std::string& line)
+{
+	const auto f = legacyFields(line);
+	if (f.size() < 2) LOG_ERROR();
+	if (f[1] == "plane") {
+		if (f.size() < 11) LOG_ERROR();
+		auto p = std::make_unique<Plane>();
+		p->pos = legacy3(f, 2); p->normal = legacy3(f, 5); p->color = legacy3(f, 8);
+		if (f.size() > 11) legacyMaterial(*p, f[11]);
+		sc.objects.push_back(std::move(p));
+	}
+	else if (f[1] == "sphere") {
+		if (f.size() < 9) LOG_ERROR();
+		auto p = std::make_unique<Sphere>();
+		p->pos = legacy3(f, 2); p->r = strToFloat(f[5]); p->r2 = p->r * p->r; p->color = legacy3(f, 6);
+		if (f.size() > 9) legacyMaterial(*p, f[9]);
+		sc.objects.push_back(std::move(p));
+	}
+	else if (f[1] == "mesh") {
+		if (f.size() < 9) LOG_ERROR();
+		auto p = std::make_unique<Mesh>();
+		p->pos = legacy3(f, 3); p->size = legacy3(f, 6);
+		if (f.size() >= 12) p->color = legacy3(f, 9);
+		if (f.size() > 12) legacyMaterial(*p, f[12]);
+		p->loadOBJ(f[2], sc.options);
+		sc.objects.push_back(std::move(p));
+	}
+	else LOG_ERROR();
+}
+
 } // namespace
 
 Scene::Scene(const std::string& sceneName) { sceneLoadSuccess = loadScene(sceneName); }
@@ -164,10 +254,12 @@ bool Scene::loadScene(const std::string& scenePath)
 	enum class Block { None, Options, Light, Object } block = Block::None;
 	std::unique_ptr<Light> light;
 	std::unique_ptr<Object> object;
+	bool legacyBlock = false;     // the current [light]/[object] block held legacy one-line entities
 	// a block is committed when the next line containing '[' is read (scene.cpp:96-107)
 	auto commit = [&]() {
-		if (block == Block::Light) { if (!light) LOG_ERROR(); lights.push_back(std::move(light)); }
-		else if (block == Block::Object) { if (!object) LOG_ERROR(); objects.push_back(std::move(object)); }
+		if (block == Block::Light) { if (light) lights.push_back(std::move(light)); else if (!legacyBlock) LOG_ERROR(); }
+		else if (block == Block::Object) { if (object) objects.push_back(std::move(object)); else if (!legacyBlock) LOG_ERROR(); }
+		legacyBlock = false;
 	};
 	std::string line;
 	while (in.good()) {
@@ -190,8 +282,14 @@ bool Scene::loadScene(const std::string& scenePath)
 		}
 		switch (block) {
 		case Block::Options: parseOption(*this, splitKeyValue(line, true)); break;
-		case Block::Light: parseLight(light, splitKeyValue(line, false)); break;
-		case Block::Object: parseObject(*this, object, splitKeyValue(line, false)); break;
+		case Block::Light:
+			if (!contains(line, "=") && contains(line, ",")) { parseLegacyLight(*this, line); legacyBlock = true; }
+			else parseLight(light, splitKeyValue(line, false));
+			break;
+		case Block::Object:
+			if (!contains(line, "=") && contains(line, ",")) { parseLegacyObject(*this, line); legacyBlock = true; }
+			else parseObject(*this, object, splitKeyValue(line, false));
+			break;
 		case Block::None: break;
 		}
 	}

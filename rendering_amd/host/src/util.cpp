@@ -8,6 +8,7 @@
 #include <iomanip>
 #include <iostream>
 #include <sstream>
+#include <vector>
 
 #include "stats.h"
 #include "timer.h"
@@ -95,21 +96,38 @@ int saveImage(const Vec3f* fb, const Options& options)
 
 unsigned char* loadBMP(const char* filename, int& width, int& height)
 {
+	// Same result as the reference (util.cpp:78-113) for the files it can read -- 54-byte header, 24 bpp, no row
+	// padding: rows stay bottom-up, channels come back as RGB.  Hardened: honours the pixel
+	// data offset, row padding (width % 4 != 0), 32 bpp and top-down files (negative height) instead of
+	// mis-reading them.
 	FILE* f = fopen(filename, "rb");
 	if (!f) {
 		std::cout << "Could not open .bmp file: " << filename << '\n';
 		LOG_ERROR();
 	}
 	unsigned char hdr[54];
-	if (fread(hdr, 1, 54, f) != 54) { fclose(f); LOG_ERROR(); }
-	memcpy(&width, hdr + 18, 4);
-	memcpy(&height, hdr + 22, 4);
-	const size_t n = (size_t)3 * width * height;
-	unsigned char* data = new unsigned char[n];
-	const size_t got = fread(data, 1, n, f);
-	(void)got;
+	if (fread(hdr, 1, 54, f) != 54 || hdr[0] != 'B' || hdr[1] != 'M') { fclose(f); std::cout << "Not a BMP file: " << filename << '\n'; LOG_ERROR(); }
+	uint32_t dataOffset; int32_t w, h; uint16_t bpp;
+	memcpy(&dataOffset, hdr + 10, 4); memcpy(&w, hdr + 18, 4); memcpy(&h, hdr + 22, 4); memcpy(&bpp, hdr + 28, 2);
+	const bool topDown = h < 0;
+	if (topDown) h = -h;
+	if (w <= 0 || h <= 0 || (bpp != 24 && bpp != 32)) { fclose(f); std::cout << "Unsupported BMP (need 24/32 bpp): " << filename << '\n'; LOG_ERROR(); }
+	width = w; height = h;
+	if (dataOffset < 54) dataOffset = 54;
+	const size_t bytesPP = bpp / 8, rowBytes = ((size_t)w * bytesPP + 3) & ~(size_t)3;
+	std::vector<unsigned char> row(rowBytes);
+	unsigned char* data = new unsigned char[(size_t)3 * w * h];
+	fseek(f, (long)dataOffset, SEEK_SET);
+	for (int y = 0; y < h; ++y) {
+		if (fread(row.data(), 1, rowBytes, f) != rowBytes) memset(row.data(), 0, rowBytes);   // truncated file: black
+		unsigned char* dst = data + (size_t)3 * w * (topDown ? (h - 1 - y) : y);             // keep file order = bottom-up
+		for (int x = 0; x < w; ++x) {
+			dst[x * 3 + 0] = row[x * bytesPP + 2];     // BGR -> RGB
+			dst[x * 3 + 1] = row[x * bytesPP + 1];
+			dst[x * 3 + 2] = row[x * bytesPP + 0];
+		}
+	}
 	fclose(f);
-	for (size_t i = 0; i + 2 < n; i += 3) { unsigned char t = data[i]; data[i] = data[i + 2]; data[i + 2] = t; }
 	return data;
 }
 

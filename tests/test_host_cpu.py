@@ -80,3 +80,57 @@ def test_host_save_bmp_matches_reference_bytes(ra, tmp_path):
     s = ra.Scene("scenes/cfg1_simple_shapes.scene", 8, 4)
     assert s.save_bmp(g["quant_fb"], str(tmp_path / "q")) == 0
     assert open(str(tmp_path / "q.bmp"), "rb").read() == g["quant_bmp"].tobytes()
+
+
+def test_legacy_dialect_equals_current_dialect(ra):
+    """Loader hardening: the reference's own input/smooth_shading.scene is written in an older
+    one-line-per-entity dialect its current loader rejects.  The host loader reads it; the legacy transliteration
+    of cfg2 must flatten to exactly the same scene as the current-dialect file."""
+    a = ra.Scene("scenes/legacy_smooth_4k.scene", 96, 64)
+    b = ra.Scene("scenes/cfg2_smooth_4k.scene", 96, 64)
+    assert (a.n_objects, a.n_lights) == (b.n_objects, b.n_lights) == (2, 3)
+    assert np.array_equal(a.digest().view(np.uint32), b.digest().view(np.uint32))
+    for x, y in zip(a.camera(), b.camera()):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    da, db = a.bvh(1), b.bvh(1)
+    for k in db:
+        assert np.array_equal(da[k], db[k]) if isinstance(db[k], np.ndarray) else da[k] == db[k]
+
+
+def test_bmp_loader_hardening(ra, tmp_path):
+    """Row padding (width % 4 != 0), 32 bpp, pixel-data offset and top-down files load to the same texels as the
+    plain 24-bpp file the reference can read (util.cpp:78-113)."""
+    import struct
+    import ctypes as C
+    _, host = ra.load()
+    host.rah_load_bmp.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int]
+    rng = np.random.default_rng(3)
+
+    def load(path):
+        w, h = C.c_int(), C.c_int()
+        buf = np.zeros(1 << 16, np.uint8)
+        n = host.rah_load_bmp(str(path).encode(), C.byref(w), C.byref(h), buf.ctypes.data_as(C.c_void_p), buf.size)
+        return buf[:n].reshape(h.value, w.value, 3).copy()
+
+    def write(path, rgb, bpp=24, top_down=False, extra=0):
+        h, w, _ = rgb.shape
+        rows = rgb if top_down else rgb[::-1]
+        body = b""
+        for r in rows:
+            px = np.concatenate([r[:, ::-1], np.full((w, 1), 255, np.uint8)], 1) if bpp == 32 else r[:, ::-1]
+            line = px.astype(np.uint8).tobytes()
+            body += line + b"\0" * ((-len(line)) % 4)
+        off = 54 + extra
+        hdr = b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off)
+        hdr += struct.pack("<IiiHHIIiiII", 40, w, -h if top_down else h, 1, bpp, 0, len(body), 2835, 2835, 0, 0)
+        open(path, "wb").write(hdr + b"\x55" * extra + body)
+
+    img = rng.integers(0, 256, (6, 8, 3), dtype=np.uint8)           # row 0 = top
+    write(tmp_path / "plain.bmp", img)
+    ref = load(tmp_path / "plain.bmp")
+    assert np.array_equal(ref, img[::-1])                            # rows stay bottom-up, channels RGB
+    write(tmp_path / "b32.bmp", img, bpp=32); assert np.array_equal(load(tmp_path / "b32.bmp"), ref)
+    write(tmp_path / "td.bmp", img, top_down=True); assert np.array_equal(load(tmp_path / "td.bmp"), ref)
+    write(tmp_path / "off.bmp", img, extra=84); assert np.array_equal(load(tmp_path / "off.bmp"), ref)
+    odd = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)            # 7*3 = 21 bytes per row -> 3 bytes of padding
+    write(tmp_path / "odd.bmp", odd); assert np.array_equal(load(tmp_path / "odd.bmp"), odd[::-1])
