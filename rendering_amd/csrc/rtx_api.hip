@@ -50,6 +50,95 @@ template <typename T> int upload(std::vector<void*>& owned, const T* src, size_t
 
 } // namespace
 
+namespace {
+
+// (v0, e1, e2, tri) record of leaf reference r (objects.cpp:70-71: v0v1 = v1 - v0, v0v2 = v2 - v0)
+LeafTri makeLeafTri(const rtx_mesh& m, uint32_t ref)
+{
+	const uint32_t t = m.refs[ref];
+	const float* p = m.tri_pos + (size_t)t * 9;
+	LeafTri lt;
+	lt.e1x = p[3] - p[0]; lt.e1y = p[4] - p[1]; lt.e1z = p[5] - p[2];
+	lt.e2x = p[6] - p[0]; lt.e2y = p[7] - p[1]; lt.e2z = p[8] - p[2];
+	lt.v0x = p[0]; lt.v0y = p[1]; lt.v0z = p[2];
+	lt.tri = t;
+	return lt;
+}
+
+void appendPairs(std::vector<LeafPair>& leaf, const rtx_mesh& m, uint32_t begin, uint32_t count)
+{
+	for (uint32_t k = 0; k < count; k += 2) {
+		LeafPair lp;
+		memset(&lp, 0, sizeof(lp));          // odd count: the second record stays degenerate (det == 0)
+		lp.t[0] = makeLeafTri(m, begin + k);
+		if (k + 1 < count) lp.t[1] = makeLeafTri(m, begin + k + 1);
+		leaf.push_back(lp);
+	}
+}
+
+// Certificate header (rtxd::LeafHeader) over leaf references [begin, begin+count), as a pair slot.
+LeafPair makeHeader(const rtx_mesh& m, uint32_t begin, uint32_t count)
+{
+	double mlo[3] = { 1e300, 1e300, 1e300 }, mhi[3] = { -1e300, -1e300, -1e300 };
+	double blo[3] = { 1e300, 1e300, 1e300 }, bhi[3] = { -1e300, -1e300, -1e300 };
+	double qmax = 0, q2max = 0, e1L1 = 0, e2L1 = 0, e1Len = 0, e2Len = 0;
+	for (uint32_t r = 0; r < count; r++) {
+		const LeafTri lt = makeLeafTri(m, begin + r);
+		const float* p = m.tri_pos + (size_t)lt.tri * 9;
+		// m = e2 x e1 and the error scales, in fp64 from the fp32 edges
+		const double e1[3] = { lt.e1x, lt.e1y, lt.e1z }, e2[3] = { lt.e2x, lt.e2y, lt.e2z };
+		const double mm[3] = { e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0] };
+		double q = 0, q2 = 0;
+		for (int c = 0; c < 3; c++) {
+			mlo[c] = std::min(mlo[c], mm[c]); mhi[c] = std::max(mhi[c], mm[c]);
+			q += std::fabs(e1[c]) * (std::fabs(e2[(c + 1) % 3]) + std::fabs(e2[(c + 2) % 3]));
+			q2 += std::fabs(e2[c]) * (std::fabs(e1[(c + 1) % 3]) + std::fabs(e1[(c + 2) % 3]));
+			for (int v = 0; v < 3; v++) { blo[c] = std::min(blo[c], (double)p[v * 3 + c]); bhi[c] = std::max(bhi[c], (double)p[v * 3 + c]); }
+		}
+		qmax = std::max(qmax, q); q2max = std::max(q2max, q2);
+		e1L1 = std::max(e1L1, std::fabs(e1[0]) + std::fabs(e1[1]) + std::fabs(e1[2]));
+		e2L1 = std::max(e2L1, std::fabs(e2[0]) + std::fabs(e2[1]) + std::fabs(e2[2]));
+		e1Len = std::max(e1Len, std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]));
+		e2Len = std::max(e2Len, std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]));
+	}
+	LeafHeader h;
+	memset(&h, 0, sizeof(h));
+	double mabs = 0;
+	bool finite = count > 0;
+	for (int c = 0; c < 3 && finite; c++) {
+		if (!std::isfinite(mlo[c]) || !std::isfinite(mhi[c]) || std::fabs(mlo[c]) > 1e30 || std::fabs(mhi[c]) > 1e30) finite = false;
+		else {
+			// outward rounding to fp32 (one extra ulp absorbs the fp64 rounding of mm)
+			float lo = (float)mlo[c], hi = (float)mhi[c];
+			lo = std::nextafterf(std::nextafterf(lo, -INFINITY), -INFINITY);
+			hi = std::nextafterf(std::nextafterf(hi, INFINITY), INFINITY);
+			h.mlo[c] = lo; h.mhi[c] = hi;
+			mabs += std::max(std::fabs((double)lo), std::fabs((double)hi));
+		}
+	}
+	const double u = 5.9604644775390625e-08;      // 2^-24
+	const double err = (8 * u * qmax + 4 * u * mabs) * 1.001 + 1e-30;
+	if (!finite || !(err < 1e30)) { h.mlo[0] = h.mlo[1] = h.mlo[2] = -INFINITY; h.mhi[0] = h.mhi[1] = h.mhi[2] = INFINITY; h.err = INFINITY; finite = false; }
+	else h.err = std::nextafterf((float)err, INFINITY);
+	// certificate (2): coefficients of the error budget, rounded up; disabled (inf) for headers whose magnitudes
+	// leave the range the derivation assumes
+	const double r3 = 1.7320508075688772;
+	const double A1 = (r3 * 32 * u * (e2L1 * e1Len + e1L1 * e2Len) + 24 * u * q2max + 13 * u * mabs) * 1.05;
+	const double A2 = (r3 * (16 * u * qmax + 6 * u * mabs) * (e1Len + e2Len)) * 1.05 + 1e-30;
+	const bool ok2 = finite && qmax < 1048576.0 && q2max < 1048576.0 && A1 < 1e30 && A2 < 1e30;
+	for (int c = 0; c < 3; c++) {
+		h.blo[c] = ok2 ? std::nextafterf((float)blo[c], -INFINITY) : -INFINITY;
+		h.bhi[c] = ok2 ? std::nextafterf((float)bhi[c], INFINITY) : INFINITY;
+	}
+	h.a1 = ok2 ? std::nextafterf((float)A1, INFINITY) : INFINITY;
+	h.a2 = ok2 ? std::nextafterf((float)A2, INFINITY) : INFINITY;
+	LeafPair out;
+	memcpy(&out, &h, sizeof(out));
+	return out;
+}
+
+} // namespace
+
 struct rtx_scene {
 	int device = 0;
 	int numCUs = 0;
@@ -196,79 +285,17 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			const uint32_t begin = (uint32_t)m.leaf_begin[i], count = (uint32_t)m.leaf_count[i];
 			if (begin + count > m.n_refs) return bail(fail(RTX_ERR_ARG, "leaf range out of bounds"));
 			nd.link = ~m.leaf_count[i]; nd.first = (int32_t)leaf.size();
-			const size_t hdrAt = leaf.size();
-			{ LeafPair z; memset(&z, 0, sizeof(z)); leaf.push_back(z); }     // header slot, filled below
-			double mlo[3] = { 1e300, 1e300, 1e300 }, mhi[3] = { -1e300, -1e300, -1e300 }, qmax = 0;
-			double blo[3] = { 1e300, 1e300, 1e300 }, bhi[3] = { -1e300, -1e300, -1e300 };
-			double q2max = 0, e1L1 = 0, e2L1 = 0, e1Len = 0, e2Len = 0;
-			for (uint32_t k = 0; k < count; k += 2) {
-				LeafPair lp;
-				memset(&lp, 0, sizeof(lp));          // odd leaf: second record stays degenerate (det == 0)
-				for (uint32_t j = 0; j < 2 && k + j < count; j++) {
-					const uint32_t t = m.refs[begin + k + j];
-					if (t >= m.n_tris) return bail(fail(RTX_ERR_ARG, "leaf reference out of range"));
-					const float* p = m.tri_pos + (size_t)t * 9;
-					LeafTri& lt = lp.t[j];
-					// v0v1 = v1 - v0, v0v2 = v2 - v0 (objects.cpp:70-71)
-					lt.e1x = p[3] - p[0]; lt.e1y = p[4] - p[1]; lt.e1z = p[5] - p[2];
-					lt.e2x = p[6] - p[0]; lt.e2y = p[7] - p[1]; lt.e2z = p[8] - p[2];
-					lt.v0x = p[0]; lt.v0y = p[1]; lt.v0z = p[2];
-					lt.tri = t;
-					// header statistics: m = e2 x e1 and the det error scale, in fp64 from the fp32 edges
-					const double e1[3] = { lt.e1x, lt.e1y, lt.e1z }, e2[3] = { lt.e2x, lt.e2y, lt.e2z };
-					const double mm[3] = { e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0] };
-					double q = 0;
-					for (int c = 0; c < 3; c++) {
-						mlo[c] = std::min(mlo[c], mm[c]); mhi[c] = std::max(mhi[c], mm[c]);
-						q += std::fabs(e1[c]) * (std::fabs(e2[(c + 1) % 3]) + std::fabs(e2[(c + 2) % 3]));
-					}
-					qmax = std::max(qmax, q);
-					double q2 = 0;
-					for (int c = 0; c < 3; c++) {
-						q2 += std::fabs(e2[c]) * (std::fabs(e1[(c + 1) % 3]) + std::fabs(e1[(c + 2) % 3]));
-						for (int v = 0; v < 3; v++) { blo[c] = std::min(blo[c], (double)p[v * 3 + c]); bhi[c] = std::max(bhi[c], (double)p[v * 3 + c]); }
-					}
-					q2max = std::max(q2max, q2);
-					e1L1 = std::max(e1L1, std::fabs(e1[0]) + std::fabs(e1[1]) + std::fabs(e1[2]));
-					e2L1 = std::max(e2L1, std::fabs(e2[0]) + std::fabs(e2[1]) + std::fabs(e2[2]));
-					e1Len = std::max(e1Len, std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]));
-					e2Len = std::max(e2Len, std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]));
+			for (uint32_t r = 0; r < count; r++)
+				if (m.refs[begin + r] >= m.n_tris) return bail(fail(RTX_ERR_ARG, "leaf reference out of range"));
+			// [leaf header] pairs...   or   [leaf header] { [chunk header] 8 pairs }...
+			leaf.push_back(makeHeader(m, begin, count));
+			if (count <= kChunkTris) appendPairs(leaf, m, begin, count);
+			else {
+				for (uint32_t c = 0; c < count; c += kChunkTris) {
+					const uint32_t cn = std::min(kChunkTris, count - c);
+					leaf.push_back(makeHeader(m, begin + c, cn));
+					appendPairs(leaf, m, begin + c, cn);
 				}
-				leaf.push_back(lp);
-			}
-			{
-				LeafHeader h;
-				memset(&h, 0, sizeof(h));
-				double mabs = 0;
-				bool finite = count > 0;
-				for (int c = 0; c < 3 && finite; c++) {
-					if (!std::isfinite(mlo[c]) || !std::isfinite(mhi[c]) || std::fabs(mlo[c]) > 1e30 || std::fabs(mhi[c]) > 1e30) finite = false;
-					else {
-						// outward rounding to fp32 (one extra ulp absorbs the fp64 rounding of mm)
-						float lo = (float)mlo[c], hi = (float)mhi[c];
-						lo = std::nextafterf(std::nextafterf(lo, -INFINITY), -INFINITY);
-						hi = std::nextafterf(std::nextafterf(hi, INFINITY), INFINITY);
-						h.mlo[c] = lo; h.mhi[c] = hi;
-						mabs += std::max(std::fabs((double)lo), std::fabs((double)hi));
-					}
-				}
-				const double u = 5.9604644775390625e-08;      // 2^-24
-				const double err = (8 * u * qmax + 4 * u * mabs) * 1.001 + 1e-30;
-				if (!finite || !(err < 1e30)) { h.mlo[0] = h.mlo[1] = h.mlo[2] = -INFINITY; h.mhi[0] = h.mhi[1] = h.mhi[2] = INFINITY; h.err = INFINITY; }
-				else h.err = std::nextafterf((float)err, INFINITY);
-				// certificate (2): coefficients of the error budget, rounded up; disabled (inf) for
-				// leaves whose magnitudes leave the range the derivation assumes
-				const double r3 = 1.7320508075688772;
-				const double A1 = (r3 * 32 * u * (e2L1 * e1Len + e1L1 * e2Len) + 24 * u * q2max + 13 * u * mabs) * 1.05;
-				const double A2 = (r3 * (16 * u * qmax + 6 * u * mabs) * (e1Len + e2Len)) * 1.05 + 1e-30;
-				const bool ok2 = finite && std::isfinite(h.err) && qmax < 1048576.0 && q2max < 1048576.0 && A1 < 1e30 && A2 < 1e30;
-				for (int c = 0; c < 3; c++) {
-					h.blo[c] = ok2 ? std::nextafterf((float)blo[c], -INFINITY) : -INFINITY;
-					h.bhi[c] = ok2 ? std::nextafterf((float)bhi[c], INFINITY) : INFINITY;
-				}
-				h.a1 = ok2 ? std::nextafterf((float)A1, INFINITY) : INFINITY;
-				h.a2 = ok2 ? std::nextafterf((float)A2, INFINITY) : INFINITY;
-				memcpy(&leaf[hdrAt], &h, sizeof(h));
 			}
 		}
 		{ LeafPair z; memset(&z, 0, sizeof(z)); leaf.push_back(z); leaf.push_back(z); }

@@ -360,6 +360,55 @@ __device__ __forceinline__ void triTest(uint32_t w0, uint32_t w1, uint32_t w2, u
 	if ((m4 >> __lane_id()) & 1ull) { bt = t; bu = u; bv = v; btri = w9; }
 }
 
+// Leaf / chunk certificates (rtxd::LeafHeader): true when the reference is CERTAIN to reject every
+// triangle the header covers for this ray, so the lane may be masked out of them.
+template <bool CULL>
+__device__ __forceinline__ bool certainlyRejected(const u32x16& hd, const V3& o, const V3& d, float dmax)
+{
+	const float ax = d.x * F(hd[0]), bx = d.x * F(hd[3]);
+	const float ay = d.y * F(hd[1]), by = d.y * F(hd[4]);
+	const float az = d.z * F(hd[2]), bz = d.z * F(hd[5]);
+	const float errd = F(hd[6]) * dmax;
+	bool skip = false;
+	// (1) certainly back-facing: U >= dir . (v0v2 x v0v1) = det for every triangle
+	if (CULL) skip = fmaxf(ax, bx) + fmaxf(ay, by) + fmaxf(az, bz) < -errd;
+	// (2) certainly front-facing and entirely behind the ray origin: computed t < 0 for every triangle
+	const float lc = fminf(ax, bx) + fminf(ay, by) + fminf(az, bz);
+	const bool facing = lc >= 4 * errd;
+	if (ballot(facing) != 0) {
+		const float lox = F(hd[8]) - o.x, hix = F(hd[11]) - o.x;
+		const float loy = F(hd[9]) - o.y, hiy = F(hd[12]) - o.y;
+		const float loz = F(hd[10]) - o.z, hiz = F(hd[13]) - o.z;
+		const float boxdot = fmaxf(lox * d.x, hix * d.x) + fmaxf(loy * d.y, hiy * d.y) + fmaxf(loz * d.z, hiz * d.z);
+		const float dinf = fmaxf(fmaxf(fmaxf(fabsf(lox), fabsf(hix)), fmaxf(fabsf(loy), fabsf(hiy))), fmaxf(fabsf(loz), fabsf(hiz)));
+		const float g = lc - 2 * errd;
+		const float need = dmax * dmax * (dinf * F(hd[7]) + F(hd[14])) * 1.02f + 1e-30f;
+		// (magnitude guards: the error budget assumes no overflow / NaN in the reference's intermediate products)
+		const bool behind = facing && dmax < 0x1p20f && dinf < 0x1p40f && -boxdot * g > need;
+		skip = skip || behind;
+	}
+	return skip;
+}
+
+// Streams `pairs` leaf-reference pairs starting at p through triTest for the lanes in exec: wait(pair) -> issue(next
+// pair) -> test both.  The pair after the last one is fetched and ignored (a header, the next leaf, or padding).
+template <bool CULL, bool STATS>
+__device__ __forceinline__ void testPairs(const LeafPair* p, uint32_t pairs, const PackedRay& pr, float& bt, float& bu, float& bv,
+                                          uint32_t& btri, Counts& cnt)
+{
+	TriPair t0 = sloadPair(p);
+	for (uint32_t left = pairs;;) {
+		p = after(p, t0.b[3]);
+		const TriPair t1 = sloadPair(p + 1);
+		triTest<CULL, STATS>(t0.a[0], t0.a[1], t0.a[2], t0.a[3], t0.a[4], t0.a[5], t0.a[6], t0.a[7], t0.a[8], t0.a[9], pr, bt, bu, bv, btri, cnt);
+		triTest<CULL, STATS>(t0.a[10], t0.a[11], t0.a[12], t0.a[13], t0.a[14], t0.a[15], t0.b[0], t0.b[1], t0.b[2], t0.b[3], pr, bt, bu, bv, btri, cnt);
+		if (left == 1) break;
+		left = uni(left - 1);
+		p += 1;
+		t0 = t1;
+	}
+}
+
 // AccelerationStructure::intersectAccelStruct (objects.cpp:587-631) for a whole wave: stackless pre-order walk.
 // A hit exists iff bt < FLT_MAX on return (the first accepted t is < FLT_MAX by objects.cpp:598,623).
 template <bool STATS, bool CULL>
@@ -419,52 +468,23 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 			const uint32_t n = (uint32_t)~link;
 			if (STATS) cnt.tri += (unsigned long long)__popcll(m) * n;
 			if (n != 0 && pass) {
-				// exec = the lanes that passed this leaf's box
+				// exec = the lanes that passed this leaf's box.  Leaf layout: [leaf header] pairs...  for n <= 16, and
+				// [leaf header] { [chunk header] 8 pairs }...  for larger leaves (rtxd::kChunkTris triangles per chunk).
 				const LeafPair* p = leaf + nd[7];
-				bool skip = false;
-				{
-					// leaf header (rtxd::LeafHeader): can the reference accept ANY triangle of this leaf for this ray?
-					const u32x16 hd = sload16(p);
-					const float ax = d.x * F(hd[0]), bx = d.x * F(hd[3]);
-					const float ay = d.y * F(hd[1]), by = d.y * F(hd[4]);
-					const float az = d.z * F(hd[2]), bz = d.z * F(hd[5]);
-					const float errd = F(hd[6]) * dmax;
-					// (1) certainly back-facing: U >= dir . (v0v2 x v0v1) = det for every triangle
-					if (CULL) skip = fmaxf(ax, bx) + fmaxf(ay, by) + fmaxf(az, bz) < -errd;
-					// (2) certainly front-facing and entirely behind the ray origin: computed t < 0 for every triangle
-					const float lc = fminf(ax, bx) + fminf(ay, by) + fminf(az, bz);
-					const bool facing = lc >= 4 * errd;
-					if (ballot(facing) != 0) {
-						const float lox = F(hd[8]) - o.x, hix = F(hd[11]) - o.x;
-						const float loy = F(hd[9]) - o.y, hiy = F(hd[12]) - o.y;
-						const float loz = F(hd[10]) - o.z, hiz = F(hd[13]) - o.z;
-						const float boxdot = fmaxf(lox * d.x, hix * d.x) + fmaxf(loy * d.y, hiy * d.y) + fmaxf(loz * d.z, hiz * d.z);
-						const float dinf = fmaxf(fmaxf(fmaxf(fabsf(lox), fabsf(hix)), fmaxf(fabsf(loy), fabsf(hiy))), fmaxf(fabsf(loz), fabsf(hiz)));
-						const float g = lc - 2 * errd;
-						const float need = dmax * dmax * (dinf * F(hd[7]) + F(hd[14])) * 1.02f + 1e-30f;
-						// (magnitude guards: the error budget assumes no overflow / NaN in the reference's intermediate products)
-						const bool behind = facing && dmax < 0x1p20f && dinf < 0x1p40f && -boxdot * g > need;
-						skip = skip || behind;
-					}
-				}
+				const bool skip = certainlyRejected<CULL>(sload16(p), o, d, dmax);
 				p += 1;
 				if (STATS && RTX_DBG) { cnt.wLeaves++; if (ballot(!skip) == 0) cnt.wLeafSkips++; }
 				if (!skip) {
-					// exec = lanes for which some triangle of the leaf may survive the back-face test.
-					// one PAIR of references per trip: wait(pair) -> issue(next pair) -> test both.  The pair after
-					// the leaf's last one may be fetched and ignored (the array is padded on upload).
-					TriPair t0 = sloadPair(p);
-					for (uint32_t left = (n + 1) / 2;;) {
-						p = after(p, t0.b[3]);
-						const TriPair t1 = sloadPair(p + 1);
-						triTest<CULL, STATS>(t0.a[0], t0.a[1], t0.a[2], t0.a[3], t0.a[4], t0.a[5], t0.a[6], t0.a[7], t0.a[8], t0.a[9],
-						                     pr, bt, bu, bv, btri, cnt);
-						triTest<CULL, STATS>(t0.a[10], t0.a[11], t0.a[12], t0.a[13], t0.a[14], t0.a[15], t0.b[0], t0.b[1], t0.b[2], t0.b[3],
-						                     pr, bt, bu, bv, btri, cnt);
-						if (left == 1) break;
-						left = uni(left - 1);
-						p += 1;
-						t0 = t1;
+					// exec = lanes for which some triangle of the leaf may be accepted
+					if (n <= kChunkTris) testPairs<CULL, STATS>(p, (n + 1) / 2, pr, bt, bu, bv, btri, cnt);
+					else {
+						for (uint32_t done = 0; done < n; done = uni(done + kChunkTris)) {
+							const uint32_t cn = n - done < kChunkTris ? n - done : kChunkTris;
+							const bool skipChunk = certainlyRejected<CULL>(sload16(p), o, d, dmax);
+							p += 1;
+							if (!skipChunk) testPairs<CULL, STATS>(p, (cn + 1) / 2, pr, bt, bu, bv, btri, cnt);
+							p += (cn + 1) / 2;
+						}
 					}
 				}
 			}
