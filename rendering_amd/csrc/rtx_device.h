@@ -40,7 +40,7 @@ struct LeafPair { LeafTri t[2]; };
 
 // Every leaf's pairs are preceded by one header of the same size (one s_load_dwordx16); leaves with more than
 // kChunkTris references additionally carry one header in front of every chunk of kChunkTris references
-// ([leaf header] { [chunk header] 8 pairs }...), because large leaves mix orientations and rarely certify as a whole.  It lets a wave skip the
+// ([leaf header] { [chunk header] kChunkTris/2 pairs }...), because large leaves mix orientations and rarely certify as a whole.  It lets a wave skip the
 // whole leaf for a ray when the reference is CERTAIN to reject every triangle of the leaf -- skipping is then
 // exact.  Two certificates, both with rigorous fp32 rounding-error bounds (derivation: DESIGN.md section 3.3):
 //   (1) back-face:  det = v0v1 . (dir x v0v2) = dir . m with m = v0v2 x v0v1.  [mlo, mhi] bounds m component-wise
@@ -142,6 +142,6 @@ struct Params {
 };
 
 constexpr int kFrameFields = 14;
-constexpr uint32_t kChunkTris = 16;   // leaves with more references carry one extra LeafHeader per 16 references
+constexpr uint32_t kChunkTris = 8; // leaves with more references carry one extra LeafHeader per kChunkTris references
 
 } // namespace rtxd

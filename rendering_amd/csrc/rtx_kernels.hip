@@ -468,8 +468,8 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 			const uint32_t n = (uint32_t)~link;
 			if (STATS) cnt.tri += (unsigned long long)__popcll(m) * n;
 			if (n != 0 && pass) {
-				// exec = the lanes that passed this leaf's box.  Leaf layout: [leaf header] pairs...  for n <= 16, and
-				// [leaf header] { [chunk header] 8 pairs }...  for larger leaves (rtxd::kChunkTris triangles per chunk).
+				// exec = the lanes that passed this leaf's box.  Leaf layout: [leaf header] pairs...  for n <= kChunkTris, and
+				// [leaf header] { [chunk header] kChunkTris/2 pairs }...  for larger leaves (rtxd::kChunkTris triangles per chunk).
 				const LeafPair* p = leaf + nd[7];
 				const bool skip = certainlyRejected<CULL>(sload16(p), o, d, dmax);
 				p += 1;
