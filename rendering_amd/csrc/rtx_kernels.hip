@@ -363,7 +363,7 @@ __device__ __forceinline__ void triTest(uint32_t w0, uint32_t w1, uint32_t w2, u
 // Leaf / chunk certificates (rtxd::LeafHeader): true when the reference is CERTAIN to reject every
 // triangle the header covers for this ray, so the lane may be masked out of them.
 template <bool CULL>
-__device__ __forceinline__ bool certainlyRejected(const u32x16& hd, const V3& o, const V3& d, float dmax)
+__device__ __forceinline__ bool certainlyRejected(const u32x16& hd, const V3& o, const V3& d, float ix, float iy, float iz, float dmax)
 {
 	const float ax = d.x * F(hd[0]), bx = d.x * F(hd[3]);
 	const float ay = d.y * F(hd[1]), by = d.y * F(hd[4]);
@@ -372,20 +372,31 @@ __device__ __forceinline__ bool certainlyRejected(const u32x16& hd, const V3& o,
 	bool skip = false;
 	// (1) certainly back-facing: U >= dir . (v0v2 x v0v1) = det for every triangle
 	if (CULL) skip = fmaxf(ax, bx) + fmaxf(ay, by) + fmaxf(az, bz) < -errd;
-	// (2) certainly front-facing and entirely behind the ray origin: computed t < 0 for every triangle
+	// certainly front-facing: det >= g > 0 for every triangle
 	const float lc = fminf(ax, bx) + fminf(ay, by) + fminf(az, bz);
 	const bool facing = lc >= 4 * errd;
 	if (ballot(facing) != 0) {
 		const float lox = F(hd[8]) - o.x, hix = F(hd[11]) - o.x;
 		const float loy = F(hd[9]) - o.y, hiy = F(hd[12]) - o.y;
 		const float loz = F(hd[10]) - o.z, hiz = F(hd[13]) - o.z;
-		const float boxdot = fmaxf(lox * d.x, hix * d.x) + fmaxf(loy * d.y, hiy * d.y) + fmaxf(loz * d.z, hiz * d.z);
 		const float dinf = fmaxf(fmaxf(fmaxf(fabsf(lox), fabsf(hix)), fmaxf(fabsf(loy), fabsf(hiy))), fmaxf(fabsf(loz), fabsf(hiz)));
 		const float g = lc - 2 * errd;
-		const float need = dmax * dmax * (dinf * F(hd[7]) + F(hd[14])) * 1.02f + 1e-30f;
+		const float budget = dmax * (dinf * F(hd[7]) + F(hd[14]));      // g * (error radius) / 2, see DESIGN.md 3.3
 		// (magnitude guards: the error budget assumes no overflow / NaN in the reference's intermediate products)
-		const bool behind = facing && dmax < 0x1p20f && dinf < 0x1p40f && -boxdot * g > need;
-		skip = skip || behind;
+		const bool sane = facing && dmax < 0x1p20f && dinf < 0x1p40f;
+		// (2) entirely behind the ray origin: computed t < 0 for every triangle
+		const float boxdot = fmaxf(lox * d.x, hix * d.x) + fmaxf(loy * d.y, hiy * d.y) + fmaxf(loz * d.z, hiz * d.z);
+		const bool behind = sane && -boxdot * g > dmax * budget * 1.02f + 1e-30f;
+		// (3) the ray's line misses the AABB inflated by the error radius rho <= 2 * budget / g (+ fp32 slack): no
+		//     triangle can pass the reference's u / v tests
+		const float rho = 2 * budget * __builtin_amdgcn_rcpf(g) * (1.0f + 0x1p-10f) + dinf * 0x1p-20f;
+		const float x0 = (lox - rho) * ix, x1 = (hix + rho) * ix;
+		const float y0 = (loy - rho) * iy, y1 = (hiy + rho) * iy;
+		const float z0 = (loz - rho) * iz, z1 = (hiz + rho) * iz;
+		const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+		const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+		const bool miss = sane && tnear > tfar;
+		skip = skip || behind || miss;
 	}
 	return skip;
 }
@@ -471,7 +482,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 				// exec = the lanes that passed this leaf's box.  Leaf layout: [leaf header] pairs...  for n <= kChunkTris, and
 				// [leaf header] { [chunk header] kChunkTris/2 pairs }...  for larger leaves (rtxd::kChunkTris triangles per chunk).
 				const LeafPair* p = leaf + nd[7];
-				const bool skip = certainlyRejected<CULL>(sload16(p), o, d, dmax);
+				const bool skip = certainlyRejected<CULL>(sload16(p), o, d, ix, iy, iz, dmax);
 				p += 1;
 				if (STATS && RTX_DBG) { cnt.wLeaves++; if (ballot(!skip) == 0) cnt.wLeafSkips++; }
 				if (!skip) {
@@ -480,7 +491,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 					else {
 						for (uint32_t done = 0; done < n; done = uni(done + kChunkTris)) {
 							const uint32_t cn = n - done < kChunkTris ? n - done : kChunkTris;
-							const bool skipChunk = certainlyRejected<CULL>(sload16(p), o, d, dmax);
+							const bool skipChunk = certainlyRejected<CULL>(sload16(p), o, d, ix, iy, iz, dmax);
 							p += 1;
 							if (!skipChunk) testPairs<CULL, STATS>(p, (cn + 1) / 2, pr, bt, bu, bv, btri, cnt);
 							p += (cn + 1) / 2;
