@@ -170,6 +170,11 @@ int rtx_last_kernel_ms(rtx_scene* scene, int which, float* ms);
 int rtx_kernel_time_reset(rtx_scene* scene);
 int rtx_kernel_time_stats(rtx_scene* scene, int which, uint32_t* launches, double* total_ms);
 
+/* Per-tile cost of the most recent rtx_render_pass1 (profiling aid; also what orders the SSAA work list):
+ * out[ty * ceil(width/8) + tx] = wall-clock ticks (100 MHz) one wave spent on the 8x8 pixel tile (tx, ty).
+ * n must be ceil(width/8) * ceil(height/8).  Synchronises the device. */
+int rtx_tile_cost_read(rtx_scene* scene, uint32_t* out, size_t n);
+
 /* Pixel sharding across the GPUs of a node: bands of band_height rows are dealt round-robin
  * to n_parts devices; this device renders / masks / re-renders only rows y with (y / band_height) % n_parts
  * == part.  With halo != 0 pass 1 additionally renders the one row above and below every owned band, so

@@ -36,7 +36,7 @@ RTX_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_set_view",
     "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_quantize_bgr8", "rtx_render_frame_host",
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
-    "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_set_row_ownership",
+    "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
 ]
 
 
@@ -72,6 +72,7 @@ def load():
     rtx.rtx_cast_rays.argtypes = [vp, u32, vp, vp, vp]
     rtx.rtx_kernel_time_reset.argtypes = [vp]
     rtx.rtx_kernel_time_stats.argtypes = [vp, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    rtx.rtx_tile_cost_read.argtypes = [vp, vp, C.c_size_t]
     rtx.rtx_set_row_ownership.argtypes = [vp, u32, u32, u32, i32]
     host.rah_scene_load.restype = vp
     host.rah_scene_load.argtypes = [C.c_char_p, C.c_char_p, i32, i32]
@@ -275,6 +276,13 @@ class Scene:
         n, ms = C.c_uint32(0), C.c_double(0)
         _check(self.rtx.rtx_kernel_time_stats(self.gpu(), which, C.byref(n), C.byref(ms)), "rtx_kernel_time_stats")
         return n.value, ms.value
+
+    def tile_cost(self):
+        """(ceil(H/8), ceil(W/8)) uint32 array: 100 MHz ticks pass 1 spent on each 8x8 tile (rtx_tile_cost_read)."""
+        self._dims()
+        out = np.zeros(((self.height + 7) // 8, (self.width + 7) // 8), np.uint32)
+        _check(self.rtx.rtx_tile_cost_read(self.gpu(), _np_ptr(out), out.size), "rtx_tile_cost_read")
+        return out
 
     def set_row_ownership(self, band_height, n_parts, part, halo=True):
         _check(self.rtx.rtx_set_row_ownership(self.gpu(), band_height, n_parts, part, int(halo)), "rtx_set_row_ownership")

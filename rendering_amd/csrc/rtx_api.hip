@@ -521,7 +521,18 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	HIPCHK(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
 	out->rays = c[0]; out->box_tests = c[1]; out->tri_tests = c[2];
 	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] slowest work item %.3f ms, sum of items %.3f ms (100 MHz wall clock)\n", c[3] * 1e-5, c[4] * 1e-5);
-	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] wave-level: node visits %llu, triangle iterations %llu (lane utilisation %.3f), reached u-stage %llu, division %llu, v-stage %llu; leaf visits %llu, skipped by the back-face header %llu\n", c[5], c[6], c[6] ? (double)c[2] / (64.0 * c[6]) : 0.0, c[7], c[8], c[9], c[10], c[11]);
+	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] wave-level: node visits %llu, triangle iterations %llu (%.1f lanes in exec), reached u-stage %llu, division %llu, v-stage %llu; leaf visits %llu, skipped whole by certificate %llu; chunk visits %llu, skipped %llu\n", c[5], c[6], c[6] ? (double)c[14] / c[6] : 0.0, c[7], c[8], c[9], c[10], c[11], c[12], c[13]);
+#if RTX_DBG
+	if (getenv("RTX_DEBUG_ITEMS")) {
+		unsigned long long h[64];
+		HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(gDbgHist), sizeof(h)));
+		{ unsigned long long z[64] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gDbgHist), z, sizeof(z))); }
+		if (h[0]) fprintf(stderr, "[rtx] certificates (one sampled lane per evaluation): %llu, back-facing %.1f%%, facing %.1f%% (behind %.1f%%, miss %.1f%%, neither %.1f%%), uncertain %.1f%%; skipped %.1f%%\n",
+		                  h[0], 100.0 * h[1] / h[0], 100.0 * h[2] / h[0], 100.0 * h[4] / h[0], 100.0 * h[5] / h[0], 100.0 * h[6] / h[0], 100.0 * (h[0] - h[1] - h[2]) / h[0], 100.0 * h[7] / h[0]);
+		for (int b = 0; b < 12; b++)
+			if (h[16 + b]) fprintf(stderr, "[rtx]   leaves of %4d..%4d refs: unskipped wave visits %10llu, chunk headers %10llu, triangle iterations %10llu\n", 1 << b, (2 << b) - 1, h[16 + b], h[32 + b], h[48 + b]);
+	}
+#endif
 	return RTX_OK;
 }
 
@@ -554,6 +565,18 @@ int rtx_kernel_time_stats(rtx_scene* s, int which, uint32_t* launches, double* t
 		HIPCHK(hipEventElapsedTime(&ms, s->evPool[which][i], s->evPool[which][i + 1]));
 		*total_ms += ms; (*launches)++;
 	}
+	return RTX_OK;
+}
+
+int rtx_tile_cost_read(rtx_scene* s, uint32_t* out, size_t n)
+{
+	if (!s || !out) return fail(RTX_ERR_ARG, "scene/out is NULL");
+	HIPCHK(hipSetDevice(s->device));
+	const size_t tiles = (size_t)((s->params.view.width + 7) / 8) * ((s->params.view.height + 7) / 8);
+	if (n != tiles) return fail(RTX_ERR_ARG, "n must be ceil(width/8) * ceil(height/8)");
+	if (!s->tileCost || s->tileCap < tiles) return fail(RTX_ERR_ARG, "no pass 1 has run at this size");
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(out, s->tileCost, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
 	return RTX_OK;
 }
 

@@ -285,7 +285,10 @@ __device__ __forceinline__ float attenuation(float intensity, float l2)
 // Render::trace for a whole wave (scene.cpp:724-756)
 // ------------------------------------------------------------------------------------------------
 struct Hit { int obj; float t; uint32_t tri; float u, v; };
-struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips; };
+#if RTX_DBG
+__device__ unsigned long long gDbgHist[64];   // [0,8) certificate outcomes (one sampled lane per evaluation), [16,64) by log2(leaf size)
+#endif
+struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips, wChunks, wChunkSkips, triLanes; };
 
 // Ordering of scalar loads.  SMEM returns out of order, so lgkmcnt can only be waited down to zero: a load issued
 // before the first use of the previous one is covered by the same wait and nothing overlaps.  after(x, v) is an
@@ -327,7 +330,7 @@ __device__ __forceinline__ void triTest(uint32_t w0, uint32_t w1, uint32_t w2, u
 	// Both compares are false for NaN, exactly like the reference's two ifs (objects.cpp:75-79).
 	const float dd = CULL ? det : fabsf(det);
 	const uint64_t m1 = ballot(!(dd < RTX_EPS8));
-	if (STATS && RTX_DBG) cnt.wTri++;
+	if (STATS && RTX_DBG) { cnt.wTri++; cnt.triLanes += __popcll(ballot(true)); }
 	if (m1 == 0) return;
 	if (STATS && RTX_DBG) cnt.wS2++;
 	const f2 txy = r.oxy - v0xy;                                              // tvec = orig - v0 (objects.cpp:82)
@@ -396,8 +399,21 @@ __device__ __forceinline__ bool certainlyRejected(const u32x16& hd, const V3& o,
 		const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
 		const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
 		const bool miss = sane && tnear > tfar;
+#if RTX_DBG
+		if ((int)__lane_id() == __builtin_ctzll(ballot(true))) {      // the first lane in exec reports for itself
+			atomicAdd(gDbgHist + 2, (unsigned long long)(facing && !skip)); atomicAdd(gDbgHist + 4, (unsigned long long)(behind && !skip));
+			atomicAdd(gDbgHist + 5, (unsigned long long)(miss && !behind && !skip)); atomicAdd(gDbgHist + 6, (unsigned long long)(sane && !behind && !miss && !skip));
+		}
+#endif
 		skip = skip || behind || miss;
 	}
+#if RTX_DBG
+	if ((int)__lane_id() == __builtin_ctzll(ballot(true))) {
+		atomicAdd(gDbgHist + 0, 1ull);
+		atomicAdd(gDbgHist + 1, (unsigned long long)(CULL && fmaxf(ax, bx) + fmaxf(ay, by) + fmaxf(az, bz) < -errd));
+		atomicAdd(gDbgHist + 7, (unsigned long long)skip);
+	}
+#endif
 	return skip;
 }
 
@@ -484,7 +500,12 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 				const LeafPair* p = leaf + nd[7];
 				const bool skip = certainlyRejected<CULL>(sload16(p), o, d, ix, iy, iz, dmax);
 				p += 1;
-				if (STATS && RTX_DBG) { cnt.wLeaves++; if (ballot(!skip) == 0) cnt.wLeafSkips++; }
+#if RTX_DBG
+				if (STATS) {
+					cnt.wLeaves++; if (ballot(!skip) == 0) cnt.wLeafSkips++;
+					if (ballot(!skip) != 0 && (int)__lane_id() == __builtin_ctzll(ballot(true))) atomicAdd(gDbgHist + 16 + (31 - __builtin_clz(n)), 1ull);
+				}
+#endif
 				if (!skip) {
 					// exec = lanes for which some triangle of the leaf may be accepted
 					if (n <= kChunkTris) testPairs<CULL, STATS>(p, (n + 1) / 2, pr, bt, bu, bv, btri, cnt);
@@ -493,6 +514,16 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 							const uint32_t cn = n - done < kChunkTris ? n - done : kChunkTris;
 							const bool skipChunk = certainlyRejected<CULL>(sload16(p), o, d, ix, iy, iz, dmax);
 							p += 1;
+#if RTX_DBG
+							if (STATS) {
+								cnt.wChunks++; if (ballot(!skipChunk) == 0) cnt.wChunkSkips++;
+								if ((int)__lane_id() == __builtin_ctzll(ballot(true))) {
+									const int bk = 31 - __builtin_clz(n);
+									atomicAdd(gDbgHist + 32 + bk, 1ull);
+									if (ballot(!skipChunk) != 0) atomicAdd(gDbgHist + 48 + bk, (unsigned long long)cn);
+								}
+							}
+#endif
 							if (!skipChunk) testPairs<CULL, STATS>(p, (cn + 1) / 2, pr, bt, bu, bv, btri, cnt);
 							p += (cn + 1) / 2;
 						}
@@ -857,6 +888,7 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 		atomicAdd(P.counters + 5, c.wNodes); atomicAdd(P.counters + 6, c.wTri); atomicAdd(P.counters + 7, c.wS2);
 		atomicAdd(P.counters + 8, c.wS3); atomicAdd(P.counters + 9, c.wS4);
 		atomicAdd(P.counters + 10, c.wLeaves); atomicAdd(P.counters + 11, c.wLeafSkips);
+		atomicAdd(P.counters + 12, c.wChunks); atomicAdd(P.counters + 13, c.wChunkSkips); atomicAdd(P.counters + 14, c.triLanes);
 	}
 }
 

@@ -104,6 +104,15 @@ def test_counters_match_reference_semantics(ra, oracle):
     assert np.array_equal(ref, got), (ref, got)
 
 
+def test_tile_cost_map(ra):
+    """rtx_tile_cost_read: one entry per 8x8 tile of the frame; tiles on the mesh cost more than background tiles."""
+    g = ra.Scene("scenes/cfg2_smooth_4k.scene", 160, 120)
+    g.render_host(ssaa=False)
+    c = g.tile_cost()
+    assert c.shape == (15, 20) and c.dtype == np.uint32
+    assert c.min() > 0 and c[7, 10] > c[0, 0]
+
+
 def test_surface_rays_250k_bit_exact(ra, oracle):
     """Stress of the leaf certificates on the headline mesh: 60k rays that START ON the surface
     (like shadow / reflection rays: most of the mesh lies behind them) in pseudo-random directions, plus rays from
