@@ -170,6 +170,20 @@ int rtx_last_kernel_ms(rtx_scene* scene, int which, float* ms);
 int rtx_kernel_time_reset(rtx_scene* scene);
 int rtx_kernel_time_stats(rtx_scene* scene, int which, uint32_t* launches, double* total_ms);
 
+/* Acceleration-structure build on the device.  Replaces Mesh::loadModel's
+ * `ac = make_unique<AccelerationStructure>(...); ac->setup(...)` (objects.cpp:385-392) and the recursive builder
+ * behind it (objects.cpp:470-526, 633-763): same topology, bounds and leaf-reference order, bit for bit.
+ *   tri_pos   n_tris x 9 host floats (a, b, c of every Triangle, in `allTris` order)
+ *   root_lo/hi  the root box Mesh::loadModel computes (objects.cpp:328-330)
+ *   ac_penalty  options::acPenalty (leaf iff n <= depth * acPenalty, root depth 1)
+ * The result stays in device memory; rtx_bvh_read copies it out in the rtx_mesh layout (any pointer may be NULL). */
+typedef struct rtx_bvh rtx_bvh;
+int rtx_bvh_build(const float* tri_pos, uint32_t n_tris, const float* root_lo, const float* root_hi, int32_t ac_penalty, int device,
+                  rtx_bvh** out);
+int rtx_bvh_info(const rtx_bvh* bvh, uint32_t* n_nodes, uint32_t* n_refs, uint32_t* max_depth, float* build_ms);
+int rtx_bvh_read(const rtx_bvh* bvh, float* node_bounds, int32_t* node_skip, int32_t* leaf_begin, int32_t* leaf_count, uint32_t* refs);
+void rtx_bvh_destroy(rtx_bvh* bvh);
+
 /* Per-tile cost of the most recent rtx_render_pass1 (profiling aid; also what orders the SSAA work list):
  * out[ty * ceil(width/8) + tx] = wall-clock ticks (100 MHz) one wave spent on the 8x8 pixel tile (tx, ty).
  * n must be ceil(width/8) * ceil(height/8).  Synchronises the device. */

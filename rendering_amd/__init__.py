@@ -37,6 +37,7 @@ RTX_SYMBOLS = [
     "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_quantize_bgr8", "rtx_render_frame_host",
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
     "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
+    "rtx_bvh_build", "rtx_bvh_info", "rtx_bvh_read", "rtx_bvh_destroy",
 ]
 
 
@@ -74,6 +75,14 @@ def load():
     rtx.rtx_kernel_time_stats.argtypes = [vp, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     rtx.rtx_tile_cost_read.argtypes = [vp, vp, C.c_size_t]
     rtx.rtx_set_row_ownership.argtypes = [vp, u32, u32, u32, i32]
+    rtx.rtx_bvh_build.argtypes = [vp, u32, vp, vp, C.c_int32, i32, C.POINTER(vp)]
+    rtx.rtx_bvh_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_float)]
+    rtx.rtx_bvh_read.argtypes = [vp, vp, vp, vp, vp, vp]
+    rtx.rtx_bvh_destroy.argtypes = [vp]
+    rtx.rtx_bvh_destroy.restype = None
+    host.rah_set_ac_build.argtypes = [i32, i32]
+    host.rah_set_ac_build.restype = None
+    host.rah_bvh_build_info.argtypes = [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_float)]
     host.rah_scene_load.restype = vp
     host.rah_scene_load.argtypes = [C.c_char_p, C.c_char_p, i32, i32]
     host.rah_scene_free.argtypes = [vp]
@@ -120,6 +129,35 @@ def device_count():
 
 def _np_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def set_ac_build(mode, device=0):
+    """Where the host loader builds acceleration structures from now on: "host", "device" (rtx_bvh_build) or
+    "auto" (the device when one is visible).  Both give the same structure bit for bit."""
+    _, host = load()
+    host.rah_set_ac_build({"auto": -1, "host": 0, "device": 1}[mode], device)
+
+
+def bvh_build(tri_pos, root_lo, root_hi, ac_penalty=1, device=0):
+    """rtx_bvh_build + rtx_bvh_read: the reference's acceleration structure (objects.cpp:470-526, 633-763) built on
+    the GPU.  Returns the dump layout of Scene.bvh() plus `build_ms` (HIP events around the build)."""
+    rtx, _ = load()
+    pos = np.ascontiguousarray(tri_pos, np.float32).reshape(-1, 9)
+    lo = np.ascontiguousarray(root_lo, np.float32); hi = np.ascontiguousarray(root_hi, np.float32)
+    b = C.c_void_p()
+    _check(rtx.rtx_bvh_build(_np_ptr(pos), pos.shape[0], _np_ptr(lo), _np_ptr(hi), ac_penalty, device, C.byref(b)), "rtx_bvh_build")
+    try:
+        nn, nr, md, ms = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_float()
+        _check(rtx.rtx_bvh_info(b, C.byref(nn), C.byref(nr), C.byref(md), C.byref(ms)), "rtx_bvh_info")
+        d = dict(bounds=np.zeros((nn.value, 6), np.float32), skip=np.zeros(nn.value, np.int32),
+                 leaf_begin=np.zeros(nn.value, np.int32), leaf_count=np.zeros(nn.value, np.int32),
+                 refs=np.zeros(nr.value, np.uint32))
+        _check(rtx.rtx_bvh_read(b, _np_ptr(d["bounds"]), _np_ptr(d["skip"]), _np_ptr(d["leaf_begin"]), _np_ptr(d["leaf_count"]),
+                                _np_ptr(d["refs"])), "rtx_bvh_read")
+        d.update(n_nodes=nn.value, n_refs=nr.value, max_depth=md.value, build_ms=ms.value)
+        return d
+    finally:
+        rtx.rtx_bvh_destroy(b)
 
 
 def math_probe(op, x, y=None, device=0):
@@ -197,6 +235,9 @@ class Scene:
         tris = np.zeros((nt, 30), np.float32)
         self.host.rah_tris(self.h, obj_idx, _np_ptr(tris))
         d.update(tris=tris, n_nodes=nn, n_leaves=nl, n_refs=nr, max_depth=md, n_tris=nt)
+        on, ms = C.c_int(0), C.c_float(0)
+        self.host.rah_bvh_build_info(self.h, obj_idx, C.byref(on), C.byref(ms))
+        d.update(built_on_device=bool(on.value), build_ms=ms.value)
         return d
 
     # ---- GPU ------------------------------------------------------------------------------------

@@ -630,3 +630,6 @@ int rtx_math_probe(int device, int op, uint32_t n, const float* x, const float* 
 }
 
 } // extern "C"
+
+// device-side acceleration-structure build (uses fail / HIPCHK above)
+#include "rtx_bvh.hip"

@@ -59,7 +59,9 @@ public:
 		int32_t leafCount = -1;
 	};
 	void setBounds(const Vec3f& a, const Vec3f& b) { rootBounds[0] = a; rootBounds[1] = b; }
-	void setup(const std::vector<Triangle>& tris, const Options& options);
+	bool setup(const std::vector<Triangle>& tris, const Options& options);   // false: the device build failed (message printed)
+	float buildMs = 0;   // device build: time of the build on the GPU (HIP events)
+	bool builtOnDevice = false;
 	Vec3f rootBounds[2];
 	std::vector<Node> nodes;
 	std::vector<uint32_t> refs;

@@ -30,6 +30,11 @@ inline bool useSkybox = false;
 inline bool useTextures = true;
 inline bool showNormals = false; // debug mode, out of scope
 inline bool enableSSAA = true;
+// Where Mesh::loadOBJ builds the acceleration structure: -1 = decide on first use (the device if one is visible,
+// environment RENDERING_AMD_AC_BUILD=host|device overrides), 0 = host builder, 1 = rtx_bvh_build on the device.
+// Both produce the same structure bit for bit (tests/test_gpu_bvh.py).
+inline int acBuildOnDevice = -1;
+inline int acBuildDevice = 0;     // HIP device index for the build
 // restores the defaults above (the reference never resets them between scenes)
 void reset();
 }

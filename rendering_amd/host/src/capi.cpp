@@ -50,6 +50,20 @@ void* rah_flatten(void* h) { return flattenScene(*(Scene*)h); }
 const rtx_scene_desc* rah_flat_desc(void* f) { return flatDesc((FlatScene*)f); }
 void rah_flat_free(void* f) { freeFlatScene((FlatScene*)f); }
 
+// Where the next rah_scene_load builds acceleration structures: -1 auto, 0 host builder, 1 device (rtx_bvh_build).
+void rah_set_ac_build(int mode, int device) { options::acBuildOnDevice = mode; options::acBuildDevice = device; }
+
+// {built on the device (0/1), device build time in ms}
+int rah_bvh_build_info(void* h, int obj, int* onDevice, float* ms)
+{
+	Scene* s = (Scene*)h;
+	if (obj < 0 || obj >= (int)s->objects.size() || s->objects[obj]->objectType != ObjectType::Mesh) return -1;
+	const Mesh& m = static_cast<const Mesh&>(*s->objects[obj]);
+	if (!m.ac) return -1;
+	*onDevice = m.ac->builtOnDevice ? 1 : 0; *ms = m.ac->buildMs;
+	return 0;
+}
+
 // BVH in the dump layout shared with the oracle / reference harness.
 int rah_bvh_counts(void* h, int obj, long long* c)
 {

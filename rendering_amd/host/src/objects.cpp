@@ -5,6 +5,7 @@
 #include "objects.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -13,6 +14,7 @@
 #include "stats.h"
 #include "timer.h"
 #include "util.h"
+#include "../../../include/rtx.h"
 
 template <> Matrix44f Matrix44f::fromEulerDegrees(const Vec3f& rot)
 {
@@ -117,13 +119,65 @@ struct Builder {
 
 } // namespace
 
-void AccelerationStructure::setup(const std::vector<Triangle>& tris, const Options& options)
+static bool wantDeviceBuild()
 {
-	nodes.clear(); refs.clear(); maxDepth = 0;
-	Builder b(tris, options.acPenalty, *this);
-	std::vector<uint32_t> ids(tris.size());
-	for (size_t i = 0; i < ids.size(); ++i) ids[i] = (uint32_t)i;
-	b.build(rootBounds[0], rootBounds[1], ids, 1);                               // root depth 1 (objects.cpp:389)
+	if (options::acBuildOnDevice < 0) {
+		const char* e = std::getenv("RENDERING_AMD_AC_BUILD");
+		int n = 0;
+		if (e && !strcmp(e, "host")) options::acBuildOnDevice = 0;
+		else if (e && !strcmp(e, "device")) options::acBuildOnDevice = 1;
+		else options::acBuildOnDevice = (rtx_device_count(&n) == RTX_OK && n > 0) ? 1 : 0;
+	}
+	return options::acBuildOnDevice == 1;
+}
+
+bool AccelerationStructure::setup(const std::vector<Triangle>& tris, const Options& options)
+{
+	nodes.clear(); refs.clear(); maxDepth = 0; buildMs = 0; builtOnDevice = false;
+	const bool onDevice = wantDeviceBuild();
+	Timer timer(onDevice ? "AC build (device)" : "AC build (host)");
+	if (!onDevice) {
+		Builder b(tris, options.acPenalty, *this);
+		std::vector<uint32_t> ids(tris.size());
+		for (size_t i = 0; i < ids.size(); ++i) ids[i] = (uint32_t)i;
+		b.build(rootBounds[0], rootBounds[1], ids, 1);                               // root depth 1 (objects.cpp:389)
+		return true;
+	}
+	// rtx_bvh_build: the same builder, level-synchronous on the GPU (include/rtx.h)
+	std::vector<float> pos(tris.size() * 9);
+	for (size_t i = 0; i < tris.size(); ++i) {
+		const Vec3f* v[3] = { &tris[i].a, &tris[i].b, &tris[i].c };
+		for (int k = 0; k < 3; ++k) { pos[i * 9 + k * 3] = v[k]->x; pos[i * 9 + k * 3 + 1] = v[k]->y; pos[i * 9 + k * 3 + 2] = v[k]->z; }
+	}
+	const float lo[3] = { rootBounds[0].x, rootBounds[0].y, rootBounds[0].z }, hi[3] = { rootBounds[1].x, rootBounds[1].y, rootBounds[1].z };
+	rtx_bvh* b = nullptr;
+	uint32_t nn = 0, nr = 0, md = 0;
+	if (rtx_bvh_build(pos.data(), (uint32_t)tris.size(), lo, hi, options.acPenalty, options::acBuildDevice, &b) != RTX_OK ||
+	    rtx_bvh_info(b, &nn, &nr, &md, &buildMs) != RTX_OK) {
+		std::cout << "Error: acceleration-structure build on the device failed: " << rtx_last_error() << '\n';
+		rtx_bvh_destroy(b);
+		return false;
+	}
+	std::vector<float> bounds((size_t)nn * 6);
+	std::vector<int32_t> skip(nn), lb(nn), lc(nn);
+	refs.resize(nr);
+	if (rtx_bvh_read(b, bounds.data(), skip.data(), lb.data(), lc.data(), refs.data()) != RTX_OK) {
+		std::cout << "Error: acceleration-structure read-back failed: " << rtx_last_error() << '\n';
+		rtx_bvh_destroy(b);
+		return false;
+	}
+	rtx_bvh_destroy(b);
+	nodes.resize(nn);
+	for (uint32_t i = 0; i < nn; ++i) {
+		nodes[i].bounds[0] = Vec3f(bounds[(size_t)i * 6], bounds[(size_t)i * 6 + 1], bounds[(size_t)i * 6 + 2]);
+		nodes[i].bounds[1] = Vec3f(bounds[(size_t)i * 6 + 3], bounds[(size_t)i * 6 + 4], bounds[(size_t)i * 6 + 5]);
+		nodes[i].skip = skip[i]; nodes[i].leafBegin = lb[i]; nodes[i].leafCount = lc[i];
+	}
+	maxDepth = (int)md;
+	stats::acCount += nn;
+	stats::triCopiesCount += nr;
+	builtOnDevice = true;
+	return true;
 }
 
 size_t AccelerationStructure::leafCount() const
@@ -267,7 +321,7 @@ bool Mesh::loadOBJ(const std::string& filename, const Options& options)
 			}
 		}
 	}
-	ac->setup(allTris, options);
+	if (!ac->setup(allTris, options)) return false;
 	stats::meshCount += allTris.size();
 	return true;
 }

@@ -1,0 +1,92 @@
+"""GPU: rtx_bvh_build must reproduce the host builder -- which the CPU suite pins to the real
+reference's BVH digests (tests/test_host_cpu.py, tests/golden) -- bit for bit: topology, bounds, reference order."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("bounds", "skip", "leaf_begin", "leaf_count", "refs")
+
+
+def _mesh_objects(g):
+    return [i for i in range(g.n_objects) if g.bvh(i) is not None]
+
+
+def _same(a, b):
+    for k in KEYS:
+        assert a[k].shape == b[k].shape, (k, a[k].shape, b[k].shape)
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert a["max_depth"] == b["max_depth"] and a["n_nodes"] == b["n_nodes"] and a["n_refs"] == b["n_refs"]
+
+
+@pytest.mark.parametrize("name", ["cfg2_smooth_4k", "cfg2_smooth_25k", "cfg4_textured_256", "mixed_materials", "legacy_smooth_4k",
+                                  "cfg2_smooth_250k"])
+def test_device_build_equals_host_build(ra, name):
+    """Same scene loaded twice: acceleration structures from the host builder and from the device builder."""
+    path = "scenes/%s.scene" % name
+    try:
+        ra.set_ac_build("host")
+        gh = ra.Scene(path, 64, 64)
+        ra.set_ac_build("device")
+        gd = ra.Scene(path, 64, 64)
+    finally:
+        ra.set_ac_build("auto")
+    objs = _mesh_objects(gh)
+    assert objs and objs == _mesh_objects(gd)
+    for oi in objs:
+        h, d = gh.bvh(oi), gd.bvh(oi)
+        assert not h["built_on_device"] and d["built_on_device"] and d["build_ms"] > 0
+        _same(h, d)
+
+
+def test_default_loader_builds_on_the_device(ra):
+    """With a GPU visible the loader's default is the device builder (no silent host path)."""
+    ra.set_ac_build("auto")
+    g = ra.Scene("scenes/cfg2_smooth_4k.scene", 64, 64)
+    assert all(g.bvh(oi)["built_on_device"] for oi in _mesh_objects(g))
+
+
+@pytest.mark.parametrize("penalty", [1, 2, 3, 7, 1000000])
+def test_penalty_sweep_against_host_builder(ra, tmp_path, penalty):
+    """Leaf rule n <= depth * acPenalty (objects.cpp:477) across penalties, via temporary scene files."""
+    src = open("scenes/cfg2_smooth_4k.scene").read().replace("fov=60", "fov=60\nac_penalty=%d" % penalty)
+    p = tmp_path / "p.scene"
+    p.write_text(src)
+    try:
+        ra.set_ac_build("host")
+        gh = ra.Scene(str(p), 64, 64)
+    finally:
+        ra.set_ac_build("auto")
+    for oi in _mesh_objects(gh):
+        h = gh.bvh(oi)
+        d = ra.bvh_build(h["tris"][:, :9], h["bounds"][0, :3], h["bounds"][0, 3:], penalty)
+        _same(h, d)
+
+
+def test_edge_cases(ra):
+    lo, hi = np.array([-1, -1, -1], np.float32), np.array([1, 1, 1], np.float32)
+    # no triangles: a single empty leaf (objects.cpp:477 with n = 0)
+    d = ra.bvh_build(np.zeros((0, 9), np.float32), lo, hi, 1)
+    assert d["n_nodes"] == 1 and d["n_refs"] == 0 and d["max_depth"] == 1
+    assert d["leaf_begin"][0] == 0 and d["leaf_count"][0] == 0 and d["skip"][0] == 1
+    assert np.array_equal(d["bounds"][0], np.concatenate([lo, hi]))
+    # one triangle: leaf at the root (1 <= 1 * 1)
+    d = ra.bvh_build(np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32), lo, hi, 1)
+    assert d["n_nodes"] == 1 and list(d["refs"]) == [0]
+    # identical triangles cannot be separated: the 1.5x duplication rule stops the recursion (objects.cpp:498)
+    tri = np.tile(np.array([[0, 0, 0, 0.5, 0, 0, 0, 0.5, 0]], np.float32), (64, 1))
+    d = ra.bvh_build(tri, lo, hi, 1)
+    leaves = d["leaf_count"] >= 0
+    assert d["n_refs"] >= 64 and set(d["refs"]) == set(range(64))
+    assert d["skip"][0] == d["n_nodes"] and (d["leaf_count"][leaves].sum() == d["n_refs"])
+    # determinism
+    d2 = ra.bvh_build(tri, lo, hi, 1)
+    _same(d, d2)
+
+
+def test_error_paths(ra):
+    lo, hi = np.zeros(3, np.float32), np.ones(3, np.float32)
+    with pytest.raises(ra.RtxError):
+        ra.bvh_build(np.zeros((1, 9), np.float32), lo, np.array([np.inf, 1, 1], np.float32), 1)
+    with pytest.raises(ra.RtxError):
+        ra.bvh_build(np.zeros((1, 9), np.float32), lo, hi, 1, device=99)
