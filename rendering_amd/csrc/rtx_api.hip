@@ -52,7 +52,9 @@ template <typename T> int upload(std::vector<void*>& owned, const T* src, size_t
 
 namespace {
 
-// (v0, e1, e2, tri) record of leaf reference r (objects.cpp:70-71: v0v1 = v1 - v0, v0v2 = v2 - v0)
+// (v0, e1, e2, tri) of leaf reference r (objects.cpp:70-71: v0v1 = v1 - v0, v0v2 = v2 - v0)
+struct LeafTri { float e1x, e1y, e1z, e2x, e2y, e2z, v0x, v0y, v0z; uint32_t tri; };
+
 LeafTri makeLeafTri(const rtx_mesh& m, uint32_t ref)
 {
 	const uint32_t t = m.refs[ref];
@@ -69,9 +71,14 @@ void appendPairs(std::vector<LeafPair>& leaf, const rtx_mesh& m, uint32_t begin,
 {
 	for (uint32_t k = 0; k < count; k += 2) {
 		LeafPair lp;
-		memset(&lp, 0, sizeof(lp));          // odd count: the second record stays degenerate (det == 0)
-		lp.t[0] = makeLeafTri(m, begin + k);
-		if (k + 1 < count) lp.t[1] = makeLeafTri(m, begin + k + 1);
+		memset(&lp, 0, sizeof(lp));          // odd count: the second triangle stays degenerate (det == 0)
+		for (uint32_t h = 0; h < 2 && k + h < count; h++) {
+			const LeafTri lt = makeLeafTri(m, begin + k + h);
+			lp.e2x[h] = lt.e2x; lp.e2y[h] = lt.e2y; lp.e2z[h] = lt.e2z;
+			lp.e1x[h] = lt.e1x; lp.e1y[h] = lt.e1y; lp.e1z[h] = lt.e1z;
+			lp.v0x[h] = lt.v0x; lp.v0y[h] = lt.v0y; lp.v0z[h] = lt.v0z;
+			lp.tri[h] = lt.tri;
+		}
 		leaf.push_back(lp);
 	}
 }

@@ -20,23 +20,22 @@ struct Node {
 static_assert(sizeof(Node) == 32, "node must be one s_load_dwordx8");
 
 // Leaf references, duplicated per leaf in the reference's DFS-left-first order (objects.cpp:622-629), stored in
-// PAIRS: 80 bytes = two 10-dword records, fetched with one s_load_dwordx16 + one s_load_dwordx4.  A leaf with an
-// odd number of references is padded with a degenerate record (all zero: det = 0 is rejected by the reference's
-// own epsilon test, objects.cpp:76-79), so a leaf always starts on a pair boundary.
-// The dword order puts the operands of the packed-f32 VALU ops (v_pk_mul_f32 / v_pk_add_f32: two IEEE fp32
-// operations per instruction at the issue cost of one -- measured, tools/ubench/pk_rate.hip) in even-aligned
-// SGPR pairs.
+// PAIRS: 80 bytes = two triangles INTERLEAVED field by field, fetched with one s_load_dwordx16 + one s_load_dwordx4.
+// Every field is an even-aligned SGPR pair (A, B), i.e. directly an operand of the packed-f32 VALU ops
+// (v_pk_mul_f32 / v_pk_add_f32: two IEEE fp32 operations per instruction at the issue cost of one -- measured,
+// tools/ubench/pk_rate.hip), so the Moeller-Trumbore arithmetic of both triangles is issued once.
+// A leaf with an odd number of references is padded with a degenerate triangle (all zero: det = 0 is rejected by
+// the reference's own epsilon test, objects.cpp:76-79), so a leaf always starts on a pair boundary.
 // e1 = b - a and e2 = c - a are the fp32 differences the reference recomputes per test (objects.cpp:70-71);
 // they are ray-independent, so computing them once on upload is bit-identical.
-struct LeafTri {
-	float e2x, e2y;
-	float e1x, e1y;
-	float e2z, e1z;
-	float v0x, v0y;
-	float v0z;
-	uint32_t tri;        // index into the per-triangle shading arrays
+struct LeafPair {
+	float e2x[2], e2y[2], e2z[2];
+	float e1x[2], e1y[2], e1z[2];
+	float v0x[2], v0y[2];
+	float v0z[2];
+	uint32_t tri[2];     // index into the per-triangle shading arrays
 };
-struct LeafPair { LeafTri t[2]; };
+static_assert(sizeof(LeafPair) == 80, "pair record = s_load_dwordx16 + s_load_dwordx4");
 
 // Every leaf's pairs are preceded by one header of the same size (one s_load_dwordx16); leaves with more than
 // kChunkTris references additionally carry one header in front of every chunk of kChunkTris references

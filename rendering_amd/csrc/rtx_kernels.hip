@@ -301,66 +301,72 @@ template <typename T> __device__ __forceinline__ T after(T x, uint32_t v)
 	return x;
 }
 
-// Triangle::rayTriangleIntersect (objects.cpp:59-95), triangle record in SGPRs.  Runs with exec = the lanes that
-// passed the leaf's box, so every ballot below is already restricted to them; the wave leaves a stage as soon as
-// no lane survives it (uniform branch on the lane mask).  Ballots are taken of the raw compares and combined with
-// scalar mask arithmetic (a ballot of a compound bool costs two extra VALU instructions).
-// The ray in the operand arrangement of the packed ops.
-struct PackedRay { f2 dyx, dxy, dzz, oxy; float dx, dy, dz, oz; };
+// Triangle::rayTriangleIntersect (objects.cpp:59-95) for the TWO triangles of a leaf-reference pair at once: the pair
+// record interleaves the two triangles (rtxd::LeafPair), so every fp32 operation of the reference is issued once as a
+// packed instruction (v_pk_mul_f32 / v_pk_add_f32: two independent IEEE operations, no contraction) with triangle A
+// in the low and triangle B in the high half.  Runs with exec = the lanes that passed the leaf's box, so every
+// ballot is already restricted to them; the wave leaves a stage as soon as no lane survives it for either triangle.
+// Ballots are taken of the raw compares and combined with scalar mask arithmetic.
+struct PackedRay { f2 dxx, dyy, dzz, oxx, oyy, ozz; };
 
-template <bool CULL, bool STATS>
-__device__ __forceinline__ void triTest(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7,
-                                        uint32_t w8, uint32_t w9, const PackedRay& r,
+// The tail of the test for one triangle (objects.cpp:81-94) for the lanes in m (a wave-uniform mask).
+template <bool STATS>
+__device__ __forceinline__ void triTail(uint64_t m, float det, float nu, float tx, float ty, float tz, float e1x, float e1y, float e1z,
+                                        float e2x, float e2y, float e2z, uint32_t tri, float dx, float dy, float dz,
                                         float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
 {
-	// record dwords: e2x e2y | e1x e1y | e2z e1z | v0x v0y | v0z tri
-	const f2 e2xy = { F(w0), F(w1) }, e2yx = { F(w1), F(w0) }, e1xy = { F(w2), F(w3) }, e2zz = { F(w4), F(w4) }, v0xy = { F(w6), F(w7) };
-	const float e2x = F(w0), e2y = F(w1), e2z = F(w4), e1x = F(w2), e1y = F(w3), e1z = F(w5), v0z = F(w8);
-	// pvec = dir x v0v2 (objects.cpp:72) with packed fp32 ops; every component is the same IEEE mul / mul / sub as
-	// the scalar form.  a = (dy*e2z, dx*e2z), b = (dz*e2y, dz*e2x):  a - b = (px, -py).  Only px, -py and pz are
-	// ever needed: e1x*px + e1y*py = e1x*px - e1y*(-py) (negating a product is exact).
-	const f2 a = r.dyx * e2zz, b = r.dzz * e2yx;
-	const f2 pxn = a - b;                                                     // (px, -py)
-	const f2 c = r.dxy * e2yx;                                                // (dx*e2y, dy*e2x)
-	const float pz = c.x - c.y;
-	const f2 dp = e1xy * pxn;                                                 // (e1x*px, -(e1y*py))
-	const float det = dp.x - dp.y + e1z * pz;                                 // objects.cpp:73
-	(void)e2xy;
+	if (STATS && RTX_DBG) cnt.wS3++;
+	const float inv = 1 / det;
+	const float u = nu * inv;
+	const uint64_t m2 = m & ballot(!(u < 0)) & ballot(!(u > 1));
+	if (m2 == 0) return;
+	if (STATS && RTX_DBG) cnt.wS4++;
+	const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;   // tvec x v0v1
+	const float v = (dx * qx + dy * qy + dz * qz) * inv;
+	const uint64_t m3 = m2 & ballot(!(v < 0)) & ballot(!(u + v > 1));
+	if (m3 == 0) return;
+	const float t = (e2x * qx + e2y * qy + e2z * qz) * inv;
+	const uint64_t m4 = m3 & ballot(!(t < 0)) & ballot(t < bt);     // objects.cpp:91, 623
+	if ((m4 >> __lane_id()) & 1ull) { bt = t; bu = u; bv = v; btri = tri; }
+}
+
+template <bool CULL, bool STATS>
+__device__ __forceinline__ void triTestPair(const TriPair& T, const PackedRay& r, float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
+{
+	// record dwords (A, B interleaved): e2x | e2y | e2z | e1x | e1y | e1z | v0x | v0y || v0z | tri
+	const f2 e2x = { F(T.a[0]), F(T.a[1]) }, e2y = { F(T.a[2]), F(T.a[3]) }, e2z = { F(T.a[4]), F(T.a[5]) };
+	const f2 e1x = { F(T.a[6]), F(T.a[7]) }, e1y = { F(T.a[8]), F(T.a[9]) }, e1z = { F(T.a[10]), F(T.a[11]) };
+	const f2 v0x = { F(T.a[12]), F(T.a[13]) }, v0y = { F(T.a[14]), F(T.a[15]) }, v0z = { F(T.b[0]), F(T.b[1]) };
+	// pvec = dir x v0v2 (objects.cpp:72), det = v0v1 . pvec (objects.cpp:73)
+	const f2 px = r.dyy * e2z - r.dzz * e2y;
+	const f2 py = r.dzz * e2x - r.dxx * e2z;
+	const f2 pz = r.dxx * e2y - r.dyy * e2x;
+	const f2 det = e1x * px + e1y * py + e1z * pz;
 	// culling on:  reject iff det < 1e-8 (then |det| < 1e-8 is implied);  off: reject iff |det| < 1e-8.
 	// Both compares are false for NaN, exactly like the reference's two ifs (objects.cpp:75-79).
-	const float dd = CULL ? det : fabsf(det);
-	const uint64_t m1 = ballot(!(dd < RTX_EPS8));
+	const uint64_t mA = ballot(!((CULL ? det.x : fabsf(det.x)) < RTX_EPS8));
+	const uint64_t mB = ballot(!((CULL ? det.y : fabsf(det.y)) < RTX_EPS8));
 	if (STATS && RTX_DBG) { cnt.wTri++; cnt.triLanes += __popcll(ballot(true)); }
-	if (m1 == 0) return;
+	if ((mA | mB) == 0) return;
 	if (STATS && RTX_DBG) cnt.wS2++;
-	const f2 txy = r.oxy - v0xy;                                              // tvec = orig - v0 (objects.cpp:82)
-	const float tz = r.oz - v0z;
-	const f2 np = txy * pxn;                                                  // (tx*px, -(ty*py))
-	const float nu = np.x - np.y + tz * pz;                                   // tvec . pvec (objects.cpp:83)
+	const f2 tx = r.oxx - v0x, ty = r.oyy - v0y, tz = r.ozz - v0z;            // tvec = orig - v0 (objects.cpp:82)
+	const f2 nu = tx * px + ty * py + tz * pz;                                // tvec . pvec (objects.cpp:83)
+	uint64_t goA = mA, goB = mB;
 	if (CULL) {
 		// Exact-safe rejection before the IEEE division.  Here 1e-8 <= det, so inv = RN(1/det) > 0 with relative
 		// error <= 2^-22 (2^-24 while 1/det is normal, <= 2^-22 in the denormal range det > 2^126), and u = RN(nu*inv):
 		//   nu < -2^-20            =>  |nu*inv| >= 2^-20 * 2^-128 * (1 - 2^-3) > 2^-149: no underflow to -0  =>  u < 0;
 		//   nu > RN(det*(1+2^-20)) =>  nu/det > 1+2^-21, and the roundings lose < 2^-21                    =>  u > 1.
-		// Lanes outside these sure cases (and every lane of the !CULL variant) take the division below, which
-		// then re-derives the same verdict for the sure cases, so the result is bit-identical either way.
-		const uint64_t sure = ballot(nu < -0x1p-20f) | ballot(nu > det * (1.0f + 0x1p-20f));
-		if ((m1 & ~sure) == 0) return;
+		// Lanes outside these sure cases (and every lane of the !CULL variant) take the division, which then
+		// re-derives the same verdict for the sure cases, so the result is bit-identical either way.
+		const f2 hi = det * (1.0f + 0x1p-20f);
+		goA &= ~(ballot(nu.x < -0x1p-20f) | ballot(nu.x > hi.x));
+		goB &= ~(ballot(nu.y < -0x1p-20f) | ballot(nu.y > hi.y));
+		if ((goA | goB) == 0) return;
 	}
-	if (STATS && RTX_DBG) cnt.wS3++;
-	const float inv = 1 / det;
-	const float u = nu * inv;
-	const uint64_t m2 = m1 & ballot(!(u < 0)) & ballot(!(u > 1));
-	if (m2 == 0) return;
-	if (STATS && RTX_DBG) cnt.wS4++;
-	const float tx = txy.x, ty = txy.y;
-	const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;   // tvec x v0v1
-	const float v = (r.dx * qx + r.dy * qy + r.dz * qz) * inv;
-	const uint64_t m3 = m2 & ballot(!(v < 0)) & ballot(!(u + v > 1));
-	if (m3 == 0) return;
-	const float t = (e2x * qx + e2y * qy + e2z * qz) * inv;
-	const uint64_t m4 = m3 & ballot(!(t < 0)) & ballot(t < bt);     // objects.cpp:91, 623
-	if ((m4 >> __lane_id()) & 1ull) { bt = t; bu = u; bv = v; btri = w9; }
+	// first-hit-wins needs A before B (objects.cpp:622-629)
+	if (goA != 0) triTail<STATS>(goA, det.x, nu.x, tx.x, ty.x, tz.x, e1x.x, e1y.x, e1z.x, e2x.x, e2y.x, e2z.x, T.b[2], r.dxx.x, r.dyy.x, r.dzz.x, bt, bu, bv, btri, cnt);
+	if (goB != 0) triTail<STATS>(goB, det.y, nu.y, tx.y, ty.y, tz.y, e1x.y, e1y.y, e1z.y, e2x.y, e2y.y, e2z.y, T.b[3], r.dxx.x, r.dyy.x, r.dzz.x, bt, bu, bv, btri, cnt);
 }
 
 // Leaf / chunk certificates (rtxd::LeafHeader): true when the reference is CERTAIN to reject every
@@ -427,8 +433,7 @@ __device__ __forceinline__ void testPairs(const LeafPair* p, uint32_t pairs, con
 	for (uint32_t left = pairs;;) {
 		p = after(p, t0.b[3]);
 		const TriPair t1 = sloadPair(p + 1);
-		triTest<CULL, STATS>(t0.a[0], t0.a[1], t0.a[2], t0.a[3], t0.a[4], t0.a[5], t0.a[6], t0.a[7], t0.a[8], t0.a[9], pr, bt, bu, bv, btri, cnt);
-		triTest<CULL, STATS>(t0.a[10], t0.a[11], t0.a[12], t0.a[13], t0.a[14], t0.a[15], t0.b[0], t0.b[1], t0.b[2], t0.b[3], pr, bt, bu, bv, btri, cnt);
+		triTestPair<CULL, STATS>(t0, pr, bt, bu, bv, btri, cnt);
 		if (left == 1) break;
 		left = uni(left - 1);
 		p += 1;
@@ -452,8 +457,8 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 	uint32_t i = 0;
 	const uint32_t last = nN - 1;
 	PackedRay pr;
-	pr.dyx = f2{ d.y, d.x }; pr.dxy = f2{ d.x, d.y }; pr.dzz = f2{ d.z, d.z }; pr.oxy = f2{ o.x, o.y };
-	pr.dx = d.x; pr.dy = d.y; pr.dz = d.z; pr.oz = o.z;
+	pr.dxx = f2{ d.x, d.x }; pr.dyy = f2{ d.y, d.y }; pr.dzz = f2{ d.z, d.z };
+	pr.oxx = f2{ o.x, o.x }; pr.oyy = f2{ o.y, o.y }; pr.ozz = f2{ o.z, o.z };
 	const f2 oxx = { o.x, o.x }, oyy = { o.y, o.y }, ozz = { o.z, o.z }, ixx = { ix, ix }, iyy = { iy, iy }, izz = { iz, iz };
 	// max |dir_i|, rounded up a little: scales the leaf headers' error bound
 	const float dmax = fmaxf(fabsf(d.x), fmaxf(fabsf(d.y), fabsf(d.z))) * (1.0f + 0x1p-20f);
