@@ -114,9 +114,15 @@ def main():
     mask = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
     ssaa = not args.no_ssaa
 
+    img = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") if world > 1 else None
+
     def step():
         parallel.shard_frame(scene, fb, mask, world, rank, ssaa=ssaa)
-        parallel.gather_frame(fb, world, rank)
+        if world > 1:
+            # the frame has to end up in ONE place: quantise to the BGR8 image saveImage writes (4x fewer bytes than
+            # the fp32 framebuffer) and send every owned band straight into rank 0's image
+            scene.quantize(fb, img)
+            parallel.gather_frame(img, world, rank, bottom_up=True)
 
     def sync():
         torch.cuda.synchronize()
@@ -173,7 +179,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s @%dx%d, pass 1%s" % (os.path.basename(args.scene), W, H, " + Sobel-adaptive SSAA" if ssaa else ""),
-                   "rays_per_frame": rays_per_frame, "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.BAND, world, ", RCCL gather to rank 0" if world > 1 else ""),
+                   "rays_per_frame": rays_per_frame, "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.BAND, world, ", BGR8 bands sent to rank 0 over RCCL" if world > 1 else ""),
                    "pass1_ms": round(avg_ms, 3), "ssaa_ms": round(ms2 / max(n2, 1), 3),
                    "pass1_rays_rank0": int(c1[0]), "ssaa_rays_rank0": int(c2[0]), "ssaa_pixels_rank0": int(mask.sum()),
                    "ssaa_box_tests": int(c2[1]), "ssaa_tri_tests": int(c2[2])},

@@ -5,7 +5,8 @@ round-robin bands of BAND rows (the mesh sits centre-frame, so contiguous blocks
 Per frame and rank:
     pass 1 on the owned bands + a 1-row halo (recomputed, so the Sobel mask needs no exchange)
     Sobel mask + adaptive 4-ray pass on the owned rows
-    ONE collective: gather of the owned rows to rank 0 (the only real exchange step of the path).
+    quantise to BGR8 (what saveImage writes, util.cpp:46-58; 4x fewer bytes than the fp32 framebuffer)
+    ONE exchange: every owned band is sent to rank 0 as a point-to-point message, placed directly (gather_frame).
 The scene (<= ~60 MB) is replicated on every GPU.
 """
 import numpy as np
@@ -29,27 +30,34 @@ def shard_frame(scene, fb, mask, n_parts, part, band=BAND, ssaa=True, stream=Non
         scene.render_ssaa(mask, fb, stream=stream)
 
 
-def gather_frame(fb, n_parts, part, band=BAND, dst=0, group=None):
-    """Collects every rank's owned rows into rank `dst`'s fb (in place).  Works for device tensors over RCCL
-    and for CPU tensors over gloo (the world_size-2 CPU test)."""
-    import torch
+def band_ranges(height, band, n_parts, part):
+    """[(y0, y1), ...]: the contiguous row ranges (bands) rank `part` owns."""
+    return [(y0, min(y0 + band, height)) for b, y0 in enumerate(range(0, height, band)) if b % n_parts == part]
+
+
+def gather_frame(img, n_parts, part, band=BAND, dst=0, group=None, bottom_up=False):
+    """Collects every rank's owned rows into rank `dst`'s img (in place), with no staging copies: a band is a
+    contiguous slab of img, so every band travels as one point-to-point message straight from the owner's buffer into
+    its final place in dst's buffer (xGMI links are point-to-point: one grouped batch of sends / receives, no ring).
+    img: (H, ...) tensor -- the fp32 framebuffer, or the quantised BGR8 image with bottom_up=True (rtx_quantize_bgr8
+    stores image row y at H-1-y, util.cpp:50).  Device tensors go over RCCL, CPU tensors over gloo (CPU test)."""
     import torch.distributed as dist
     if n_parts == 1:
-        return fb
-    H = fb.shape[0]
-    counts = [len(owned_rows(H, band, n_parts, r)) for r in range(n_parts)]
-    mx = max(counts)
-    mine = torch.as_tensor(owned_rows(H, band, n_parts, part), device=fb.device)
-    send = torch.zeros((mx,) + tuple(fb.shape[1:]), dtype=fb.dtype, device=fb.device)
-    send[: len(mine)] = fb.index_select(0, mine)
+        return img
+    H = img.shape[0]
+    flat = img.view(H, -1)
+
+    def slab(y0, y1):
+        return flat[H - y1:H - y0] if bottom_up else flat[y0:y1]
+
+    ops = []
     if part == dst:
-        recv = [torch.empty_like(send) for _ in range(n_parts)]
-        dist.gather(send, recv, dst=dst, group=group)
         for r in range(n_parts):
-            if r == dst:
-                continue
-            rows = torch.as_tensor(owned_rows(H, band, n_parts, r), device=fb.device)
-            fb.index_copy_(0, rows, recv[r][: len(rows)])
+            if r != dst:
+                ops += [dist.P2POp(dist.irecv, slab(y0, y1), r, group) for y0, y1 in band_ranges(H, band, n_parts, r)]
     else:
-        dist.gather(send, None, dst=dst, group=group)
-    return fb
+        ops = [dist.P2POp(dist.isend, slab(y0, y1), dst, group) for y0, y1 in band_ranges(H, band, n_parts, part)]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return img

@@ -34,10 +34,19 @@ fb2 = o.ssaa(fb, own)
 keep = np.zeros_like(fb2); keep[mine] = fb2[mine]
 t = torch.from_numpy(keep.copy())
 parallel.gather_frame(t, world, rank, band=band)
+ref = o.ssaa(full, mask_full)
 if rank == 0:
-    ref = o.ssaa(full, mask_full)
     got = t.numpy()
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), 'gathered frame != single-process frame'
+    # the quantised, bottom-up image travels the same way (what bench.py gathers at N > 1)
+q = np.zeros((H, W, 3), np.uint8)
+qk = np.clip(keep, 0, 1)
+q[H - 1 - mine] = (qk[mine][:, :, ::-1] * 255).astype(np.uint8)
+tq = torch.from_numpy(q)
+parallel.gather_frame(tq, world, rank, band=band, bottom_up=True)
+if rank == 0:
+    want = (np.clip(ref, 0, 1)[::-1, :, ::-1] * 255).astype(np.uint8)
+    assert np.array_equal(tq.numpy(), want), 'gathered BGR8 image != single-process image'
     print('GATHER_OK')
 dist.destroy_process_group()
 """

@@ -1,4 +1,5 @@
-// Microbenchmark: issue rate of v_mul_f32 / v_pk_mul_f32 / v_fma_f32 on gfx950 (wave64), 8 waves per SIMD.
+// Microbenchmark: issue rate of v_mul_f32 / v_pk_mul_f32 / v_fma_f32 / v_pk_fma_f32 / v_pk_add_f32 / v_cmp (SGPR result) /
+// v_max3_f32 / v_rcp_f32 on gfx950 (wave64), 8 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -16,6 +17,29 @@ template <int MODE> __global__ void __launch_bounds__(256) k(float* out, float a
 		else if (MODE == 1) {
 #pragma unroll
 			for (int u = 0; u < 8; u++) { p0 *= bb; p1 *= bb; p2 *= bb; p3 *= bb; }
+		}
+		else if (MODE == 3) {
+#pragma unroll
+			for (int u = 0; u < 8; u++) { p0 = __builtin_elementwise_fma(p0, bb, p1); p1 = __builtin_elementwise_fma(p1, bb, p2); p2 = __builtin_elementwise_fma(p2, bb, p3); p3 = __builtin_elementwise_fma(p3, bb, p0); }
+		}
+		else if (MODE == 4) {
+#pragma unroll
+			for (int u = 0; u < 8; u++) { p0 += bb; p1 += bb; p2 += bb; p3 += bb; }
+		}
+		else if (MODE == 5) {
+#pragma unroll
+			for (int u = 0; u < 8; u++) { x0 = __builtin_fmaxf(__builtin_fmaxf(x0, x1), b); x1 = __builtin_fmaxf(__builtin_fmaxf(x1, x2), b); x2 = __builtin_fmaxf(__builtin_fmaxf(x2, x3), b); x3 = __builtin_fmaxf(__builtin_fmaxf(x3, x0), a); }
+		}
+		else if (MODE == 6) {
+#pragma unroll
+			for (int u = 0; u < 8; u++) { x0 = __builtin_amdgcn_rcpf(x0); x1 = __builtin_amdgcn_rcpf(x1); x2 = __builtin_amdgcn_rcpf(x2); x3 = __builtin_amdgcn_rcpf(x3); }
+		}
+		else if (MODE == 7) {
+			// v_cmp writing an SGPR pair + scalar use
+			unsigned long long acc = 0;
+#pragma unroll
+			for (int u = 0; u < 8; u++) { acc += __builtin_amdgcn_ballot_w64(x0 < b + u); acc ^= __builtin_amdgcn_ballot_w64(x1 < a + u); acc += __builtin_amdgcn_ballot_w64(x2 > b + u); acc ^= __builtin_amdgcn_ballot_w64(x3 > a + u); }
+			x4 += (float)(unsigned)(acc & 1);
 		}
 		else {
 #pragma unroll
@@ -41,4 +65,6 @@ template <int MODE> void run(const char* name, int instrPerIter, int flopsPerIns
 	       waveInstr * 64 * flopsPerInstrPerLane / (ms * 1e-3) / 1e12);
 	hipFree(out);
 }
-int main() { run<0>("v_mul_f32", 64, 1); run<1>("v_pk_mul_f32", 32, 2); run<2>("v_fma_f32", 64, 2); return 0; }
+int main() { run<0>("v_mul_f32", 64, 1); run<1>("v_pk_mul_f32", 32, 2); run<2>("v_fma_f32", 64, 2);
+	run<3>("v_pk_fma_f32", 32, 4); run<4>("v_pk_add_f32", 32, 2); run<5>("v_max3_f32", 32, 1); run<6>("v_rcp_f32", 32, 1); run<7>("v_cmp->sgpr", 32, 1);
+	return 0; }
