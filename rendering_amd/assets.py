@@ -58,6 +58,31 @@ def bumpy_sphere_obj(nu, nv):
     return ("\n".join(lines) + "\n").encode()
 
 
+def coincident_obj(nu=48, nv=25):
+    """Bumpy sphere in which every face is listed twice: the copies share positions but carry different vertex
+    normals, so every hit is an exact t tie between two triangles with different shading.  The reference keeps the
+    copy it meets first (strict `<`, objects.cpp:623); a renderer that stores leaf references in another order must
+    break the tie by the reference's order to agree."""
+    base = bumpy_sphere_obj(nu, nv).decode().split("\n")
+    v = [l for l in base if l.startswith("v ")]
+    vn = [l for l in base if l.startswith("vn ")]
+    f = [l for l in base if l.startswith("f ")]
+    n = len(vn)
+    # second normal set: the same normals rotated about y by 60 degrees
+    c, s_ = np.cos(np.pi / 3), np.sin(np.pi / 3)
+    vn2 = []
+    for l in vn:
+        x, y, z = [float(t) for t in l.split()[1:]]
+        vn2.append("vn %.6f %.6f %.6f" % (c * x + s_ * z, y, -s_ * x + c * z))
+    lines = ["# bumpy sphere with every face duplicated (generated)"] + v + vn + vn2
+    for k, l in enumerate(f):
+        idx = [t.split("//") for t in l.split()[1:]]
+        dup = "f " + " ".join("%s//%d" % (a, int(b) + n) for a, b in idx)
+        # alternate which copy comes first in the file
+        lines += [l, dup] if k % 2 == 0 else [dup, l]
+    return ("\n".join(lines) + "\n").encode()
+
+
 def torus_obj(nu=32, nv=24, R=1.0, r=0.35):
     """Textured torus, 2*nu*nv triangles, faces `v/vt/vn`, uv in [0,1] (cfg4 stand-in for shotgun.obj)."""
     lines = ["# torus nu=%d nv=%d (generated)" % (nu, nv)]
@@ -153,6 +178,7 @@ _GENERATORS = {
     "bumpy_25k.obj": lambda: bumpy_sphere_obj(160, 81),
     "bumpy_4k.obj": lambda: bumpy_sphere_obj(64, 33),
     "torus_1536.obj": lambda: torus_obj(32, 24),
+    "coincident_4k.obj": coincident_obj,
     "quad.obj": quad_poly_obj,
     "diffuse_1024.bmp": lambda: bmp24(diffuse_map(1024)),
     "normal_1024.bmp": lambda: bmp24(normal_map(1024)),

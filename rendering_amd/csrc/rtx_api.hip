@@ -67,30 +67,70 @@ LeafTri makeLeafTri(const rtx_mesh& m, uint32_t ref)
 	return lt;
 }
 
-void appendPairs(std::vector<LeafPair>& leaf, const rtx_mesh& m, uint32_t begin, uint32_t count)
+// Storage order of the references of one leaf: positions (relative to the leaf's first reference) sorted by the
+// 30-bit Morton code of the triangle centroids, so that consecutive references form compact patches.  Equal codes
+// are stored in DESCENDING reference order on purpose: coincident triangles then always exercise the tie-break that
+// restores the reference's winner (tests/test_gpu_parity.py, scenes/coincident.scene).
+std::vector<uint32_t> leafOrder(const rtx_mesh& m, uint32_t begin, uint32_t count, uint32_t maxOrd, bool& reordered)
+{
+	reordered = false;
+	std::vector<uint32_t> order(count);
+	for (uint32_t i = 0; i < count; i++) order[i] = i;
+	if (count <= kChunkTris || count - 1 > maxOrd) return order;    // one chunk / too long for the position field: reference order
+	std::vector<double> c((size_t)count * 3);
+	double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+	for (uint32_t i = 0; i < count; i++) {
+		const float* p = m.tri_pos + (size_t)m.refs[begin + i] * 9;
+		for (int a = 0; a < 3; a++) {
+			const double v = ((double)p[a] + (double)p[3 + a] + (double)p[6 + a]) / 3.0;
+			c[(size_t)i * 3 + a] = v;
+			if (v < lo[a]) lo[a] = v;
+			if (v > hi[a]) hi[a] = v;
+		}
+	}
+	const double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+	if (!(ext > 0) || !std::isfinite(ext)) return order;
+	auto spread = [](uint32_t v) { v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; return (v | (v << 2)) & 0x09249249u; };
+	std::vector<uint32_t> code(count);
+	for (uint32_t i = 0; i < count; i++) {
+		uint32_t q[3];
+		for (int a = 0; a < 3; a++) {
+			const double f = (c[(size_t)i * 3 + a] - lo[a]) / ext * 1023.0;
+			q[a] = f > 0 ? (f < 1023 ? (uint32_t)f : 1023u) : 0u;
+		}
+		code[i] = spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2;
+	}
+	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return code[a] != code[b] ? code[a] < code[b] : a > b; });
+	reordered = true;
+	return order;
+}
+
+// pairs of the references begin + order[k0 .. k0+count)
+// (triBits == 32: the leaf is stored in reference order and its records carry no position)
+void appendPairs(std::vector<LeafPair>& leaf, const rtx_mesh& m, uint32_t begin, const uint32_t* order, uint32_t count, uint32_t triBits)
 {
 	for (uint32_t k = 0; k < count; k += 2) {
 		LeafPair lp;
 		memset(&lp, 0, sizeof(lp));          // odd count: the second triangle stays degenerate (det == 0)
 		for (uint32_t h = 0; h < 2 && k + h < count; h++) {
-			const LeafTri lt = makeLeafTri(m, begin + k + h);
+			const LeafTri lt = makeLeafTri(m, begin + order[k + h]);
 			lp.e2x[h] = lt.e2x; lp.e2y[h] = lt.e2y; lp.e2z[h] = lt.e2z;
 			lp.e1x[h] = lt.e1x; lp.e1y[h] = lt.e1y; lp.e1z[h] = lt.e1z;
 			lp.v0x[h] = lt.v0x; lp.v0y[h] = lt.v0y; lp.v0z[h] = lt.v0z;
-			lp.tri[h] = lt.tri;
+			lp.tri[h] = lt.tri | (triBits < 32 ? order[k + h] << triBits : 0u);
 		}
 		leaf.push_back(lp);
 	}
 }
 
 // Certificate header (rtxd::LeafHeader) over leaf references [begin, begin+count), as a pair slot.
-LeafPair makeHeader(const rtx_mesh& m, uint32_t begin, uint32_t count)
+LeafPair makeHeader(const rtx_mesh& m, uint32_t begin, const uint32_t* order, uint32_t count)
 {
 	double mlo[3] = { 1e300, 1e300, 1e300 }, mhi[3] = { -1e300, -1e300, -1e300 };
 	double blo[3] = { 1e300, 1e300, 1e300 }, bhi[3] = { -1e300, -1e300, -1e300 };
 	double qmax = 0, q2max = 0, e1L1 = 0, e2L1 = 0, e1Len = 0, e2Len = 0;
 	for (uint32_t r = 0; r < count; r++) {
-		const LeafTri lt = makeLeafTri(m, begin + r);
+		const LeafTri lt = makeLeafTri(m, begin + order[r]);
 		const float* p = m.tri_pos + (size_t)lt.tri * 9;
 		// m = e2 x e1 and the error scales, in fp64 from the fp32 edges
 		const double e1[3] = { lt.e1x, lt.e1y, lt.e1z }, e2[3] = { lt.e2x, lt.e2y, lt.e2z };
@@ -280,6 +320,10 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		if (m.normal_map && !m.tri_tb) return bail(fail(RTX_ERR_ARG, "normal map without tangents"));
 		std::vector<Node> nodes(m.n_nodes);
 		std::vector<LeafPair> leaf;
+		// LeafPair::tri = triangle index | position in the reference's leaf order << triBits
+		uint32_t triBits = 1;
+		while (triBits < 32 && (m.n_tris >> triBits) != 0) triBits++;
+		const uint32_t maxOrd = triBits < 31 ? (1u << (32 - triBits)) - 2u : 0u;
 		leaf.reserve(m.n_refs / 2 + m.n_nodes / 2 + 2);
 		for (uint32_t i = 0; i < m.n_nodes; i++) {
 			Node& nd = nodes[i];
@@ -294,14 +338,17 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			nd.link = ~m.leaf_count[i]; nd.first = (int32_t)leaf.size();
 			for (uint32_t r = 0; r < count; r++)
 				if (m.refs[begin + r] >= m.n_tris) return bail(fail(RTX_ERR_ARG, "leaf reference out of range"));
-			// [leaf header] pairs...   or   [leaf header] { [chunk header] 8 pairs }...
-			leaf.push_back(makeHeader(m, begin, count));
-			if (count <= kChunkTris) appendPairs(leaf, m, begin, count);
+			// [leaf header] pairs...   or   [leaf header] { [chunk header] 8 pairs }...   in the leaf's storage order
+			bool reordered;
+			const std::vector<uint32_t> order = leafOrder(m, begin, count, maxOrd, reordered);
+			const uint32_t tb = reordered ? triBits : 32u;
+			leaf.push_back(makeHeader(m, begin, order.data(), count));
+			if (count <= kChunkTris) appendPairs(leaf, m, begin, order.data(), count, tb);
 			else {
 				for (uint32_t c = 0; c < count; c += kChunkTris) {
 					const uint32_t cn = std::min(kChunkTris, count - c);
-					leaf.push_back(makeHeader(m, begin + c, cn));
-					appendPairs(leaf, m, begin + c, cn);
+					leaf.push_back(makeHeader(m, begin, order.data() + c, cn));
+					appendPairs(leaf, m, begin, order.data() + c, cn, tb);
 				}
 			}
 		}
@@ -317,7 +364,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		if ((rc = upload(s->owned, m.diffuse_map, (size_t)m.diffuse_w * m.diffuse_h * 3, &dm.diffuse))) return bail(rc);
 		if ((rc = upload(s->owned, m.normal_map, (size_t)m.normal_w * m.normal_h * 3, &dm.normal))) return bail(rc);
 		if ((rc = upload(s->owned, m.specular_map, (size_t)m.specular_w * m.specular_h, &dm.specular))) return bail(rc);
-		dm.nNodes = m.n_nodes; dm.nRefs = m.n_refs; dm.nTris = m.n_tris;
+		dm.nNodes = m.n_nodes; dm.nRefs = m.n_refs; dm.nTris = m.n_tris; dm.triBits = triBits;
 		dm.dW = m.diffuse_w; dm.dH = m.diffuse_h; dm.nW = m.normal_w; dm.nH = m.normal_h; dm.sW = m.specular_w; dm.sH = m.specular_h;
 	}
 	std::vector<Object> objs(desc->n_objects);

@@ -26,6 +26,11 @@ static_assert(sizeof(Node) == 32, "node must be one s_load_dwordx8");
 // tools/ubench/pk_rate.hip), so the Moeller-Trumbore arithmetic of both triangles is issued once.
 // A leaf with an odd number of references is padded with a degenerate triangle (all zero: det = 0 is rejected by
 // the reference's own epsilon test, objects.cpp:76-79), so a leaf always starts on a pair boundary.
+// Inside a leaf the references are stored in SPATIAL order (Morton code of the centroids), not in the reference's
+// vector order, so that a chunk of consecutive references is a compact patch with a tight box and a narrow normal
+// range.  The reference keeps the FIRST of several accepted triangles with equal t (strict `<`, objects.cpp:623), so
+// every record carries its position in the reference's order and the walk breaks exact ties with it -- the winner
+// is the same triangle, bit for bit.
 // e1 = b - a and e2 = c - a are the fp32 differences the reference recomputes per test (objects.cpp:70-71);
 // they are ray-independent, so computing them once on upload is bit-identical.
 struct LeafPair {
@@ -33,7 +38,7 @@ struct LeafPair {
 	float e1x[2], e1y[2], e1z[2];
 	float v0x[2], v0y[2];
 	float v0z[2];
-	uint32_t tri[2];     // index into the per-triangle shading arrays
+	uint32_t tri[2];     // triangle index (into the per-triangle shading arrays) | position in the reference's leaf order << Mesh::triBits
 };
 static_assert(sizeof(LeafPair) == 80, "pair record = s_load_dwordx16 + s_load_dwordx4");
 
@@ -72,7 +77,7 @@ struct Mesh {
 	const float* specular; // w*h or null
 	uint32_t nNodes, nRefs, nTris;
 	uint32_t dW, dH, nW, nH, sW, sH;
-	uint32_t pad;
+	uint32_t triBits;      // low bits of LeafPair::tri that hold the triangle index
 };
 
 struct Object {

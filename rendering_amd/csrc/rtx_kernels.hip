@@ -310,10 +310,15 @@ template <typename T> __device__ __forceinline__ T after(T x, uint32_t v)
 struct PackedRay { f2 dxx, dyy, dzz, oxx, oyy, ozz; };
 
 // The tail of the test for one triangle (objects.cpp:81-94) for the lanes in m (a wave-uniform mask).
+// w = triangle index | (position in the reference's leaf order) << bits.  `best` = 1 + that position for the lanes whose
+// closest hit so far was found in THIS leaf, 0 otherwise: of several triangles accepted with exactly the same t the
+// reference keeps the one it meets first (strict `<`, objects.cpp:623), whatever order they are stored in here.
+struct Best { float t, u, v; uint32_t tri, ord; };
+
 template <bool STATS>
 __device__ __forceinline__ void triTail(uint64_t m, float det, float nu, float tx, float ty, float tz, float e1x, float e1y, float e1z,
-                                        float e2x, float e2y, float e2z, uint32_t tri, float dx, float dy, float dz,
-                                        float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
+                                        float e2x, float e2y, float e2z, uint32_t w, uint32_t bits, float dx, float dy, float dz,
+                                        Best& b, Counts& cnt)
 {
 	if (STATS && RTX_DBG) cnt.wS3++;
 	const float inv = 1 / det;
@@ -326,12 +331,13 @@ __device__ __forceinline__ void triTail(uint64_t m, float det, float nu, float t
 	const uint64_t m3 = m2 & ballot(!(v < 0)) & ballot(!(u + v > 1));
 	if (m3 == 0) return;
 	const float t = (e2x * qx + e2y * qy + e2z * qz) * inv;
-	const uint64_t m4 = m3 & ballot(!(t < 0)) & ballot(t < bt);     // objects.cpp:91, 623
-	if ((m4 >> __lane_id()) & 1ull) { bt = t; bu = u; bv = v; btri = tri; }
+	const uint32_t ord = (w >> bits) + 1u;
+	const uint64_t m4 = m3 & ballot(!(t < 0)) & (ballot(t < b.t) | (ballot(t == b.t) & ballot(ord < b.ord)));     // objects.cpp:91, 623
+	if ((m4 >> __lane_id()) & 1ull) { b.t = t; b.u = u; b.v = v; b.tri = w & ((1u << bits) - 1u); b.ord = ord; }
 }
 
 template <bool CULL, bool STATS>
-__device__ __forceinline__ void triTestPair(const TriPair& T, const PackedRay& r, float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
+__device__ __forceinline__ void triTestPair(const TriPair& T, uint32_t bits, const PackedRay& r, Best& b, Counts& cnt)
 {
 	// record dwords (A, B interleaved): e2x | e2y | e2z | e1x | e1y | e1z | v0x | v0y || v0z | tri
 	const f2 e2x = { F(T.a[0]), F(T.a[1]) }, e2y = { F(T.a[2]), F(T.a[3]) }, e2z = { F(T.a[4]), F(T.a[5]) };
@@ -365,8 +371,8 @@ __device__ __forceinline__ void triTestPair(const TriPair& T, const PackedRay& r
 		if ((goA | goB) == 0) return;
 	}
 	// first-hit-wins needs A before B (objects.cpp:622-629)
-	if (goA != 0) triTail<STATS>(goA, det.x, nu.x, tx.x, ty.x, tz.x, e1x.x, e1y.x, e1z.x, e2x.x, e2y.x, e2z.x, T.b[2], r.dxx.x, r.dyy.x, r.dzz.x, bt, bu, bv, btri, cnt);
-	if (goB != 0) triTail<STATS>(goB, det.y, nu.y, tx.y, ty.y, tz.y, e1x.y, e1y.y, e1z.y, e2x.y, e2y.y, e2z.y, T.b[3], r.dxx.x, r.dyy.x, r.dzz.x, bt, bu, bv, btri, cnt);
+	if (goA != 0) triTail<STATS>(goA, det.x, nu.x, tx.x, ty.x, tz.x, e1x.x, e1y.x, e1z.x, e2x.x, e2y.x, e2z.x, T.b[2], bits, r.dxx.x, r.dyy.x, r.dzz.x, b, cnt);
+	if (goB != 0) triTail<STATS>(goB, det.y, nu.y, tx.y, ty.y, tz.y, e1x.y, e1y.y, e1z.y, e2x.y, e2y.y, e2z.y, T.b[3], bits, r.dxx.x, r.dyy.x, r.dzz.x, b, cnt);
 }
 
 // Leaf / chunk certificates (rtxd::LeafHeader): true when the reference is CERTAIN to reject every
@@ -426,14 +432,13 @@ __device__ __forceinline__ bool certainlyRejected(const u32x16& hd, const V3& o,
 // Streams `pairs` leaf-reference pairs starting at p through triTest for the lanes in exec: wait(pair) -> issue(next
 // pair) -> test both.  The pair after the last one is fetched and ignored (a header, the next leaf, or padding).
 template <bool CULL, bool STATS>
-__device__ __forceinline__ void testPairs(const LeafPair* p, uint32_t pairs, const PackedRay& pr, float& bt, float& bu, float& bv,
-                                          uint32_t& btri, Counts& cnt)
+__device__ __forceinline__ void testPairs(const LeafPair* p, uint32_t pairs, uint32_t bits, const PackedRay& pr, Best& b, Counts& cnt)
 {
 	TriPair t0 = sloadPair(p);
 	for (uint32_t left = pairs;;) {
 		p = after(p, t0.b[3]);
 		const TriPair t1 = sloadPair(p + 1);
-		triTestPair<CULL, STATS>(t0, pr, bt, bu, bv, btri, cnt);
+		triTestPair<CULL, STATS>(t0, bits, pr, b, cnt);
 		if (left == 1) break;
 		left = uni(left - 1);
 		p += 1;
@@ -451,8 +456,11 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 	const Node* nodes = uni((const Node*)sloadp(&M->nodes));
 	const LeafPair* leaf = uni((const LeafPair*)sloadp(&M->leaf));
 	const uint32_t nN = uni(sload1(&M->nNodes));
+	Best b;
+	b.t = kFltMax; b.u = 0; b.v = 0; b.tri = 0; b.ord = 0;
 	bt = kFltMax; bu = 0; bv = 0; btri = 0;
 	if (nN == 0) return;
+	const uint32_t bits = uni(sload1(&M->triBits));
 	uint32_t resume = consider ? 0u : kNever;
 	uint32_t i = 0;
 	const uint32_t last = nN - 1;
@@ -503,6 +511,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 				// exec = the lanes that passed this leaf's box.  Leaf layout: [leaf header] pairs...  for n <= kChunkTris, and
 				// [leaf header] { [chunk header] kChunkTris/2 pairs }...  for larger leaves (rtxd::kChunkTris triangles per chunk).
 				const LeafPair* p = leaf + nd[7];
+				b.ord = 0;          // the closest hit so far (if any) comes from an earlier leaf: it wins every tie
 				const bool skip = certainlyRejected<CULL>(sload16(p), o, d, ix, iy, iz, dmax);
 				p += 1;
 #if RTX_DBG
@@ -513,7 +522,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 #endif
 				if (!skip) {
 					// exec = lanes for which some triangle of the leaf may be accepted
-					if (n <= kChunkTris) testPairs<CULL, STATS>(p, (n + 1) / 2, pr, bt, bu, bv, btri, cnt);
+					if (n <= kChunkTris) testPairs<CULL, STATS>(p, (n + 1) / 2, bits, pr, b, cnt);
 					else {
 						for (uint32_t done = 0; done < n; done = uni(done + kChunkTris)) {
 							const uint32_t cn = n - done < kChunkTris ? n - done : kChunkTris;
@@ -529,7 +538,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 								}
 							}
 #endif
-							if (!skipChunk) testPairs<CULL, STATS>(p, (cn + 1) / 2, pr, bt, bu, bv, btri, cnt);
+							if (!skipChunk) testPairs<CULL, STATS>(p, (cn + 1) / 2, bits, pr, b, cnt);
 							p += (cn + 1) / 2;
 						}
 					}
@@ -537,11 +546,12 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 			}
 			// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is true
 			// for this lane no later triangle or object can change the answer.
-			if (!STATS) { if (shadow && bt < tLimit) resume = kNever; }
+			if (!STATS) { if (shadow && b.t < tLimit) resume = kNever; }
 		}
 		nd = nxA;
 		i = next;
 	}
+	bt = b.t; bu = b.u; bv = b.v; btri = b.tri;
 }
 
 template <bool STATS>

@@ -19,6 +19,7 @@ BITEXACT = [
     ("mixed_materials", 320, 240),
     ("cfg4_textured_256", 256, 256),
     ("area_light", 320, 240),
+    ("coincident", 320, 240),     # every hit is an exact t tie between two triangles with different normals
 ]
 
 

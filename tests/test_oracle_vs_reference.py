@@ -37,7 +37,7 @@ print('OK')
 
 @pytest.mark.parametrize("name,w,h", [("cfg1_simple_shapes", 200, 120), ("cfg3_reflective_refractive", 200, 112),
                                       ("cfg4_textured_256", 160, 160), ("mixed_materials", 200, 152),
-                                      ("cfg2_smooth_4k", 160, 120), ("area_light", 200, 152)])
+                                      ("cfg2_smooth_4k", 160, 120), ("area_light", 200, 152), ("coincident", 160, 120)])
 def test_oracle_bit_identical_to_reference(name, w, h):
     # one scene per process: the reference keeps process-global option flags
     out = subprocess.run([sys.executable, "-c", CHILD % ROOT, name, str(w), str(h)], cwd=ROOT, capture_output=True, text=True)
