@@ -345,10 +345,21 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			leaf.push_back(makeHeader(m, begin, order.data(), count));
 			if (count <= kChunkTris) appendPairs(leaf, m, begin, order.data(), count, tb);
 			else {
-				for (uint32_t c = 0; c < count; c += kChunkTris) {
-					const uint32_t cn = std::min(kChunkTris, count - c);
-					leaf.push_back(makeHeader(m, begin, order.data() + c, cn));
-					appendPairs(leaf, m, begin, order.data() + c, cn, tb);
+				for (uint32_t g0 = 0; g0 < count; g0 += kGroupTris) {
+					const uint32_t gn = std::min(kGroupTris, count - g0);
+					size_t groupAt = 0;
+					if (count > kGroupTris) { groupAt = leaf.size(); leaf.push_back(makeHeader(m, begin, order.data() + g0, gn)); }
+					for (uint32_t c = g0; c < g0 + gn; c += kChunkTris) {
+						const uint32_t cn = std::min(kChunkTris, g0 + gn - c);
+						leaf.push_back(makeHeader(m, begin, order.data() + c, cn));
+						appendPairs(leaf, m, begin, order.data() + c, cn, tb);
+					}
+					if (count > kGroupTris) {
+						LeafHeader h;
+						memcpy(&h, &leaf[groupAt], sizeof(h));
+						h.pad[0] = (uint32_t)(leaf.size() - groupAt - 1);     // slots of the group: what a wave jumps over
+						memcpy(&leaf[groupAt], &h, sizeof(h));
+					}
 				}
 			}
 		}

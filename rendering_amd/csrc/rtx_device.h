@@ -146,6 +146,7 @@ struct Params {
 };
 
 constexpr int kFrameFields = 14;
+constexpr uint32_t kGroupTris = 64; // leaves with more references also carry one LeafHeader per kGroupTris references (LeafHeader::pad[0] = slots of the group)
 constexpr uint32_t kChunkTris = 8; // leaves with more references carry one extra LeafHeader per kChunkTris references
 
 } // namespace rtxd

@@ -524,22 +524,28 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 					// exec = lanes for which some triangle of the leaf may be accepted
 					if (n <= kChunkTris) testPairs<CULL, STATS>(p, (n + 1) / 2, bits, pr, b, cnt);
 					else {
-						for (uint32_t done = 0; done < n; done = uni(done + kChunkTris)) {
+						// leaves of more than kGroupTris references: every kGroupTris references (kGroupTris / kChunkTris chunks)
+						// are preceded by a group header; a lane holding its certificate sits the group out, the wave jumps
+						// over it when every lane does
+						const bool grouped = n > kGroupTris;
+						bool skipGroup = false;
+						uint32_t groupEnd = 0;
+						for (uint32_t done = 0; done < n;) {
+							if (grouped && done == groupEnd) {
+								const u32x16 gh = sload16(p);
+								skipGroup = certainlyRejected<CULL>(gh, o, d, ix, iy, iz, dmax);
+								p += 1;
+								groupEnd = uni(n - done < kGroupTris ? n : done + kGroupTris);
+								if (STATS && RTX_DBG) { cnt.wChunks++; if (ballot(!skipGroup) == 0) cnt.wChunkSkips++; }
+								if (ballot(!skipGroup) == 0) { p += gh[15]; done = groupEnd; continue; }
+							}
 							const uint32_t cn = n - done < kChunkTris ? n - done : kChunkTris;
 							const bool skipChunk = certainlyRejected<CULL>(sload16(p), o, d, ix, iy, iz, dmax);
 							p += 1;
-#if RTX_DBG
-							if (STATS) {
-								cnt.wChunks++; if (ballot(!skipChunk) == 0) cnt.wChunkSkips++;
-								if ((int)__lane_id() == __builtin_ctzll(ballot(true))) {
-									const int bk = 31 - __builtin_clz(n);
-									atomicAdd(gDbgHist + 32 + bk, 1ull);
-									if (ballot(!skipChunk) != 0) atomicAdd(gDbgHist + 48 + bk, (unsigned long long)cn);
-								}
-							}
-#endif
-							if (!skipChunk) testPairs<CULL, STATS>(p, (cn + 1) / 2, bits, pr, b, cnt);
+							if (STATS && RTX_DBG) { cnt.wChunks++; if (ballot(!(skipChunk || skipGroup)) == 0) cnt.wChunkSkips++; }
+							if (!(skipChunk || skipGroup)) testPairs<CULL, STATS>(p, (cn + 1) / 2, bits, pr, b, cnt);
 							p += (cn + 1) / 2;
+							done = uni(done + kChunkTris);
 						}
 					}
 				}
