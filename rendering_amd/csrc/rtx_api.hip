@@ -198,6 +198,11 @@ struct rtx_scene {
 	uint32_t* work = nullptr;     // [0] pass-1 queue head, [1] ssaa queue head, [3] probe queue head
 	unsigned long long* counters = nullptr;
 	int blocksPass1 = 0, blocksSsaa = 0;
+	// pass-1 tile queues (buildTileList): rebuilt when the view, the row range or the row ownership changes
+	std::vector<float> meshBounds;        // 6 floats per mesh: the root box
+	uint32_t* tileList = nullptr; size_t tileListCap = 0;   // [0, cap): queues in geometric order, [cap, 2 cap): ordered by cost
+	bool costValid = false;               // tileCost holds the costs of a launch with the current tileKey
+	std::vector<uint32_t> tileKey;        // what the current list was built for
 	// HIP-event pairs around every launch of {pass 1, sobel, ssaa} since the last rtx_kernel_time_reset
 	std::vector<hipEvent_t> evPool[3];
 	size_t evUsed[3] = { 0, 0, 0 };
@@ -364,6 +369,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			}
 		}
 		{ LeafPair z; memset(&z, 0, sizeof(z)); leaf.push_back(z); leaf.push_back(z); }
+		for (int c = 0; c < 6; c++) s->meshBounds.push_back(m.n_nodes ? m.node_bounds[c] : 0.0f);
 		Mesh& dm = meshes[mi];
 		memset(&dm, 0, sizeof(dm));
 		int rc;
@@ -432,6 +438,7 @@ void rtx_scene_destroy(rtx_scene* s)
 	for (void* p : s->owned) (void)hipFree(p);
 	if (s->frames) (void)hipFree(s->frames);
 	if (s->tileCost) { (void)hipFree(s->tileCost); (void)hipFree(s->items); }
+	if (s->tileList) (void)hipFree(s->tileList);
 	if (s->work) {
 		(void)hipFree(s->work); (void)hipFree(s->counters);
 		for (int i = 0; i < 3; i++) for (hipEvent_t e : s->evPool[i]) (void)hipEventDestroy(e);
@@ -446,6 +453,85 @@ int rtx_scene_set_view(rtx_scene* s, const rtx_view* v)
 	if (rc) return rc;
 	return ensureWork(s);
 }
+
+namespace {
+
+// Tile rectangle [tx0, tx1) x [ty0, ty1) that can see the root box of some mesh through the camera (conservative; the
+// whole frame when a box reaches behind the camera).  Inverse of primaryRay(): dir = normalize(xp, yp, -1) . M3 with an
+// orthonormal M3 (rMatrix, scene.cpp:22-49), so camera-space s = (P - camPos) . M3^T.
+void meshTileRect(const rtx_scene* s, uint32_t tilesX, uint32_t tilesYFull, uint32_t r[4])
+{
+	const View& v = s->params.view;
+	r[0] = tilesX; r[1] = 0; r[2] = tilesYFull; r[3] = 0;
+	const float* M = v.camM;
+	for (size_t m = 0; m + 6 <= s->meshBounds.size(); m += 6) {
+		const float* b = &s->meshBounds[m];
+		double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+		bool behind = false;
+		for (int c = 0; c < 8; c++) {
+			const double P[3] = { b[(c & 1) ? 3 : 0] - v.camPos[0], b[(c & 2) ? 4 : 1] - v.camPos[1], b[(c & 4) ? 5 : 2] - v.camPos[2] };
+			const double sx = P[0] * M[0] + P[1] * M[1] + P[2] * M[2], sy = P[0] * M[4] + P[1] * M[5] + P[2] * M[6], sz = P[0] * M[8] + P[1] * M[9] + P[2] * M[10];
+			if (!(sz < -1e-6)) { behind = true; break; }
+			const double xp = sx / -sz, yp = sy / -sz;
+			const double px = (xp / ((double)v.scale * v.aspect) + 1) * 0.5 * v.width - 1.0, py = (-yp / (double)v.scale + 1) * 0.5 * v.height - 1.0;
+			x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
+		}
+		if (behind || !(x0 <= x1) || !std::isfinite(x0 + x1 + y0 + y1)) { r[0] = 0; r[1] = tilesX; r[2] = 0; r[3] = tilesYFull; return; }
+		auto lo = [](double p) { const double t = std::floor(p / 8.0) - 1; return t < 0 ? 0u : (uint32_t)std::min(t, 65535.0); };
+		auto hi = [](double p, uint32_t cap) { const double t = std::floor(p / 8.0) + 2; return t < 0 ? 0u : (uint32_t)std::min<double>(t, cap); };
+		r[0] = std::min(r[0], lo(x0)); r[1] = std::max(r[1], hi(x1, tilesX)); r[2] = std::min(r[2], lo(y0)); r[3] = std::max(r[3], hi(y1, tilesYFull));
+	}
+}
+
+// The eight per-XCD queues of one pass-1 launch.  Only tiles with a row this launch renders are listed.
+int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t tilesX, uint32_t tileRow0, uint32_t tilesY)
+{
+	const Params& p = s->params;
+	std::vector<uint32_t> key = { rowBegin, lastRow, tilesX, p.bandH, p.nParts, p.part, p.halo, p.view.width, p.view.height };
+	for (int i = 0; i < 16; i++) { uint32_t w; memcpy(&w, &p.view.camM[i], 4); key.push_back(w); }
+	for (int i = 0; i < 3; i++) { uint32_t w; memcpy(&w, &p.view.camPos[i], 4); key.push_back(w); }
+	{ uint32_t w; memcpy(&w, &p.view.scale, 4); key.push_back(w); memcpy(&w, &p.view.aspect, 4); key.push_back(w); }
+	if (s->tileList && key == s->tileKey) return RTX_OK;
+	s->costValid = false;
+	const uint32_t H = p.view.height;
+	auto rowOwnedH = [&](uint32_t y) { return p.bandH == 0 || (y / p.bandH) % p.nParts == p.part; };
+	auto rowRenderedH = [&](uint32_t y) {
+		if (rowOwnedH(y)) return true;
+		if (!p.halo) return false;
+		return (y > 0 && rowOwnedH(y - 1)) || rowOwnedH(y + 1);
+	};
+	uint32_t rect[4];
+	meshTileRect(s, tilesX, (H + 7) / 8, rect);
+	std::vector<uint32_t> q[8][2];
+	for (uint32_t t = 0; t < tilesY; t++) {
+		const uint32_t ty = tileRow0 + t;
+		bool any = false;
+		for (uint32_t y = std::max(ty * 8, rowBegin); y < std::min(ty * 8 + 8, lastRow) && !any; y++) any = rowRenderedH(y);
+		if (!any) continue;
+		const uint32_t xq = (t / 8) & 7u;
+		const bool inY = ty >= rect[2] && ty < rect[3];
+		for (uint32_t tx = 0; tx < tilesX; tx++) q[xq][(inY && tx >= rect[0] && tx < rect[1]) ? 0 : 1].push_back(ty << 16 | tx);
+	}
+	std::vector<uint32_t> list(16);
+	for (int x = 0; x < 8; x++) {
+		list[x] = (uint32_t)list.size();
+		list[8 + x] = (uint32_t)(q[x][0].size() + q[x][1].size());
+		list.insert(list.end(), q[x][0].begin(), q[x][0].end());
+		list.insert(list.end(), q[x][1].begin(), q[x][1].end());
+	}
+	if (list.size() > s->tileListCap) {
+		if (s->tileList) HIPCHK(hipFree(s->tileList));
+		s->tileList = nullptr; s->tileListCap = 0;
+		HIPCHK(hipMalloc((void**)&s->tileList, 2 * list.size() * sizeof(uint32_t)));
+		s->tileListCap = list.size();
+	}
+	HIPCHK(hipDeviceSynchronize());      // an earlier launch may still be reading the old list
+	HIPCHK(hipMemcpy(s->tileList, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	s->tileKey = key;
+	return RTX_OK;
+}
+
+} // namespace
 
 int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, void* stream)
 {
@@ -467,6 +553,15 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	p.nTiles = p.tilesX * tilesY;
 	p.tilesY = tilesY;
 	p.workCounter = s->work + 128;            // eight per-XCD queue heads, 64 bytes apart
+	if (p.view.width > 0x7fff8u || p.view.height > 0x7fff8u) return fail(RTX_ERR_ARG, "frame too large");
+	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY))) return rc;
+	p.tileList = s->tileList;
+	if (s->costValid) {
+		// the previous launch rendered exactly these tiles from this view: start with the ones that were expensive
+		hipLaunchKernelGGL(rtxTileOrderKernel, dim3(8), dim3(1024), 0, st, s->tileList, s->tileCost, s->params.tilesXFull, s->tileList + s->tileListCap);
+		p.tileList = s->tileList + s->tileListCap;
+	}
+	s->costValid = true;
 	HIPCHK(hipMemsetAsync(s->work + 128, 0, 128 * sizeof(uint32_t), st));
 	uint32_t blocks = (uint32_t)s->blocksPass1;
 	const uint32_t wavesNeeded = (p.nTiles + 3) / 4;
@@ -588,6 +683,21 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] slowest work item %.3f ms, sum of items %.3f ms (100 MHz wall clock)\n", c[3] * 1e-5, c[4] * 1e-5);
 	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] wave-level: node visits %llu, triangle iterations %llu (%.1f lanes in exec), reached u-stage %llu, division %llu, v-stage %llu; leaf visits %llu, skipped whole by certificate %llu; chunk visits %llu, skipped %llu\n", c[5], c[6], c[6] ? (double)c[14] / c[6] : 0.0, c[7], c[8], c[9], c[10], c[11], c[12], c[13]);
 #if RTX_DBG
+	if (getenv("RTX_DEBUG_ITEMS")) {
+		std::vector<unsigned long long> w(3 * 16384);
+		HIPCHK(hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(gDbgWave), w.size() * 8));
+		unsigned long long t0 = ~0ull, t1 = 0; double busy = 0; int n = 0;
+		for (int i = 0; i < 16384; i++) if (w[3 * i]) { t0 = std::min(t0, w[3 * i]); t1 = std::max(t1, w[3 * i + 1]); busy += (double)w[3 * i + 2]; n++; }
+		if (n) {
+			int hist[10] = { 0 }; double idleEnd = 0, idleStart = 0;
+			for (int i = 0; i < 16384; i++) if (w[3 * i]) { int b = (int)(10.0 * (double)(w[3 * i + 1] - t0) / (double)(t1 - t0 + 1)); hist[b < 0 ? 0 : b > 9 ? 9 : b]++; idleEnd += (double)(t1 - w[3 * i + 1]); idleStart += (double)(w[3 * i] - t0); }
+			fprintf(stderr, "[rtx] pass-1 waves %d: span %.3f ms, mean busy %.3f ms, mean idle before first tile %.3f ms, after last tile %.3f ms; waves ending in each tenth of the span:", n, (t1 - t0) * 1e-5, busy / n * 1e-5, idleStart / n * 1e-5, idleEnd / n * 1e-5);
+			for (int b = 0; b < 10; b++) fprintf(stderr, " %d", hist[b]);
+			fprintf(stderr, "\n");
+		}
+	}
+#endif
+#if RTX_DBG >= 2
 	if (getenv("RTX_DEBUG_ITEMS")) {
 		unsigned long long h[64];
 		HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(gDbgHist), sizeof(h)));

@@ -125,6 +125,7 @@ struct Params {
 	// multi-GPU row ownership: row y belongs to this device iff (y / bandH) % nParts == part (bandH == 0: all rows)
 	uint32_t bandH, nParts, part, halo;
 	uint32_t* workCounter;          // persistent-wave work queue head (pass 1: eight heads, one per XCD, 64 B apart)
+	const uint32_t* tileList;       // pass 1: [0,8) first entry of each XCD's queue, [8,16) its length, then the tiles (ty << 16 | tx)
 	uint32_t tilesY, pad3;          // pass 1: tile rows covered by this launch
 	const uint8_t* ssaaMask;        // Sobel mask consumed by the SSAA kernels
 	const uint32_t* ssaaItems;      // (tile << 2 | chunk) work items: heavy tiles first ([0,nTiles*4) heavy, then normal)

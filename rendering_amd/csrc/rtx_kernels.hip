@@ -27,7 +27,7 @@
 using namespace rtxd;
 
 #ifndef RTX_DBG
-#define RTX_DBG 0     // 1: the instrumented variant also gathers wave-level stage counters (RTX_DEBUG_ITEMS=1 prints them)
+#define RTX_DBG 0     // 1: wave-level stage counters + per-wave pass-1 timeline, 2: + sampled certificate outcomes / leaf-size histograms (slow) (RTX_DEBUG_ITEMS=1 prints them)
 #endif
 #ifndef RTX_WAVES
 #define RTX_WAVES 8   // target waves per SIMD of the two ray kernels (register budget = 512 / RTX_WAVES VGPRs)
@@ -286,6 +286,7 @@ __device__ __forceinline__ float attenuation(float intensity, float l2)
 // ------------------------------------------------------------------------------------------------
 struct Hit { int obj; float t; uint32_t tri; float u, v; };
 #if RTX_DBG
+__device__ unsigned long long gDbgWave[3 * 16384];   // per wave of the last pass 1: first pop, last tile end, busy ticks
 __device__ unsigned long long gDbgHist[64];   // [0,8) certificate outcomes (one sampled lane per evaluation), [16,64) by log2(leaf size)
 #endif
 struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips, wChunks, wChunkSkips, triLanes; };
@@ -411,7 +412,7 @@ __device__ __forceinline__ bool certainlyRejected(const u32x16& hd, const V3& o,
 		const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
 		const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
 		const bool miss = sane && tnear > tfar;
-#if RTX_DBG
+#if RTX_DBG >= 2
 		if ((int)__lane_id() == __builtin_ctzll(ballot(true))) {      // the first lane in exec reports for itself
 			atomicAdd(gDbgHist + 2, (unsigned long long)(facing && !skip)); atomicAdd(gDbgHist + 4, (unsigned long long)(behind && !skip));
 			atomicAdd(gDbgHist + 5, (unsigned long long)(miss && !behind && !skip)); atomicAdd(gDbgHist + 6, (unsigned long long)(sane && !behind && !miss && !skip));
@@ -419,7 +420,7 @@ __device__ __forceinline__ bool certainlyRejected(const u32x16& hd, const V3& o,
 #endif
 		skip = skip || behind || miss;
 	}
-#if RTX_DBG
+#if RTX_DBG >= 2
 	if ((int)__lane_id() == __builtin_ctzll(ballot(true))) {
 		atomicAdd(gDbgHist + 0, 1ull);
 		atomicAdd(gDbgHist + 1, (unsigned long long)(CULL && fmaxf(ax, bx) + fmaxf(ay, by) + fmaxf(az, bz) < -errd));
@@ -514,7 +515,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shad
 				b.ord = 0;          // the closest hit so far (if any) comes from an earlier leaf: it wins every tie
 				const bool skip = certainlyRejected<CULL>(sload16(p), o, d, ix, iy, iz, dmax);
 				p += 1;
-#if RTX_DBG
+#if RTX_DBG >= 2
 				if (STATS) {
 					cnt.wLeaves++; if (ballot(!skip) == 0) cnt.wLeafSkips++;
 					if (ballot(!skip) != 0 && (int)__lane_id() == __builtin_ctzll(ballot(true))) atomicAdd(gDbgHist + 16 + (31 - __builtin_clz(n)), 1ull);
@@ -929,20 +930,21 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 	// (one global queue) every L2 would have to hold the triangles of the whole sweep.  Instead the frame is cut
 	// into bands of 8 tile rows (64 pixel rows), band b belongs to queue b % 8, and a wave first drains the queue
 	// of the XCD it runs on (s_getreg XCC_ID), then helps the others (work stealing, for load balance only --
-	// any wave may render any tile).
+	// any wave may render any tile).  The queues are explicit tile lists built by the host (rtx_api.hip,
+	// buildTileList): tiles that can see a mesh come first, so the tail of the launch consists of cheap tiles.
 	const uint32_t xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
-	const uint32_t bandTiles = 8 * P.tilesX;
-	const uint32_t nBands = (P.tilesY + 7) / 8;
+#if RTX_DBG
+	const unsigned long long dbgStart = wall_clock64();
+	unsigned long long dbgEnd = dbgStart, dbgBusy = 0;
+#endif
 	for (uint32_t attempt = 0; attempt < 8; attempt = uni(attempt + 1)) {
 		const uint32_t q = (xcd + attempt) & 7u;
-		const uint32_t qBands = nBands > q ? (nBands - q + 7) / 8 : 0;
-		const uint32_t qSize = qBands * bandTiles;
+		const uint32_t qBase = sload1(P.tileList + q), qSize = sload1(P.tileList + 8 + q);
 		for (;;) {
 			const uint32_t j = nextWork(P.workCounter + q * 16);
 			if (j >= qSize) break;
-			const uint32_t lb = j / bandTiles, r = j - lb * bandTiles;
-			const uint32_t ty0 = (lb * 8 + q) * 8 + r / P.tilesX, tx = r % P.tilesX, ty = P.tileRow0 + ty0;
-			if (ty0 >= P.tilesY) continue;
+			const uint32_t tile = sload1(P.tileList + qBase + j);
+			const uint32_t tx = tile & 0xffffu, ty = tile >> 16;
 			const uint32_t x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
 			// x1/y1 are clamped to W-1/H-1: the last column and row are never rendered (scene.cpp:369-372)
 			const bool valid = x < W - 1 && y < H - 1 && y >= P.rowBegin && y < P.rowEnd && rowRendered(P, y);
@@ -952,6 +954,9 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 			const unsigned long long t0 = wall_clock64();
 			const V3 c = castRayWave<STATS>(P, valid, o, d, gl, cnt);
 			const unsigned long long dt = wall_clock64() - t0;
+#if RTX_DBG
+			dbgEnd = t0 + dt; dbgBusy += dt;
+#endif
 			if (lane == 0) {
 				// remembered per tile: the SSAA pass starts with the tiles that were expensive here (longest job first)
 				P.tileCost[ty * P.tilesXFull + tx] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
@@ -963,6 +968,9 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 			}
 		}
 	}
+#if RTX_DBG
+	if (lane == 0 && (gl >> 6) < 16384) { gDbgWave[3 * (gl >> 6)] = dbgStart; gDbgWave[3 * (gl >> 6) + 1] = dbgEnd; gDbgWave[3 * (gl >> 6) + 2] = dbgBusy; }
+#endif
 	if (STATS) flushCounts(P, cnt);
 }
 
@@ -1030,6 +1038,33 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
 		}
 	}
 	if (STATS) flushCounts(P, cnt);
+}
+
+// Re-orders the eight pass-1 queues by the cost the tiles had in the previous launch of the same view (heaviest first:
+// longest-job-first keeps the end of the launch free of long tiles).  One block per queue: histogram of the cost
+// classes (log2 of the ticks), offsets in descending class order, scatter.  The order inside a class is arbitrary --
+// the picture does not depend on the order tiles are rendered in.
+__global__ void __launch_bounds__(1024) rtxTileOrderKernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ cost,
+                                                           uint32_t tilesXFull, uint32_t* __restrict__ out)
+{
+	__shared__ uint32_t hist[32], cursor[32];
+	const uint32_t q = blockIdx.x;
+	const uint32_t base = list[q], n = list[8 + q];
+	if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+	if (threadIdx.x == 0) { out[q] = base; out[8 + q] = n; }
+	__syncthreads();
+	auto klass = [&](uint32_t tile) { const uint32_t c = cost[(tile >> 16) * tilesXFull + (tile & 0xffffu)]; return c ? 31u - (uint32_t)__builtin_clz(c) : 0u; };
+	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[klass(list[base + i])], 1u);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t run = 0;
+		for (int k = 31; k >= 0; k--) { cursor[k] = run; run += hist[k]; }
+	}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+		const uint32_t tile = list[base + i];
+		out[base + atomicAdd(&cursor[klass(tile)], 1u)] = tile;
+	}
 }
 
 // Builds the SSAA work list: one thread per 8x8 tile counts the tile's flagged pixels and appends one item per
