@@ -22,6 +22,8 @@ namespace {
 
 thread_local std::string gErr;
 
+int scanExclusive(uint32_t* data, uint32_t n, uint32_t* tmp, hipStream_t st, uint32_t& launches);   // rtx_bvh.hip
+
 int fail(int code, const std::string& msg) { gErr = msg; return code; }
 
 #define HIPCHK(expr)                                                                                         \
@@ -194,7 +196,8 @@ struct rtx_scene {
 	bool stats = false;
 	// lazily sized work buffers
 	float* frames = nullptr; size_t framesBytes = 0;
-	uint32_t* tileCost = nullptr; uint32_t* items = nullptr; size_t tileCap = 0;   // per-tile pass-1 cost, SSAA work lists
+	uint32_t* tileCost = nullptr; uint32_t* items = nullptr; size_t tileCap = 0;   // per-tile pass-1 cost, SSAA scan array (2 tiles + 1, then scan scratch)
+	uint32_t* ssaaPixels = nullptr; size_t ssaaPixCap = 0;                         // SSAA flagged-pixel list (<= W * H entries)
 	uint32_t* work = nullptr;     // [0] pass-1 queue head, [1] ssaa queue head, [3] probe queue head
 	unsigned long long* counters = nullptr;
 	int blocksPass1 = 0, blocksSsaa = 0;
@@ -257,9 +260,16 @@ int ensureWork(rtx_scene* s)
 		if (s->tileCost) { HIPCHK(hipFree(s->tileCost)); HIPCHK(hipFree(s->items)); }
 		s->tileCost = nullptr; s->items = nullptr; s->tileCap = 0;
 		HIPCHK(hipMalloc((void**)&s->tileCost, tiles * sizeof(uint32_t)));
-		HIPCHK(hipMalloc((void**)&s->items, tiles * 8 * sizeof(uint32_t)));
+		HIPCHK(hipMalloc((void**)&s->items, (tiles * 2 + 1 + tiles / 256 + 1024) * sizeof(uint32_t)));
 		HIPCHK(hipMemset(s->tileCost, 0, tiles * sizeof(uint32_t)));
 		s->tileCap = tiles;
+	}
+	const size_t pixels = tiles * 64;     // every tile's pixels, padded to whole tiles
+	if (pixels > s->ssaaPixCap) {
+		if (s->ssaaPixels) HIPCHK(hipFree(s->ssaaPixels));
+		s->ssaaPixels = nullptr; s->ssaaPixCap = 0;
+		HIPCHK(hipMalloc((void**)&s->ssaaPixels, pixels * sizeof(uint32_t)));
+		s->ssaaPixCap = pixels;
 	}
 	s->params.tileCost = s->tileCost;
 	s->params.tilesXFull = txFull;
@@ -439,6 +449,7 @@ void rtx_scene_destroy(rtx_scene* s)
 	if (s->frames) (void)hipFree(s->frames);
 	if (s->tileCost) { (void)hipFree(s->tileCost); (void)hipFree(s->items); }
 	if (s->tileList) (void)hipFree(s->tileList);
+	if (s->ssaaPixels) (void)hipFree(s->ssaaPixels);
 	if (s->work) {
 		(void)hipFree(s->work); (void)hipFree(s->counters);
 		for (int i = 0; i < 3; i++) for (hipEvent_t e : s->evPool[i]) (void)hipEventDestroy(e);
@@ -602,7 +613,6 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream;
 	HIPCHK(hipMemsetAsync(s->work + 1, 0, sizeof(uint32_t), st));
-	HIPCHK(hipMemsetAsync(s->work + 4, 0, 2 * sizeof(uint32_t), st));
 	if ((rc = stamp(s, 2, st))) return rc;
 	Params p = s->params;
 	p.fb = fb_dev;
@@ -610,10 +620,21 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	p.ssaaMask = mask_dev;
 	p.rowBegin = rowBegin; p.rowEnd = rowEnd;
 	p.nTiles = (uint32_t)s->tileCap >= p.tilesXFull * ((H + 7) / 8) ? p.tilesXFull * ((H + 7) / 8) : 0;
-	p.ssaaItems = s->items;
-	p.ssaaCounts = s->work + 4;
-	// tiles on which pass 1 spent more than 0.25 ms go first (wall clock = 100 MHz)
-	hipLaunchKernelGGL(rtxSsaaListKernel, dim3((p.nTiles + 255) / 256), dim3(256), 0, st, p, s->items, s->work + 4, 25000u);
+	p.ssaaScan = s->items;
+	p.ssaaPixels = s->ssaaPixels;
+	if (p.nTiles == 0 || p.view.width > 0xffffu || p.view.height > 0xffffu) return fail(RTX_ERR_ARG, "frame too large for the SSAA pixel list");
+	// flagged pixels -> one packed list; tiles on which pass 1 spent more than 0.25 ms go first (wall clock = 100 MHz)
+	const uint32_t heavyTicks = 25000u, scanN = 2 * p.nTiles + 1;
+	// fewer flagged pixels than two full rounds of waves: tile-local waves (see rtxSsaaCountKernel)
+	const uint32_t localBelow = (uint32_t)s->blocksSsaa * 4u * 16u * 2u;
+	uint32_t* mode = s->work + 8;             // [0] local mode, [1] flagged pixels
+	uint32_t launches = 0;
+	hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, 0u, 0u);
+	if ((rc = scanExclusive(s->items, scanN, s->items + scanN, st, launches))) return rc;
+	HIPCHK(hipMemcpyAsync(mode + 1, s->items + 2 * (size_t)p.nTiles, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+	hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, 1u, localBelow);
+	if ((rc = scanExclusive(s->items, scanN, s->items + scanN, st, launches))) return rc;
+	hipLaunchKernelGGL(rtxSsaaScatterKernel, dim3((p.nTiles + 255) / 256), dim3(256), 0, st, p, s->items, mode, s->ssaaPixels, heavyTicks);
 	HIPCHK(hipGetLastError());
 	if (s->stats) hipLaunchKernelGGL(rtxSsaaKernel<true>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxSsaaKernel<false>, dim3(s->blocksSsaa), dim3(256), 0, st, p);

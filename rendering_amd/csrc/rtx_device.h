@@ -128,8 +128,8 @@ struct Params {
 	const uint32_t* tileList;       // pass 1: [0,8) first entry of each XCD's queue, [8,16) its length, then the tiles (ty << 16 | tx)
 	uint32_t tilesY, pad3;          // pass 1: tile rows covered by this launch
 	const uint8_t* ssaaMask;        // Sobel mask consumed by the SSAA kernels
-	const uint32_t* ssaaItems;      // (tile << 2 | chunk) work items: heavy tiles first ([0,nTiles*4) heavy, then normal)
-	const uint32_t* ssaaCounts;     // [0] heavy items, [1] normal items
+	const uint32_t* ssaaPixels;     // the flagged pixels (x | y << 16; ~0 = padding), tiles that were expensive in pass 1 first, tile by tile
+	const uint32_t* ssaaScan;       // [t]: first list slot of heavy tile t, [nTiles + t]: of normal tile t, [2 nTiles]: number of flagged pixels
 	uint32_t* tileCost;             // pass 1: wall-clock ticks (100 MHz) spent on each 8x8 tile of the frame
 	uint32_t tilesXFull, pad2;      // tiles per row of the whole frame (tileCost indexing)
 	// recursion frames: [slot][field][lane]

@@ -999,27 +999,17 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
 	const uint32_t W = P.view.width, H = P.view.height;
 	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	for (;;) {
-		// work item = (tile, chunk) from the list built by rtxSsaaListKernel: chunk c re-renders flagged pixels
-		// 16c .. 16c+15 of the tile; tiles that were expensive in pass 1 come first (longest-job-first)
+		// work item = 16 consecutive entries of the flagged-pixel list (rtxSsaaCountKernel / rtxSsaaScatterKernel):
+		// full waves even where a tile has only a few flagged pixels; the pixels of tiles that were expensive in pass 1
+		// come first (longest-job-first), tile by tile, so the rays of a wave stay close together
 		const uint32_t work = nextWork(P.workCounter);
-		const uint32_t nHeavy = sload1(P.ssaaCounts), nNormal = sload1(P.ssaaCounts + 1);
-		if (work >= nHeavy + nNormal) break;
-		const uint32_t item = work < nHeavy ? P.ssaaItems[work] : P.ssaaItems[(size_t)P.nTiles * 4 + (work - nHeavy)];
-		const uint32_t tile = uni(item) >> 2, chunk = uni(item) & 3;
-		const uint32_t ty = tile / P.tilesXFull, tx = tile - ty * P.tilesXFull;
-		const uint32_t x0 = tx * 8, y0 = ty * 8;
-		uint64_t flagged;
-		{
-			const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3);
-			// the workers only visit x < W-1, y < H-1 (scene.cpp:369-372, 523-525)
-			const bool in = x < W - 1 && y < H - 1 && y >= P.rowBegin && y < P.rowEnd && rowOwned(P.bandH, P.nParts, P.part, y);
-			flagged = ballot(in && P.ssaaMask[(size_t)y * W + x] != 0);
-		}
-		const uint32_t nf = (uint32_t)__popcll(flagged);
-		const uint32_t g = chunk * 16 + (lane >> 2), sub = lane & 3;
-		const bool valid = g < nf;
-		const uint32_t pos = nthSetBit(flagged, valid ? g : 0);
-		const uint32_t x = x0 + (pos & 7), y = y0 + (pos >> 3);
+		const uint32_t total = sload1(P.ssaaScan + 2 * (size_t)P.nTiles);
+		const uint32_t first = work * 16;
+		if (first >= total) break;
+		const uint32_t g = first + (lane >> 2), sub = lane & 3;
+		const uint32_t pxy = P.ssaaPixels[g < total ? g : first];
+		const bool valid = g < total && pxy != 0xffffffffu;
+		const uint32_t x = pxy & 0xffffu, y = pxy >> 16;
 		// offsets in the reference's order: (.25,.25) (.25,.75) (.75,.25) (.75,.75)  (scene.cpp:527-534)
 		const float fx = (float)x + ((sub & 2) ? 0.75f : 0.25f), fy = (float)y + ((sub & 1) ? 0.75f : 0.25f);
 		V3 o, d;
@@ -1067,41 +1057,59 @@ __global__ void __launch_bounds__(1024) rtxTileOrderKernel(const uint32_t* __res
 	}
 }
 
-// Builds the SSAA work list: one thread per 8x8 tile counts the tile's flagged pixels and appends one item per
-// started group of 16 to the heavy or the normal list (heavy = pass 1 spent more than `heavyTicks` on the tile).
-__global__ void __launch_bounds__(256) rtxSsaaListKernel(const Params P, uint32_t* __restrict__ items,
-                                                         uint32_t* __restrict__ counts, uint32_t heavyTicks)
+// SSAA work list, step 1: one thread per 8x8 tile counts the tile's flagged pixels (of the rows this launch re-renders)
+// into the heavy or the normal half of `scan` (heavy = pass 1 spent more than `heavyTicks` on the tile).  After an
+// exclusive scan over the 2 nTiles + 1 entries, step 2 writes the pixels to their slots.
+__device__ __forceinline__ uint64_t ssaaFlagged(const Params& P, uint32_t tx, uint32_t ty)
 {
 	const uint32_t W = P.view.width, H = P.view.height;
+	uint64_t m = 0;
+	for (uint32_t r = 0; r < 8; ++r) {
+		const uint32_t y = ty * 8 + r;
+		// the workers only visit x < W-1, y < H-1 (scene.cpp:369-372, 523-525)
+		if (!(y < H - 1 && y >= P.rowBegin && y < P.rowEnd && rowOwned(P.bandH, P.nParts, P.part, y))) continue;
+		for (uint32_t c = 0; c < 8; ++c) {
+			const uint32_t x = tx * 8 + c;
+			if (x < W - 1 && P.ssaaMask[(size_t)y * W + x] != 0) m |= 1ull << (r * 8 + c);
+		}
+	}
+	return m;
+}
+
+// mode[0] != 0 ("local"): every tile's pixels are padded to a multiple of 16 slots, so a wave never mixes tiles.
+// Chosen on the device (decide != 0: from the total of the previous, unpadded count): with few flagged pixels the
+// launch is bounded by its slowest wave and coherent, tile-local waves are shorter; with many, full waves win.
+__global__ void __launch_bounds__(256) rtxSsaaCountKernel(const Params P, uint32_t* __restrict__ scan, uint32_t* __restrict__ mode,
+                                                          uint32_t heavyTicks, uint32_t decide, uint32_t localBelow)
+{
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t tilesY = (H + 7) / 8;
-	const bool inGrid = t < P.tilesXFull * tilesY;
+	if (t > 2 * P.nTiles) return;
+	// mode[1] = number of flagged pixels found by the previous (unpadded) count
+	const uint32_t local = decide ? (mode[1] < localBelow ? 1u : 0u) : 0u;
+	if (t >= P.nTiles) { if (t == 2 * P.nTiles) { scan[t] = 0; if (decide) mode[0] = local; } return; }
 	const uint32_t ty = t / P.tilesXFull, tx = t - ty * P.tilesXFull;
-	uint32_t nf = 0;
-	if (inGrid) {
-		for (uint32_t r = 0; r < 8; ++r) {
-			const uint32_t y = ty * 8 + r;
-			// the workers only visit x < W-1, y < H-1 (scene.cpp:369-372, 523-525)
-			if (!(y < H - 1 && y >= P.rowBegin && y < P.rowEnd && rowOwned(P.bandH, P.nParts, P.part, y))) continue;
-			for (uint32_t c = 0; c < 8; ++c) {
-				const uint32_t x = tx * 8 + c;
-				if (x < W - 1 && P.ssaaMask[(size_t)y * W + x] != 0) nf++;
-			}
-		}
+	uint32_t nf = (uint32_t)__popcll(ssaaFlagged(P, tx, ty));
+	if (local) nf = (nf + 15u) & ~15u;
+	const bool heavy = P.tileCost[t] > heavyTicks;
+	scan[t] = heavy ? nf : 0u;
+	scan[P.nTiles + t] = heavy ? 0u : nf;
+}
+
+__global__ void __launch_bounds__(256) rtxSsaaScatterKernel(const Params P, const uint32_t* __restrict__ scan, const uint32_t* __restrict__ mode,
+                                                            uint32_t* __restrict__ pixels, uint32_t heavyTicks)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= P.nTiles) return;
+	const uint32_t ty = t / P.tilesXFull, tx = t - ty * P.tilesXFull;
+	uint64_t m = ssaaFlagged(P, tx, ty);
+	uint32_t slot = scan[P.tileCost[t] > heavyTicks ? t : P.nTiles + t];
+	uint32_t n = 0;
+	while (m) {
+		const uint32_t pos = (uint32_t)__builtin_ctzll(m);
+		m &= m - 1;
+		pixels[slot + n++] = (tx * 8 + (pos & 7)) | (ty * 8 + (pos >> 3)) << 16;
 	}
-	const uint32_t chunks = (nf + 15) / 16;
-	const bool heavy = inGrid && P.tileCost[t] > heavyTicks;
-	for (uint32_t c = 0; c < 4; ++c) {
-		for (int h = 0; h < 2; ++h) {
-			const bool mine = chunks > c && (heavy ? h == 0 : h == 1);
-			const uint64_t m = ballot(mine);
-			if (m == 0) continue;
-			uint32_t base = 0;
-			if (__lane_id() == 0) base = atomicAdd(counts + h, (uint32_t)__popcll(m));
-			base = __builtin_amdgcn_readfirstlane(base);
-			if (mine) items[(size_t)h * P.nTiles * 4 + base + __popcll(m & ((1ull << __lane_id()) - 1))] = (t << 2) | c;
-		}
-	}
+	if (mode[0]) for (; n & 15u; n++) pixels[slot + n] = 0xffffffffu;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import rendering_amd as RA
 g = RA.Scene("scenes/cfg2_smooth_250k.scene", 4096, 4096)
 fb = torch.zeros((4096, 4096, 3), dtype=torch.float32, device="cuda")
-g.render_pass1(fb); g.render_pass1(fb)
+g.render_pass1(fb); g.render_pass1(fb); g.render_pass1(fb)
 torch.cuda.synchronize()
 print("pass1 ms", g.last_kernel_ms(0))
 g.counters()
