@@ -26,6 +26,9 @@
 
 using namespace rtxd;
 
+#ifndef RTX_SSAA_VERY
+#define RTX_SSAA_VERY 8u   // x 0.25 ms of pass-1 time: tiles above get 4-pixel SSAA waves
+#endif
 #ifndef RTX_DBG
 #define RTX_DBG 0     // 1: wave-level stage counters + per-wave pass-1 timeline, 2: + sampled certificate outcomes / leaf-size histograms (slow) (RTX_DEBUG_ITEMS=1 prints them)
 #endif
@@ -1089,7 +1092,9 @@ __global__ void __launch_bounds__(256) rtxSsaaCountKernel(const Params P, uint32
 	if (t >= P.nTiles) { if (t == 2 * P.nTiles) { scan[t] = 0; if (decide) mode[0] = local; } return; }
 	const uint32_t ty = t / P.tilesXFull, tx = t - ty * P.tilesXFull;
 	uint32_t nf = (uint32_t)__popcll(ssaaFlagged(P, tx, ty));
-	if (local) nf = (nf + 15u) & ~15u;
+	// local mode: a wave holds 16 pixels of one tile -- or only 4 of a tile that was VERY slow in pass 1 (a silhouette),
+	// because the launch lasts as long as its slowest wave
+	if (local) nf = P.tileCost[t] > RTX_SSAA_VERY * heavyTicks ? ((nf + 3u) >> 2) * 16u : (nf + 15u) & ~15u;
 	const bool heavy = P.tileCost[t] > heavyTicks;
 	scan[t] = heavy ? nf : 0u;
 	scan[P.nTiles + t] = heavy ? 0u : nf;
@@ -1103,11 +1108,13 @@ __global__ void __launch_bounds__(256) rtxSsaaScatterKernel(const Params P, cons
 	const uint32_t ty = t / P.tilesXFull, tx = t - ty * P.tilesXFull;
 	uint64_t m = ssaaFlagged(P, tx, ty);
 	uint32_t slot = scan[P.tileCost[t] > heavyTicks ? t : P.nTiles + t];
+	const bool spread = mode[0] && P.tileCost[t] > RTX_SSAA_VERY * heavyTicks;      // 4 pixels per group of 16 slots
 	uint32_t n = 0;
 	while (m) {
 		const uint32_t pos = (uint32_t)__builtin_ctzll(m);
 		m &= m - 1;
 		pixels[slot + n++] = (tx * 8 + (pos & 7)) | (ty * 8 + (pos >> 3)) << 16;
+		if (spread && (n & 3u) == 0) for (int k = 0; k < 12; k++) pixels[slot + n++] = 0xffffffffu;
 	}
 	if (mode[0]) for (; n & 15u; n++) pixels[slot + n] = 0xffffffffu;
 }
