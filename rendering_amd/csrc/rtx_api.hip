@@ -161,13 +161,13 @@ LeafPair makeHeader(const rtx_mesh& m, uint32_t begin, const uint32_t* order, ui
 			float lo = (float)mlo[c], hi = (float)mhi[c];
 			lo = std::nextafterf(std::nextafterf(lo, -INFINITY), -INFINITY);
 			hi = std::nextafterf(std::nextafterf(hi, INFINITY), INFINITY);
-			h.mlo[c] = lo; h.mhi[c] = hi;
+			h.m[c][0] = lo; h.m[c][1] = hi;
 			mabs += std::max(std::fabs((double)lo), std::fabs((double)hi));
 		}
 	}
 	const double u = 5.9604644775390625e-08;      // 2^-24
 	const double err = (8 * u * qmax + 4 * u * mabs) * 1.001 + 1e-30;
-	if (!finite || !(err < 1e30)) { h.mlo[0] = h.mlo[1] = h.mlo[2] = -INFINITY; h.mhi[0] = h.mhi[1] = h.mhi[2] = INFINITY; h.err = INFINITY; finite = false; }
+	if (!finite || !(err < 1e30)) { for (int c = 0; c < 3; c++) { h.m[c][0] = -INFINITY; h.m[c][1] = INFINITY; } h.err = INFINITY; finite = false; }
 	else h.err = std::nextafterf((float)err, INFINITY);
 	// certificate (2): coefficients of the error budget, rounded up; disabled (inf) for headers whose magnitudes
 	// leave the range the derivation assumes
@@ -176,8 +176,8 @@ LeafPair makeHeader(const rtx_mesh& m, uint32_t begin, const uint32_t* order, ui
 	const double A2 = (r3 * (16 * u * qmax + 6 * u * mabs) * (e1Len + e2Len)) * 1.05 + 1e-30;
 	const bool ok2 = finite && qmax < 1048576.0 && q2max < 1048576.0 && A1 < 1e30 && A2 < 1e30;
 	for (int c = 0; c < 3; c++) {
-		h.blo[c] = ok2 ? std::nextafterf((float)blo[c], -INFINITY) : -INFINITY;
-		h.bhi[c] = ok2 ? std::nextafterf((float)bhi[c], INFINITY) : INFINITY;
+		h.b[c][0] = ok2 ? std::nextafterf((float)blo[c], -INFINITY) : -INFINITY;
+		h.b[c][1] = ok2 ? std::nextafterf((float)bhi[c], INFINITY) : INFINITY;
 	}
 	h.a1 = ok2 ? std::nextafterf((float)A1, INFINITY) : INFINITY;
 	h.a2 = ok2 ? std::nextafterf((float)A2, INFINITY) : INFINITY;

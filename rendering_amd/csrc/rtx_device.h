@@ -57,12 +57,12 @@ static_assert(sizeof(LeafPair) == 80, "pair record = s_load_dwordx16 + s_load_dw
 //       a computed t < 0 and is rejected by objects.cpp:91.  (The reference's box test has no t range, so e.g. every
 //       shadow ray leaving the mesh walks all the leaves behind it.)
 struct LeafHeader {
-	float mlo[3], mhi[3];
+	float m[3][2];     // (mlo_i, mhi_i): interval of m = v0v2 x v0v1, an operand pair of the packed instructions
 	float err;
 	float a1;
-	float blo[3], bhi[3];
+	float b[3][2];     // (blo_i, bhi_i): the AABB
 	float a2;
-	uint32_t pad[5];
+	uint32_t pad[5];   // pad[0]: group headers: pair slots of the group (what a wave jumps over)
 };
 static_assert(sizeof(LeafHeader) == sizeof(LeafPair), "header occupies one pair slot");
 

@@ -384,9 +384,10 @@ __device__ __forceinline__ void triTestPair(const TriPair& T, uint32_t bits, con
 template <bool CULL>
 __device__ __forceinline__ bool certainlyRejected(const u32x16& hd, const V3& o, const V3& d, float ix, float iy, float iz, float dmax)
 {
-	const float ax = d.x * F(hd[0]), bx = d.x * F(hd[3]);
-	const float ay = d.y * F(hd[1]), by = d.y * F(hd[4]);
-	const float az = d.z * F(hd[2]), bz = d.z * F(hd[5]);
+	// header dwords: (mlo.x mhi.x) (mlo.y mhi.y) (mlo.z mhi.z) err a1 (blo.x bhi.x) (blo.y bhi.y) (blo.z bhi.z) a2 span:
+	// the (lo, hi) pairs are operands of packed instructions
+	const f2 mx = f2{ F(hd[0]), F(hd[1]) } * f2{ d.x, d.x }, my = f2{ F(hd[2]), F(hd[3]) } * f2{ d.y, d.y }, mz = f2{ F(hd[4]), F(hd[5]) } * f2{ d.z, d.z };
+	const float ax = mx.x, bx = mx.y, ay = my.x, by = my.y, az = mz.x, bz = mz.y;
 	const float errd = F(hd[6]) * dmax;
 	bool skip = false;
 	// (1) certainly back-facing: U >= dir . (v0v2 x v0v1) = det for every triangle
@@ -395,25 +396,24 @@ __device__ __forceinline__ bool certainlyRejected(const u32x16& hd, const V3& o,
 	const float lc = fminf(ax, bx) + fminf(ay, by) + fminf(az, bz);
 	const bool facing = lc >= 4 * errd;
 	if (ballot(facing) != 0) {
-		const float lox = F(hd[8]) - o.x, hix = F(hd[11]) - o.x;
-		const float loy = F(hd[9]) - o.y, hiy = F(hd[12]) - o.y;
-		const float loz = F(hd[10]) - o.z, hiz = F(hd[13]) - o.z;
+		const f2 bxp = f2{ F(hd[8]), F(hd[9]) } - f2{ o.x, o.x }, byp = f2{ F(hd[10]), F(hd[11]) } - f2{ o.y, o.y }, bzp = f2{ F(hd[12]), F(hd[13]) } - f2{ o.z, o.z };
+		const float lox = bxp.x, hix = bxp.y, loy = byp.x, hiy = byp.y, loz = bzp.x, hiz = bzp.y;
 		const float dinf = fmaxf(fmaxf(fmaxf(fabsf(lox), fabsf(hix)), fmaxf(fabsf(loy), fabsf(hiy))), fmaxf(fabsf(loz), fabsf(hiz)));
 		const float g = lc - 2 * errd;
 		const float budget = dmax * (dinf * F(hd[7]) + F(hd[14]));      // g * (error radius) / 2, see DESIGN.md 3.3
 		// (magnitude guards: the error budget assumes no overflow / NaN in the reference's intermediate products)
 		const bool sane = facing && dmax < 0x1p20f && dinf < 0x1p40f;
 		// (2) entirely behind the ray origin: computed t < 0 for every triangle
-		const float boxdot = fmaxf(lox * d.x, hix * d.x) + fmaxf(loy * d.y, hiy * d.y) + fmaxf(loz * d.z, hiz * d.z);
+		const f2 dxp = bxp * f2{ d.x, d.x }, dyp = byp * f2{ d.y, d.y }, dzp = bzp * f2{ d.z, d.z };
+		const float boxdot = fmaxf(dxp.x, dxp.y) + fmaxf(dyp.x, dyp.y) + fmaxf(dzp.x, dzp.y);
 		const bool behind = sane && -boxdot * g > dmax * budget * 1.02f + 1e-30f;
 		// (3) the ray's line misses the AABB inflated by the error radius rho <= 2 * budget / g (+ fp32 slack): no
 		//     triangle can pass the reference's u / v tests
 		const float rho = 2 * budget * __builtin_amdgcn_rcpf(g) * (1.0f + 0x1p-10f) + dinf * 0x1p-20f;
-		const float x0 = (lox - rho) * ix, x1 = (hix + rho) * ix;
-		const float y0 = (loy - rho) * iy, y1 = (hiy + rho) * iy;
-		const float z0 = (loz - rho) * iz, z1 = (hiz + rho) * iz;
-		const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-		const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+		const f2 inflate = { -rho, rho };
+		const f2 tx = (bxp + inflate) * f2{ ix, ix }, ty = (byp + inflate) * f2{ iy, iy }, tz = (bzp + inflate) * f2{ iz, iz };
+		const float tnear = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
+		const float tfar = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
 		const bool miss = sane && tnear > tfar;
 #if RTX_DBG >= 2
 		if ((int)__lane_id() == __builtin_ctzll(ballot(true))) {      // the first lane in exec reports for itself
