@@ -130,11 +130,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # rays / box tests / triangle tests of one frame under reference semantics (instrumented variant, untimed)
+    # rays / box tests / triangle tests of one frame under reference semantics (instrumented variant, untimed).
+    # Pass 1 is counted over the OWNED rows only (halo off), so that the sum over the ranks is the ray count of the
+    # frame itself -- the rays of the recomputed halo rows are extra work of the sharding, not units of the metric.
     scene.counters_enable(True)
+    scene.set_row_ownership(parallel.BAND if world > 1 else 0, world, rank, halo=False)
     scene.counters_reset()
-    parallel.shard_frame(scene, fb, mask, world, rank, ssaa=False)
-    c1 = scene.counters()                       # pass 1 only (this rank's rows, halo rows included)
+    scene.render_pass1(fb)
+    c1 = scene.counters()                       # pass 1, this rank's rows
+    scene.counters_enable(False)
+    parallel.shard_frame(scene, fb, mask, world, rank, ssaa=False)      # proper framebuffer (with halo rows) for the mask
+    scene.counters_enable(True)
     if ssaa:
         scene.counters_reset()
         scene.sobel(fb, mask)

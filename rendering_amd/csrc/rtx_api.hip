@@ -626,7 +626,8 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	// flagged pixels -> one packed list; tiles on which pass 1 spent more than 0.25 ms go first (wall clock = 100 MHz)
 	const uint32_t heavyTicks = 25000u, scanN = 2 * p.nTiles + 1;
 	// fewer flagged pixels than two full rounds of waves: tile-local waves (see rtxSsaaCountKernel)
-	const uint32_t localBelow = (uint32_t)s->blocksSsaa * 4u * 16u * 2u;
+	uint32_t localBelow = (uint32_t)s->blocksSsaa * 4u * 16u * 2u;
+	if (const char* e = getenv("RTX_SSAA_LOCAL_BELOW")) localBelow = (uint32_t)strtoul(e, nullptr, 10);   // test knob: 0 = always packed
 	uint32_t* mode = s->work + 8;             // [0] local mode, [1] flagged pixels
 	uint32_t launches = 0;
 	hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, 0u, 0u);

@@ -105,6 +105,20 @@ def test_counters_match_reference_semantics(ra, oracle):
     assert np.array_equal(ref, got), (ref, got)
 
 
+@pytest.mark.parametrize("local_below", ["0", "4000000000"])
+def test_ssaa_list_modes_bit_exact(ra, oracle, monkeypatch, local_below):
+    """Both layouts of the SSAA flagged-pixel list (dense = full waves, tile-local = padded) give the reference's
+    frame; the knob forces the mode the device would otherwise pick from the number of flagged pixels."""
+    monkeypatch.setenv("RTX_SSAA_LOCAL_BELOW", local_below)
+    for name, w, h in (("cfg2_smooth_4k", 320, 240), ("cfg1_simple_shapes", 256, 256)):
+        path = "scenes/%s.scene" % name
+        o = oracle.OracleScene(path, w, h)
+        g = ra.Scene(path, w, h)
+        ref = o.ssaa(o.pass1())
+        got = g.render_host(ssaa=True)
+        assert ndiff(ref, got) == 0
+
+
 def test_tile_cost_map(ra):
     """rtx_tile_cost_read: one entry per 8x8 tile of the frame; tiles on the mesh cost more than background tiles."""
     g = ra.Scene("scenes/cfg2_smooth_4k.scene", 160, 120)
