@@ -27,12 +27,13 @@ SCENES = [
     ("cfg4_textured_256", 128, 128),
     ("mixed_materials", 128, 96),
     ("area_light", 128, 96),
+    ("coincident", 128, 96),       # every hit is an exact t tie: pins "first in leaf order wins" (objects.cpp:623)
 ]
 ASSETS_OF = {
     "cfg2_smooth_4k": ["bumpy_4k.obj"], "cfg2_smooth_25k": ["bumpy_25k.obj"],
     "cfg3_reflective_refractive": ["sky_left.bmp", "sky_front.bmp", "sky_right.bmp", "sky_back.bmp", "sky_top.bmp", "sky_bottom.bmp"],
     "cfg4_textured_256": ["torus_1536.obj", "diffuse_256.bmp", "normal_256.bmp", "specular_256.bmp"],
-    "mixed_materials": ["quad.obj", "bumpy_4k.obj", "torus_1536.obj"], "cfg1_simple_shapes": [], "area_light": ["bumpy_4k.obj"],
+    "mixed_materials": ["quad.obj", "bumpy_4k.obj", "torus_1536.obj"], "cfg1_simple_shapes": [], "area_light": ["bumpy_4k.obj"], "coincident": ["coincident_4k.obj"],
 }
 
 
