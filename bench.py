@@ -9,6 +9,7 @@ N > 1: rows are dealt to the ranks in 64-row bands, every frame ends with an RCC
 scaling of the same frame).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import subprocess
 import json
 import os
 import sys
@@ -24,11 +25,52 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+REF_CHILD = r"""
+import os, sys, time
+sys.path.insert(0, %r)
+from tools import ref_harness as R
+s = R.RefScene(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), workers=int(sys.argv[4]))
+t0 = time.perf_counter(); s.pass1(); dt = time.perf_counter() - t0
+print("REF_PASS1_SECONDS %%.6f" %% dt)
+"""
+
+
+def reference_baseline(scene_path, width, height, gpu_scene, cores):
+    """The REAL reference (oracle/_ref, built from /root/reference by oracle/Makefile where that tree exists; the .so
+    travels with the repo): Scene::launchWorkers of the whole frame with nWorkers = host cores, in a child process
+    (the reference prints progress to stdout and keeps process-global option flags).  None if it is not available."""
+    from tools import ref_harness
+    if not ref_harness.available():
+        return None
+    try:
+        out = subprocess.run([sys.executable, "-c", REF_CHILD % ROOT, scene_path, str(width), str(height), str(cores)],
+                             cwd=ROOT, capture_output=True, text=True, timeout=180)
+        sec = [float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith("REF_PASS1_SECONDS")]
+        if out.returncode != 0 or not sec:
+            return None
+    except Exception:
+        return None
+    fb = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
+    gpu_scene.set_row_ownership(0, 1, 0, False)
+    gpu_scene.counters_enable(True)
+    gpu_scene.counters_reset()
+    gpu_scene.render_pass1(fb)
+    rays = int(gpu_scene.counters()[0])
+    gpu_scene.counters_enable(False)
+    return {"value": round(rays / sec[0] / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "reference",
+            "sample": "pass 1 (Scene::launchWorkers, nWorkers = %d) of the whole %dx%d frame by the reference itself: %d rays in %.1f s"
+                      % (cores, width, height, rays, sec[0])}
+
+
 def cpu_baseline(scene_path, width, height, gpu_scene, target_s=15.0):
     """Oracle (CPU restatement: same exhaustive BVH walk, thread per 128x128 tile, all host cores) on a bounded
     sample of the SAME frame: 32-row bands spread evenly over the image, as many as fit ~target_s seconds
     (the whole frame when the host is fast enough).  The rays of the sampled rows are counted by the
     instrumented GPU kernel (tests/test_gpu_parity.py proves those counts identical to the oracle's)."""
+    cores = os.cpu_count() or 1
+    ref = reference_baseline(scene_path, width, height, gpu_scene, cores) if os.environ.get("BENCH_CPU_BASELINE", "reference") == "reference" else None
+    if ref is not None:
+        return ref
     from oracle import oracle as O
     o = O.OracleScene(scene_path, width, height)
     band = 32
