@@ -42,20 +42,25 @@ struct LeafPair {
 };
 static_assert(sizeof(LeafPair) == 80, "pair record = s_load_dwordx16 + s_load_dwordx4");
 
-// Every leaf's pairs are preceded by one header of the same size (one s_load_dwordx16); leaves with more than
-// kChunkTris references additionally carry one header in front of every chunk of kChunkTris references
-// ([leaf header] { [chunk header] kChunkTris/2 pairs }...), because large leaves mix orientations and rarely certify as a whole.  It lets a wave skip the
-// whole leaf for a ray when the reference is CERTAIN to reject every triangle of the leaf -- skipping is then
-// exact.  Two certificates, both with rigorous fp32 rounding-error bounds (derivation: DESIGN.md section 3.3):
+// Certificate headers (one pair slot, fetched with one s_load_dwordx16).  Leaf layout in the pair array:
+//   n <= kChunkTris:  [leaf header] pairs
+//   n <= kGroupTris:  [leaf header] { [chunk header] kChunkTris/2 pairs }...
+//   larger:           [leaf header] { [group header] { [chunk header] kChunkTris/2 pairs }... }...   (pad[0] of a group
+//                     header = pair slots of the group, what a wave jumps over)
+// A header lets a wave skip all its references for a ray when the reference is CERTAIN to reject every one of them
+// -- skipping is then exact.  Three certificates, all with rigorous fp32 rounding-error bounds (derivation:
+// DESIGN.md section 3.3):
 //   (1) back-face:  det = v0v1 . (dir x v0v2) = dir . m with m = v0v2 x v0v1.  [mlo, mhi] bounds m component-wise
-//       over the leaf, so U = sum_i max(dir_i*mlo_i, dir_i*mhi_i) >= det_exact and L = sum_i min(..) <= det_exact.
+//       over the range, so U = sum_i max(dir_i*mlo_i, dir_i*mhi_i) >= det_exact and L = sum_i min(..) <= det_exact.
 //       `err` (per unit of max|dir_i|) bounds the reference's rounding error of det plus the error of evaluating
 //       U / L in fp32.  U < -err*dmax  =>  det_computed < 0 < 1e-8 for every triangle (objects.cpp:75-77, culling on).
 //   (2) behind the origin:  if every triangle certainly faces the ray (L >= 4*err*dmax, so det >= g = L - 2*err*dmax)
-//       and the leaf's true AABB [blo, bhi] lies behind the ray origin by more than the error budget
+//       and the range's true AABB [blo, bhi] lies behind the ray origin by more than the error budget
 //       (-boxdot * g > dmax^2 * (Dinf*a1 + a2)), then any triangle that passes the reference's det / u / v tests gets
 //       a computed t < 0 and is rejected by objects.cpp:91.  (The reference's box test has no t range, so e.g. every
 //       shadow ray leaving the mesh walks all the leaves behind it.)
+//   (3) missed:  same g; the exact plane hit of any accepted triangle lies within rho <= 2*dmax*(Dinf*a1 + a2)/g of the
+//       triangle, so a ray LINE that misses [blo - rho, bhi + rho] cannot be accepted by any triangle of the range.
 struct LeafHeader {
 	float m[3][2];     // (mlo_i, mhi_i): interval of m = v0v2 x v0v1, an operand pair of the packed instructions
 	float err;
