@@ -195,7 +195,7 @@ struct rtx_scene {
 	Params params;                // template of the kernel argument block
 	bool stats = false;
 	// lazily sized work buffers
-	float* frames = nullptr; size_t framesBytes = 0;
+	float* frames = nullptr; size_t framesBytes = 0, framesArea = 0;
 	uint32_t* tileCost = nullptr; uint32_t* items = nullptr; size_t tileCap = 0;   // per-tile pass-1 cost, SSAA scan array (2 tiles + 1, then scan scratch)
 	uint32_t* ssaaPixels = nullptr; size_t ssaaPixCap = 0;                         // SSAA flagged-pixel list (<= W * H entries)
 	uint32_t* work = nullptr;     // [0] pass-1 queue head, [1] ssaa queue head, [3] probe queue head
@@ -203,9 +203,14 @@ struct rtx_scene {
 	int blocksPass1 = 0, blocksSsaa = 0;
 	// pass-1 tile queues (buildTileList): rebuilt when the view, the row range or the row ownership changes
 	std::vector<float> meshBounds;        // 6 floats per mesh: the root box
-	uint32_t* tileList = nullptr; size_t tileListCap = 0;   // [0, cap): queues in geometric order, [cap, 2 cap): ordered by cost
-	bool costValid = false;               // tileCost holds the costs of a launch with the current tileKey
-	std::vector<uint32_t> tileKey;        // what the current list was built for
+	struct TileQueues {
+		std::vector<uint32_t> key;        // what the list was built for (view, row range, row ownership)
+		uint32_t* list = nullptr; size_t cap = 0;   // [0, cap): queues in geometric order, [cap, 2 cap): ordered by cost
+		bool costValid = false;           // tileCost holds the costs of a launch with this key
+		uint64_t lastUse = 0;
+	};
+	std::vector<TileQueues> tileQueues;   // a few entries: a frame may be rendered in several row ranges
+	uint64_t tileUse = 0;
 	// HIP-event pairs around every launch of {pass 1, sobel, ssaa} since the last rtx_kernel_time_reset
 	std::vector<hipEvent_t> evPool[3];
 	size_t evUsed[3] = { 0, 0, 0 };
@@ -247,7 +252,10 @@ int ensureWork(rtx_scene* s)
 	const int blocks = s->blocksPass1 > s->blocksSsaa ? s->blocksPass1 : s->blocksSsaa;
 	const uint32_t totalLanes = (uint32_t)blocks * 256u;
 	const int slots = s->params.view.maxDepth + 2;
-	const size_t need = (size_t)(slots < 1 ? 1 : slots) * kFrameFields * sizeof(float) * totalLanes;
+	// two areas: pass-1 launches use the first, SSAA launches the second (the two may run concurrently on two streams)
+	const size_t area = (size_t)(slots < 1 ? 1 : slots) * kFrameFields * sizeof(float) * totalLanes;
+	const size_t need = 2 * area;
+	s->framesArea = area / sizeof(float);
 	if (need > s->framesBytes) {
 		if (s->frames) HIPCHK(hipFree(s->frames));
 		s->frames = nullptr; s->framesBytes = 0;
@@ -448,7 +456,7 @@ void rtx_scene_destroy(rtx_scene* s)
 	for (void* p : s->owned) (void)hipFree(p);
 	if (s->frames) (void)hipFree(s->frames);
 	if (s->tileCost) { (void)hipFree(s->tileCost); (void)hipFree(s->items); }
-	if (s->tileList) (void)hipFree(s->tileList);
+	for (auto& q : s->tileQueues) if (q.list) (void)hipFree(q.list);
 	if (s->ssaaPixels) (void)hipFree(s->ssaaPixels);
 	if (s->work) {
 		(void)hipFree(s->work); (void)hipFree(s->counters);
@@ -495,15 +503,20 @@ void meshTileRect(const rtx_scene* s, uint32_t tilesX, uint32_t tilesYFull, uint
 }
 
 // The eight per-XCD queues of one pass-1 launch.  Only tiles with a row this launch renders are listed.
-int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t tilesX, uint32_t tileRow0, uint32_t tilesY)
+int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t tilesX, uint32_t tileRow0, uint32_t tilesY, rtx_scene::TileQueues** out)
 {
 	const Params& p = s->params;
 	std::vector<uint32_t> key = { rowBegin, lastRow, tilesX, p.bandH, p.nParts, p.part, p.halo, p.view.width, p.view.height };
 	for (int i = 0; i < 16; i++) { uint32_t w; memcpy(&w, &p.view.camM[i], 4); key.push_back(w); }
 	for (int i = 0; i < 3; i++) { uint32_t w; memcpy(&w, &p.view.camPos[i], 4); key.push_back(w); }
 	{ uint32_t w; memcpy(&w, &p.view.scale, 4); key.push_back(w); memcpy(&w, &p.view.aspect, 4); key.push_back(w); }
-	if (s->tileList && key == s->tileKey) return RTX_OK;
-	s->costValid = false;
+	for (auto& q : s->tileQueues)
+		if (q.list && q.key == key) { q.lastUse = ++s->tileUse; *out = &q; return RTX_OK; }
+	// new entry (the least recently used one is recycled once there are 16)
+	if (s->tileQueues.size() < 16) s->tileQueues.emplace_back();
+	rtx_scene::TileQueues* e = &s->tileQueues[0];
+	for (auto& q : s->tileQueues) { if (!q.list) { e = &q; break; } if (q.lastUse < e->lastUse) e = &q; }
+	e->costValid = false; e->key.clear();
 	const uint32_t H = p.view.height;
 	auto rowOwnedH = [&](uint32_t y) { return p.bandH == 0 || (y / p.bandH) % p.nParts == p.part; };
 	auto rowRenderedH = [&](uint32_t y) {
@@ -530,15 +543,17 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 		list.insert(list.end(), q[x][0].begin(), q[x][0].end());
 		list.insert(list.end(), q[x][1].begin(), q[x][1].end());
 	}
-	if (list.size() > s->tileListCap) {
-		if (s->tileList) HIPCHK(hipFree(s->tileList));
-		s->tileList = nullptr; s->tileListCap = 0;
-		HIPCHK(hipMalloc((void**)&s->tileList, 2 * list.size() * sizeof(uint32_t)));
-		s->tileListCap = list.size();
+	HIPCHK(hipDeviceSynchronize());      // an earlier launch may still be reading the list that is recycled
+	if (list.size() > e->cap) {
+		if (e->list) HIPCHK(hipFree(e->list));
+		e->list = nullptr; e->cap = 0;
+		HIPCHK(hipMalloc((void**)&e->list, 2 * list.size() * sizeof(uint32_t)));
+		e->cap = list.size();
 	}
-	HIPCHK(hipDeviceSynchronize());      // an earlier launch may still be reading the old list
-	HIPCHK(hipMemcpy(s->tileList, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	s->tileKey = key;
+	HIPCHK(hipMemcpy(e->list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	e->key = key;
+	e->lastUse = ++s->tileUse;
+	*out = e;
 	return RTX_OK;
 }
 
@@ -565,14 +580,15 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	p.tilesY = tilesY;
 	p.workCounter = s->work + 128;            // eight per-XCD queue heads, 64 bytes apart
 	if (p.view.width > 0x7fff8u || p.view.height > 0x7fff8u) return fail(RTX_ERR_ARG, "frame too large");
-	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY))) return rc;
-	p.tileList = s->tileList;
-	if (s->costValid) {
+	rtx_scene::TileQueues* tq = nullptr;
+	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY, &tq))) return rc;
+	p.tileList = tq->list;
+	if (tq->costValid) {
 		// the previous launch rendered exactly these tiles from this view: start with the ones that were expensive
-		hipLaunchKernelGGL(rtxTileOrderKernel, dim3(8), dim3(1024), 0, st, s->tileList, s->tileCost, s->params.tilesXFull, s->tileList + s->tileListCap);
-		p.tileList = s->tileList + s->tileListCap;
+		hipLaunchKernelGGL(rtxTileOrderKernel, dim3(8), dim3(1024), 0, st, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap);
+		p.tileList = tq->list + tq->cap;
 	}
-	s->costValid = true;
+	tq->costValid = true;
 	HIPCHK(hipMemsetAsync(s->work + 128, 0, 128 * sizeof(uint32_t), st));
 	uint32_t blocks = (uint32_t)s->blocksPass1;
 	const uint32_t wavesNeeded = (p.nTiles + 3) / 4;
@@ -621,6 +637,7 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	p.rowBegin = rowBegin; p.rowEnd = rowEnd;
 	p.nTiles = (uint32_t)s->tileCap >= p.tilesXFull * ((H + 7) / 8) ? p.tilesXFull * ((H + 7) / 8) : 0;
 	p.ssaaScan = s->items;
+	p.frames = s->frames + s->framesArea;
 	p.ssaaPixels = s->ssaaPixels;
 	if (p.nTiles == 0 || p.view.width > 0xffffu || p.view.height > 0xffffu) return fail(RTX_ERR_ARG, "frame too large for the SSAA pixel list");
 	// flagged pixels -> one packed list; tiles on which pass 1 spent more than 0.25 ms go first (wall clock = 100 MHz)
