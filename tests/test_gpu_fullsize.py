@@ -122,6 +122,31 @@ def test_ragged_sizes_and_row_ranges(ra, oracle, torch_cuda):
     assert not got[:50].any() and not got[60:].any() and np.array_equal(bits(ref[50:60]), bits(got[50:60]))
 
 
+@pytest.mark.parametrize("name,w,h,edges", [("cfg2_smooth_4k", 316, 203, (0, 37, 38, 120, 203)), ("cfg3_reflective_refractive", 480, 272, (0, 64, 200, 272))])
+def test_frame_in_row_bands_with_ssaa_equals_whole_frame(ra, oracle, torch_cuda, name, w, h, edges):
+    """The whole path (pass 1, Sobel, SSAA) run band by band through the row-range arguments gives the reference's frame,
+    provided every mask row is computed before any of the three framebuffer rows it reads is re-rendered: band k's
+    pass 1 runs two rows into band k+1, its Sobel covers rows up to the first row of band k+1, its SSAA only its own
+    rows (the scheme of tools/research/pipeline_exp.py)."""
+    torch = torch_cuda
+    g = ra.Scene("scenes/%s.scene" % name, w, h)
+    o = oracle.OracleScene("scenes/%s.scene" % name, w, h)
+    ref = o.ssaa(o.pass1())
+    fb = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    mask = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+    done = 0
+    for k in range(len(edges) - 1):
+        a, b = edges[k], edges[k + 1]
+        p_end = min(b + 2, h)
+        if p_end > done:
+            g.render_pass1(fb, rows=(done, p_end))
+            done = p_end
+        g.sobel(fb, mask, rows=(a + (1 if k else 0), min(b + 1, h)))
+        g.render_ssaa(mask, fb, rows=(a, b))
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(ref), bits(fb.cpu().numpy()))
+
+
 def test_error_paths(ra):
     import ctypes as C
     rtx, _ = ra.load()
