@@ -98,42 +98,62 @@ __global__ void bisectStepKernel(BNode* nodes, uint32_t n, uint32_t* unfinished)
 	atomicAdd(unfinished, 1u);
 }
 
-// Counting pass: one thread per id of the level.  Lanes of a wave that belong to the same node are reduced with
-// ballots and added with one atomic per counter.
-__global__ void countKernel(BNode* nodes, const uint32_t* __restrict__ owner, const uint32_t* __restrict__ ids, uint32_t total,
-                            const float* __restrict__ ext, uint32_t nTris)
+// Counting pass over the ids of the level.  A block covers 256 * perThread consecutive ids (coalesced; perThread grows
+// with the level's size, so that big levels have few blocks per node).
+// Ids of the node the block STARTS in are counted in registers and reduced once per block (wave shuffles, LDS, one
+// atomic per counter) -- at the top of the tree, where a few nodes own all ids, this replaces thousands of atomics
+// on the same four words; ids of other nodes (deep levels: many small nodes per block) are reduced per wave segment
+// with ballots and added with one atomic per (wave, node, counter).
+__global__ void __launch_bounds__(256) countKernel(BNode* nodes, const uint32_t* __restrict__ owner, const uint32_t* __restrict__ ids, uint32_t total,
+                                                   const float* __restrict__ ext, uint32_t nTris, uint32_t perThread)
 {
-	const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-	bool active = false;
-	uint32_t node = 0;
-	bool p0 = false, p1 = false, p2 = false, p3 = false;
-	if (e < total) {
-		node = owner[e];
-		const BNode& nd = nodes[node];
-		const uint32_t st = nd.state;
-		if (st == kActive || st == kFinalCount) {
-			active = true;
-			const uint32_t id = ids[e];
-			const float l = ext[(size_t)(2 * nd.axis) * nTris + id], h = ext[(size_t)(2 * nd.axis + 1) * nTris + id];
-			p0 = l <= nd.s1; p1 = h >= nd.s1; p2 = l <= nd.s2; p3 = h >= nd.s2;
+	__shared__ uint32_t part[4][4];
+	const uint32_t base = blockIdx.x * 256 * perThread;
+	const uint32_t home = owner[base];                    // base < total by construction of the grid
+	const int lane = (int)__lane_id();
+	uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+	for (uint32_t k = 0; k < perThread; k++) {
+		const uint32_t e = base + k * 256 + threadIdx.x;
+		bool active = false;
+		uint32_t node = 0;
+		bool p0 = false, p1 = false, p2 = false, p3 = false;
+		if (e < total) {
+			node = owner[e];
+			const BNode& nd = nodes[node];
+			const uint32_t st = nd.state;
+			if (st == kActive || st == kFinalCount) {
+				active = true;
+				const uint32_t id = ids[e];
+				const float l = ext[(size_t)(2 * nd.axis) * nTris + id], h = ext[(size_t)(2 * nd.axis + 1) * nTris + id];
+				p0 = l <= nd.s1; p1 = h >= nd.s1; p2 = l <= nd.s2; p3 = h >= nd.s2;
+			}
+		}
+		if (active && node == home) { h0 += p0; h1 += p1; h2 += p2; h3 += p3; active = false; }
+		unsigned long long todo = __ballot(active);
+		while (todo) {
+			const int leader = __builtin_ctzll(todo);
+			const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)node, leader);
+			const bool mine = active && node == ln;
+			const unsigned long long same = __ballot(mine);
+			const uint32_t c0 = (uint32_t)__popcll(__ballot(mine && p0)), c1 = (uint32_t)__popcll(__ballot(mine && p1));
+			const uint32_t c2 = (uint32_t)__popcll(__ballot(mine && p2)), c3 = (uint32_t)__popcll(__ballot(mine && p3));
+			if (lane == leader) {
+				BNode& nd = nodes[ln];
+				if (c0) atomicAdd(&nd.cnt[0], c0);
+				if (c1) atomicAdd(&nd.cnt[1], c1);
+				if (nd.state == kActive) { if (c2) atomicAdd(&nd.cnt[2], c2); if (c3) atomicAdd(&nd.cnt[3], c3); }
+			}
+			todo &= ~same;
 		}
 	}
-	unsigned long long todo = __ballot(active);
-	const int lane = (int)__lane_id();
-	while (todo) {
-		const int leader = __builtin_ctzll(todo);
-		const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)node, leader);
-		const bool mine = active && node == ln;
-		const unsigned long long same = __ballot(mine);
-		const uint32_t c0 = (uint32_t)__popcll(__ballot(mine && p0)), c1 = (uint32_t)__popcll(__ballot(mine && p1));
-		const uint32_t c2 = (uint32_t)__popcll(__ballot(mine && p2)), c3 = (uint32_t)__popcll(__ballot(mine && p3));
-		if (lane == leader) {
-			BNode& nd = nodes[ln];
-			if (c0) atomicAdd(&nd.cnt[0], c0);
-			if (c1) atomicAdd(&nd.cnt[1], c1);
-			if (nd.state == kActive) { if (c2) atomicAdd(&nd.cnt[2], c2); if (c3) atomicAdd(&nd.cnt[3], c3); }
-		}
-		todo &= ~same;
+	// the home node's counts: wave reduction, then across the four waves
+	for (int d = 32; d >= 1; d >>= 1) { h0 += __shfl_down(h0, d, 64); h1 += __shfl_down(h1, d, 64); h2 += __shfl_down(h2, d, 64); h3 += __shfl_down(h3, d, 64); }
+	if (lane == 0) { uint32_t* q = part[threadIdx.x >> 6]; q[0] = h0; q[1] = h1; q[2] = h2; q[3] = h3; }
+	__syncthreads();
+	if (threadIdx.x < 4) {
+		const uint32_t c = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+		BNode& nd = nodes[home];
+		if (c && (threadIdx.x < 2 || nd.state == kActive)) atomicAdd(&nd.cnt[threadIdx.x], c);
 	}
 }
 
@@ -391,6 +411,7 @@ int rtx_bvh_build(const float* tri_pos, uint32_t n_tris, const float* root_lo, c
 		if (depth > 4096) return fail(RTX_ERR_ARG, "acceleration structure deeper than 4096 levels");
 		BvhLevel& L = levels.back();
 		const unsigned gN = gridFor(L.n), gE = gridFor(L.total);
+		const uint32_t perThread = std::min<uint32_t>(16u, std::max<uint32_t>(1u, L.total >> 16));
 		hipLaunchKernelGGL(levelInitKernel, dim3(gN), dim3(256), 0, st, L.nodes, L.n, depth, ac_penalty);
 		launches++;
 		// `steps` bisection steps, each followed by its counting pass; step k reports in dFlags[k] how many nodes were
@@ -401,7 +422,7 @@ int rtx_bvh_build(const float* tri_pos, uint32_t n_tris, const float* root_lo, c
 			HIPCHK(hipMemsetAsync(dFlags, 0, kMaxSteps * 4, st));
 			for (int k = 0; k < steps; k++) {
 				hipLaunchKernelGGL(bisectStepKernel, dim3(gN), dim3(256), 0, st, L.nodes, L.n, dFlags + k);
-				if (L.total) hipLaunchKernelGGL(countKernel, dim3(gE), dim3(256), 0, st, L.nodes, L.owner, L.ids, L.total, dExt, n_tris);
+				if (L.total) hipLaunchKernelGGL(countKernel, dim3(gridFor(L.total, 256 * perThread)), dim3(256), 0, st, L.nodes, L.owner, L.ids, L.total, dExt, n_tris, perThread);
 				launches += 2;
 			}
 			uint32_t busy[kMaxSteps];
