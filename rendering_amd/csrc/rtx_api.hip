@@ -198,7 +198,7 @@ struct rtx_scene {
 	float* frames = nullptr; size_t framesBytes = 0, framesArea = 0;
 	uint32_t* tileCost = nullptr; uint32_t* items = nullptr; size_t tileCap = 0;   // per-tile pass-1 cost, SSAA scan array (2 tiles + 1, then scan scratch)
 	uint32_t* ssaaPixels = nullptr; size_t ssaaPixCap = 0;                         // SSAA flagged-pixel list (<= W * H entries)
-	uint32_t* work = nullptr;     // [0] pass-1 queue head, [1] ssaa queue head, [3] probe queue head
+	uint32_t* work = nullptr;     // 256 words: [1] SSAA queue head, [3] probe queue head, [8] SSAA list mode, [9] flagged pixels, [128 + 16 q] pass-1 queue head of XCD q
 	unsigned long long* counters = nullptr;
 	int blocksPass1 = 0, blocksSsaa = 0;
 	// pass-1 tile queues (buildTileList): rebuilt when the view, the row range or the row ownership changes
