@@ -5,6 +5,8 @@ One "step" = one frame of the hot path = Scene::launchWorkers (pass 1) + Scene::
 adaptive 4-ray pass) on synthetic input (scenes/cfg2_smooth_250k.scene, generated mesh), scene resident in HBM,
 framebuffer resident in HBM.  A ray = one Render::trace invocation (stats::raysCasted): primary, shadow,
 reflect/refract and SSAA rays; rays/frame is counted once by the instrumented kernel variant (deterministic).
+Of these, `moot_shadow_rays` are shadow rays whose answer cannot influence the pixel (Diffuse surface turned away from
+the light: vis * max(0, N.-L) is +0 either way); the timed kernels do not walk them, the frame is bit-identical.
 N > 1: rows are dealt to the ranks in 64-row bands, every frame ends with an RCCL gather to rank 0 (strong
 scaling of the same frame).  Prints ONE JSON line on rank 0.
 """
@@ -180,6 +182,7 @@ def main():
     scene.counters_reset()
     scene.render_pass1(fb)
     c1 = scene.counters()                       # pass 1, this rank's rows
+    moot = scene.moot_rays
     scene.counters_enable(False)
     parallel.shard_frame(scene, fb, mask, world, rank, ssaa=False)      # proper framebuffer (with halo rows) for the mask
     scene.counters_enable(True)
@@ -188,10 +191,11 @@ def main():
         scene.sobel(fb, mask)
         scene.render_ssaa(mask, fb)
         c2 = scene.counters()
+        moot += scene.moot_rays
     else:
         c2 = np.zeros(3, np.int64)
     scene.counters_enable(False)
-    tot = torch.tensor([int(x) for x in (c1 + c2)], dtype=torch.int64, device="cuda")
+    tot = torch.tensor([int(x) for x in (c1 + c2)] + [moot], dtype=torch.int64, device="cuda")
     if world > 1:
         dist.all_reduce(tot)
     rays_per_frame = int(tot[0])
@@ -227,7 +231,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s @%dx%d, pass 1%s" % (os.path.basename(args.scene), W, H, " + Sobel-adaptive SSAA" if ssaa else ""),
-                   "rays_per_frame": rays_per_frame, "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.BAND, world, ", BGR8 bands sent to rank 0 over RCCL" if world > 1 else ""),
+                   "rays_per_frame": rays_per_frame, "moot_shadow_rays": int(tot[3]), "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.BAND, world, ", BGR8 bands sent to rank 0 over RCCL" if world > 1 else ""),
                    "pass1_ms": round(avg_ms, 3), "ssaa_ms": round(ms2 / max(n2, 1), 3),
                    "pass1_rays_rank0": int(c1[0]), "ssaa_rays_rank0": int(c2[0]), "ssaa_pixels_rank0": int(mask.sum()),
                    "ssaa_box_tests": int(c2[1]), "ssaa_tri_tests": int(c2[2])},

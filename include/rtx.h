@@ -120,6 +120,8 @@ typedef struct rtx_counters {
 	uint64_t rays;      /* Render::trace invocations (stats::raysCasted) */
 	uint64_t box_tests; /* AccelerationStructure::intersectBox calls (stats::accelStructTests) */
 	uint64_t tri_tests; /* Triangle::rayTriangleIntersect calls (stats::rayTriTests) */
+	uint64_t moot_rays; /* of `rays`: shadow rays whose answer cannot influence the pixel (Diffuse material, N . -L <= 0:
+	                       vis * max(0, N . -L) is +0 either way, scene.cpp:788); only the instrumented variant traces them */
 } rtx_counters;
 
 typedef struct rtx_scene rtx_scene;

@@ -25,7 +25,7 @@ class RtxError(RuntimeError):
 
 
 class Counters(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64)]
+    _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("moot_rays", C.c_uint64)]
 
 
 _rtx = None
@@ -302,6 +302,7 @@ class Scene:
     def counters(self):
         c = Counters()
         _check(self.rtx.rtx_counters_read(self.gpu(), C.byref(c)), "rtx_counters_read")
+        self.moot_rays = int(c.moot_rays)      # shadow rays that cannot influence the pixel (only the instrumented variant traces them)
         return np.array([c.rays, c.box_tests, c.tri_tests], np.int64)
 
     def last_kernel_ms(self, which=0):

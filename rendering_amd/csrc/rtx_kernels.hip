@@ -292,7 +292,7 @@ struct Hit { int obj; float t; uint32_t tri; float u, v; };
 __device__ unsigned long long gDbgWave[3 * 16384];   // per wave of the last pass 1: first pop, last tile end, busy ticks
 __device__ unsigned long long gDbgHist[64];   // [0,8) certificate outcomes (one sampled lane per evaluation), [16,64) by log2(leaf size)
 #endif
-struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips, wChunks, wChunkSkips, triLanes; };
+struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips, wChunks, wChunkSkips, triLanes, moot; };
 
 // Ordering of scalar loads.  SMEM returns out of order, so lgkmcnt can only be waited down to zero: a load issued
 // before the first use of the previous one is covered by the same wait and nothing overlaps.  after(x, v) is an
@@ -638,6 +638,7 @@ struct Lane {
 	uint32_t li, si;
 	// pending trace request
 	V3 qo, qd; float qtmax; bool qshadow;
+	bool qmoot;                   // the pending shadow ray cannot influence the pixel (see advance)
 };
 
 __device__ __forceinline__ float& frameAt(const Params& P, uint32_t gl, int slot, int field)
@@ -741,6 +742,10 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 				dist = length(L);
 				s.L = normalized(L);
 			}
+			// Diffuse (scene.cpp:780-809): the only use of the shadow ray is  vis * max(0, N . -L)  with vis in {0, 1}.  When
+			// the max is +0 (surface turned away from the light, or NaN) the product is the same +0 for either answer: the
+			// ray cannot influence the pixel ("moot"), and the product kernels do not walk it (castRayWave).
+			s.qmoot = s.mat == 0 && fmaxRef(0.f, dot(s.N, -s.L)) == 0.f;
 			s.qo = s.P + s.N * bias; s.qd = -s.L; s.qtmax = dist; s.qshadow = true;               // scene.cpp:787
 			s.state = ST_WAIT_SHADOW;
 			return;
@@ -870,11 +875,15 @@ __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 
 	s.obj = 0; s.mat = 0; s.li = 0; s.si = 0;
 	s.P = s.N = s.objColor = s.diff = s.spec = s.L = s.I = mk(0, 0, 0);
 	s.specCoef = s.nSpec = s.dsum = s.ssum = 0;
-	s.qo = o; s.qd = d; s.qtmax = kFltMax; s.qshadow = false;
+	s.qo = o; s.qd = d; s.qtmax = kFltMax; s.qshadow = false; s.qmoot = false;
 	advance(P, s, gl);
 	while (ballot(s.state != ST_DONE) != 0) {
 		Hit h;
-		traceWave<STATS>(P, s.state != ST_DONE, s.qshadow, s.qo, s.qd, s.qtmax, h, cnt);
+		// moot shadow rays (see advance): only the instrumented variant walks them -- the reference's statistics count
+		// them; here the lane just sits the trace out and consumes "not occluded", which gives the same +0 product
+		const bool moot = s.state == ST_WAIT_SHADOW && s.qmoot;
+		if (STATS) cnt.moot += __popcll(ballot(moot));
+		traceWave<STATS>(P, s.state != ST_DONE && (STATS || !moot), s.qshadow, s.qo, s.qd, s.qtmax, h, cnt);
 		if (s.state != ST_DONE) {
 			consume(P, s, h);
 			advance(P, s, gl);
@@ -914,6 +923,7 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 		atomicAdd(P.counters + 8, c.wS3); atomicAdd(P.counters + 9, c.wS4);
 		atomicAdd(P.counters + 10, c.wLeaves); atomicAdd(P.counters + 11, c.wLeafSkips);
 		atomicAdd(P.counters + 12, c.wChunks); atomicAdd(P.counters + 13, c.wChunkSkips); atomicAdd(P.counters + 14, c.triLanes);
+		atomicAdd(P.counters + 15, c.moot);
 	}
 }
 
