@@ -18,4 +18,4 @@ for part in range(N):
     p1, ss = g.last_kernel_ms(0), g.last_kernel_ms(2)
     worst = max(worst, p1 + ss)
     print("part %d/%d: pass 1 %.3f ms, SSAA %.3f ms" % (part, N, p1, ss))
-print("slowest part %.3f ms  (1 GPU: ~16.8 ms of kernels -> ideal %.2f ms)" % (worst, 16.8 / N))
+print("slowest part %.3f ms  (1 GPU: ~15.4 ms of kernels -> ideal %.2f ms)" % (worst, 15.4 / N))
