@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ssaa", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="N > 1: rank 0 also renders the whole frame alone and compares the gathered image with it")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -141,10 +142,18 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    # BENCH_DIST_BACKEND=gloo is a functional check of the N > 1 flow on a box with fewer GPUs than ranks: the ranks share
+    # the devices and the exchange is staged through host memory (not a measurement; see --verify)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    rdev = "cuda" if backend == "nccl" else "cpu"          # where the small reductions live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from rendering_amd import assets, parallel
     import rendering_amd as RA
@@ -166,7 +175,12 @@ def main():
             # the frame has to end up in ONE place: quantise to the BGR8 image saveImage writes (4x fewer bytes than
             # the fp32 framebuffer) and send every owned band straight into rank 0's image
             scene.quantize(fb, img)
-            parallel.gather_frame(img, world, rank, bottom_up=True)
+            if backend == "nccl":
+                parallel.gather_frame(img, world, rank, bottom_up=True)
+            else:
+                host = img.cpu()
+                parallel.gather_frame(host, world, rank, bottom_up=True)
+                img.copy_(host)
 
     def sync():
         torch.cuda.synchronize()
@@ -195,7 +209,7 @@ def main():
     else:
         c2 = np.zeros(3, np.int64)
     scene.counters_enable(False)
-    tot = torch.tensor([int(x) for x in (c1 + c2)] + [moot], dtype=torch.int64, device="cuda")
+    tot = torch.tensor([int(x) for x in (c1 + c2)] + [moot], dtype=torch.int64, device=rdev)
     if world > 1:
         dist.all_reduce(tot)
     rays_per_frame = int(tot[0])
@@ -209,11 +223,21 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0])
 
+    verified = None
+    if args.verify and world > 1:
+        gathered = img.clone()
+        if rank == 0:
+            parallel.shard_frame(scene, fb, mask, 1, 0, ssaa=ssaa)
+            whole = torch.zeros_like(img)
+            scene.quantize(fb, whole)
+            torch.cuda.synchronize()
+            verified = bool((whole == gathered).all())
+        sync()
     n1, ms1 = scene.kernel_time_stats(0)
     n2, ms2 = scene.kernel_time_stats(2)
     # algorithmic bytes of ONE pass-1 launch: 32 B per box test + 40 B per triangle test counted
@@ -241,6 +265,8 @@ def main():
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "box_tests": int(c1[1]), "tri_tests": int(c1[2])},
     }
+    if verified is not None:
+        out["config"]["gathered_image_equals_single_gpu_image"] = verified
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.scene, W, H, scene)
     if rank == 0:
