@@ -121,6 +121,18 @@ def measured_traffic():
         return None
 
 
+def valu_issue(avg_ms):
+    """Fraction of the VALU issue rate (the kernel's real bound) the pass-1 launch achieves: VALU
+    wave-instructions per launch (SQ_INSTS_VALU of a separate rocprofv3 --pmc run of this command, committed under
+    profiles/) over what 1024 SIMDs issue in the measured duration at one instruction per 4 cycles, 2.4 GHz."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pass1_traffic.json")))
+        n = float(d["SQ_INSTS_VALU_per_launch"])
+        return {"instructions_per_launch": n, "peak_per_s": 1024 * 2.4e9 / 4, "frac": round(n / (avg_ms * 1e-3) / (1024 * 2.4e9 / 4), 4)}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,7 +275,8 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
                      "kernel": "rtxPass1Kernel", "avg_launch_ms": round(avg_ms, 3),
                      "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "box_tests": int(c1[1]), "tri_tests": int(c1[2])},
+                     "box_tests": int(c1[1]), "tri_tests": int(c1[2]),
+                     "valu_issue": valu_issue(avg_ms) if world == 1 else None},
     }
     if verified is not None:
         out["config"]["gathered_image_equals_single_gpu_image"] = verified
