@@ -1,0 +1,75 @@
+"""GPU: random small scenes (every object type, material and light type, random camera, culling on / off, random
+penalties and recursion depths) rendered by the HIP path and by the oracle: bit-exact pass-1 and post-SSAA frames and
+per-ray records.  Deterministic seeds; the scenes are written to a temporary directory."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def v3(r, lo, hi):
+    return ",".join("%.3f" % r.uniform(lo, hi) for _ in range(3))
+
+
+def material(r):
+    k = r.randrange(5)
+    if k == 0:
+        return ""                                    # diffuse (default)
+    if k == 1:
+        return "material=reflective\n"
+    if k == 2:
+        return "material=transparent,%.2f\n" % r.uniform(1.05, 1.8)
+    return "material=phong,%.2f,%.2f,%.2f,%.1f\n" % (r.uniform(0, 0.5), r.uniform(0, 1), r.uniform(0, 1), r.choice([1, 2, 5, 10, 20, 64]))
+
+
+def make_scene(seed, w, h):
+    r = random.Random(seed)
+    s = "[options]\nwidth=%d\nheight=%d\nfov=%d\nposition=%s\nrotation=%s\nmax_ray_depth=%d\nac_penalty=%d\nuseBackfaceCulling=%d\nbackground_color=%s\nimage_name=output/fuzz\n\n" % (
+        w, h, r.choice([40, 60, 75, 90]), v3(r, -0.5, 0.5), v3(r, -15, 15), r.randrange(0, 5), r.choice([1, 1, 2, 3, 5]), r.randrange(2), v3(r, 0, 0.6))
+    for _ in range(r.randrange(1, 4)):
+        t = r.choice(["point", "point", "distant", "area"])
+        if t == "point":
+            s += "[light]\ntype=point\nposition=%s\ncolor=%s\nintensity=%.2f\n\n" % (v3(r, -3, 3), v3(r, 0, 1), r.uniform(0.1, 2))
+        elif t == "distant":
+            s += "[light]\ntype=distant\ndirection=%s\ncolor=%s\nintensity=%.2f\n\n" % (v3(r, -1, 1), v3(r, 0, 1), r.uniform(0.1, 1))
+        else:
+            s += "[light]\ntype=area\npos=%s\ni=%s\nj=%s\nsamples=%d\ncolor=%s\nintensity=%.2f\n\n" % (v3(r, -3, 3), v3(r, -1, 1), v3(r, -1, 1), r.randrange(1, 4), v3(r, 0, 1), r.uniform(0.5, 3))
+    for _ in range(r.randrange(2, 6)):
+        t = r.choice(["sphere", "plane", "mesh", "mesh"])
+        if t == "sphere":
+            s += "[object]\ntype=sphere\npos=%s\ncolor=%s\nradius=%.2f\n%s\n" % (",".join("%.3f" % x for x in (r.uniform(-2, 2), r.uniform(-1.5, 1.5), r.uniform(-6, -2))), v3(r, 0.1, 1), r.uniform(0.2, 1.2), material(r))
+        elif t == "plane":
+            s += "[object]\ntype=plane\npos=%s\nnormal=%s\ncolor=%s\n%s\n" % (",".join("%.3f" % x for x in (0, r.uniform(-2.5, -1), r.uniform(-9, -5))), r.choice(["0,1,0", "0,0,1", "0.1,1,0.2"]), v3(r, 0.2, 1), material(r))
+        else:
+            name = r.choice(["bumpy_4k.obj", "torus_1536.obj", "quad.obj", "coincident_4k.obj"])
+            s += "[object]\ntype=mesh\npos=%s\nsize=%s\nrot=%s\ncolor=%s\n%sname=scenes/assets/%s\n\n" % (
+                ",".join("%.3f" % x for x in (r.uniform(-2, 2), r.uniform(-1, 1), r.uniform(-6, -2.5))), v3(r, 0.8, 2.5), v3(r, -40, 40), v3(r, 0.2, 1), material(r), name)
+    return s + "[end]\n"
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_scene_bit_exact(ra, oracle, tmp_path, seed):
+    from tests.util_rays import probe_rays
+    w, h = 96 + 8 * (seed % 3), 72 + 4 * (seed % 5)
+    path = tmp_path / ("fuzz%d.scene" % seed)
+    path.write_text(make_scene(seed, w, h))
+    o = oracle.OracleScene(str(path), w, h)
+    g = ra.Scene(str(path), w, h)
+    ref1 = o.pass1()
+    got1 = g.render_host(ssaa=False)
+    assert np.array_equal(bits(ref1), bits(got1)), "seed %d: pass 1 differs in %d pixels" % (seed, int((bits(ref1) != bits(got1)).any(-1).sum()))
+    ref2 = o.ssaa(ref1)
+    got2 = g.render_host(ssaa=True)
+    assert np.array_equal(bits(ref2), bits(got2)), "seed %d: post-SSAA frame differs" % seed
+    rays = probe_rays(512)
+    rh, rc = o.probe(rays)
+    gh, gc = g.cast_rays(rays)
+    assert np.array_equal(bits(rh), bits(gh)) and np.array_equal(bits(rc), bits(gc)), "seed %d: probe rays differ" % seed

@@ -61,3 +61,39 @@ def test_reference_cli_md5_cfg1():
     assert hashlib.md5(ref).hexdigest() == "0e5f3b78e230e36d9bc9ed8fcdfa6fd3"
     o = O.OracleScene("scenes/cfg1_simple_shapes.scene", 512, 512)
     assert O.encode_bmp(o.ssaa(o.pass1())) == ref
+
+
+FUZZ_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from tools import ref_harness as R
+from oracle import oracle as O
+from tests.util_rays import probe_rays
+path, w, h = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+r = R.RefScene(path, w, h); o = O.OracleScene(path, w, h)
+b = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+fr = r.pass1(); fo = o.pass1()
+assert np.array_equal(b(fr), b(fo)), 'pass1'
+f2r = r.ssaa(fr); f2o = o.ssaa(fo)
+d = (b(f2r) != b(f2o)).any(-1); d[0, :] = False; d[:, 0] = False
+assert not d.any(), 'ssaa'
+rays = probe_rays(512)
+hr, cr = r.probe(rays); ho, co = o.probe(rays)
+assert np.array_equal(b(hr), b(ho)) and np.array_equal(b(cr), b(co)), 'probe'
+print('OK')
+"""
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_oracle_bit_identical_to_reference_on_random_scenes(tmp_path, seed):
+    """The random scenes of tests/test_gpu_fuzz.py (same generator, same seeds): the oracle the GPU is compared with
+    there is itself bit-identical to the real reference on them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_scenes", os.path.join(ROOT, "tests", "test_gpu_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    w, h = 96 + 8 * (seed % 3), 72 + 4 * (seed % 5)
+    path = tmp_path / ("fuzz%d.scene" % seed)
+    path.write_text(fz.make_scene(seed, w, h))
+    out = subprocess.run([sys.executable, "-c", FUZZ_CHILD % ROOT, str(path), str(w), str(h)], cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
