@@ -73,3 +73,25 @@ def test_random_scene_bit_exact(ra, oracle, tmp_path, seed):
     rh, rc = o.probe(rays)
     gh, gc = g.cast_rays(rays)
     assert np.array_equal(bits(rh), bits(gh)) and np.array_equal(bits(rc), bits(gc)), "seed %d: probe rays differ" % seed
+
+
+EDGE_SCENES = {
+    "no_objects": "[options]\nwidth=40\nheight=24\nbackground_color=0.3,0.5,0.7\nimage_name=output/e\n\n[light]\ntype=point\nposition=0,1,0\ncolor=1,1,1\nintensity=1\n\n[end]\n",
+    "no_lights": "[options]\nwidth=40\nheight=24\nimage_name=output/e\n\n[object]\ntype=sphere\npos=0,0,-3\ncolor=1,0.5,0.2\nradius=1\n\n[object]\ntype=mesh\npos=1,0,-4\nsize=1,1,1\ncolor=1,1,1\nname=scenes/assets/bumpy_4k.obj\n\n[end]\n",
+    "tiny_frame": "[options]\nwidth=4\nheight=3\nimage_name=output/e\n\n[light]\ntype=distant\ndirection=0,-1,-1\ncolor=1,1,1\nintensity=1\n\n[object]\ntype=mesh\npos=0,0,-3\nsize=2,2,2\ncolor=1,1,1\nname=scenes/assets/torus_1536.obj\n\n[end]\n",
+    "mesh_behind_camera": "[options]\nwidth=48\nheight=32\nimage_name=output/e\n\n[light]\ntype=point\nposition=0,2,2\ncolor=1,1,1\nintensity=2\n\n[object]\ntype=mesh\npos=0,0,3\nsize=2,2,2\ncolor=1,1,1\nmaterial=reflective\nname=scenes/assets/bumpy_4k.obj\n\n[object]\ntype=plane\npos=0,-1,0\nnormal=0,1,0\ncolor=0.8,0.8,0.8\n\n[end]\n",
+    "depth_zero": "[options]\nwidth=48\nheight=32\nmax_ray_depth=0\nimage_name=output/e\n\n[light]\ntype=point\nposition=0,2,0\ncolor=1,1,1\nintensity=2\n\n[object]\ntype=sphere\npos=0,0,-3\ncolor=1,1,1\nradius=1\nmaterial=reflective\n\n[object]\ntype=sphere\npos=1.5,0,-3\ncolor=1,1,1\nradius=0.5\nmaterial=transparent,1.5\n\n[end]\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(EDGE_SCENES))
+def test_edge_scene_bit_exact(ra, oracle, tmp_path, name):
+    """Empty object / light lists, a 4x3 frame (3x2 rendered pixels), geometry behind the camera, recursion depth 0."""
+    path = tmp_path / (name + ".scene")
+    path.write_text(EDGE_SCENES[name])
+    o = oracle.OracleScene(str(path))
+    g = ra.Scene(str(path))
+    assert (o.width, o.height) == (g.width, g.height)
+    ref = o.ssaa(o.pass1())
+    got = g.render_host(ssaa=True)
+    assert np.array_equal(bits(ref), bits(got))

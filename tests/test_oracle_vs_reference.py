@@ -97,3 +97,20 @@ def test_oracle_bit_identical_to_reference_on_random_scenes(tmp_path, seed):
     path.write_text(fz.make_scene(seed, w, h))
     out = subprocess.run([sys.executable, "-c", FUZZ_CHILD % ROOT, str(path), str(w), str(h)], cwd=ROOT, capture_output=True, text=True)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def _fuzz_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_scenes", os.path.join(ROOT, "tests", "test_gpu_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    return fz
+
+
+@pytest.mark.parametrize("name", ["depth_zero", "mesh_behind_camera", "no_lights", "no_objects", "tiny_frame"])
+def test_oracle_bit_identical_to_reference_on_edge_scenes(tmp_path, name):
+    """Empty object / light lists, a 4x3 frame, geometry behind the camera, recursion depth 0 (tests/test_gpu_fuzz.py)."""
+    path = tmp_path / (name + ".scene")
+    path.write_text(_fuzz_module().EDGE_SCENES[name])
+    out = subprocess.run([sys.executable, "-c", FUZZ_CHILD % ROOT, str(path), "-1", "-1"], cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
