@@ -909,7 +909,16 @@ V3 skyColor(const orc_scene& sc, V3 dir)  // scene.cpp:381-442
 	}
 }
 
-inline int texel(int dim, float coord) { int v = (int)(dim * coord); if (v >= dim) v = dim - 1; return v; }
+// objects.cpp:144-147, 156-159: (int)(dim * coord), clamped on the high side only.  For 0 <= dim*coord < 2^31 this is the
+// reference bit for bit.  Outside that range the reference is undefined (negative index = out-of-bounds read, NaN / huge
+// = UB conversion); the oracle DEFINES those cases: negative or NaN -> texel 0, too large -> dim-1.
+inline int texel(int dim, float coord)
+{
+	const float f = dim * coord;
+	if (f >= (float)dim) return dim - 1;
+	if (!(f >= 0)) return 0;
+	return (int)f;
+}
 
 void surfaceData(const Object& o, V3 P, int tri, V2 uv, V3& N, V2& tex)
 {

@@ -83,8 +83,10 @@ def coincident_obj(nu=48, nv=25):
     return ("\n".join(lines) + "\n").encode()
 
 
-def torus_obj(nu=32, nv=24, R=1.0, r=0.35):
-    """Textured torus, 2*nu*nv triangles, faces `v/vt/vn`, uv in [0,1] (cfg4 stand-in for shotgun.obj)."""
+def torus_obj(nu=32, nv=24, R=1.0, r=0.35, uv=(1.0, 0.0, 1.0, 0.0)):
+    """Textured torus, 2*nu*nv triangles, faces `v/vt/vn`, uv in [0,1] (cfg4 stand-in for shotgun.obj).
+    uv = (su, ou, sv, ov): texture coordinates su*u+ou, sv*v+ov -- values outside [0,1] exercise the texel clamps
+    (negative coordinates are out-of-bounds reads in the reference)."""
     lines = ["# torus nu=%d nv=%d (generated)" % (nu, nv)]
     for j in range(nv + 1):
         for i in range(nu + 1):
@@ -101,7 +103,7 @@ def torus_obj(nu=32, nv=24, R=1.0, r=0.35):
             lines.append("vn %.6f %.6f %.6f" % (np.cos(b) * np.cos(a), np.sin(b), np.cos(b) * np.sin(a)))
     for j in range(nv + 1):
         for i in range(nu + 1):
-            lines.append("vt %.6f %.6f" % (i / nu, j / nv))
+            lines.append("vt %.6f %.6f" % (uv[0] * i / nu + uv[1], uv[2] * j / nv + uv[3]))
     w = nu + 1
     for j in range(nv):
         for i in range(nu):
@@ -178,6 +180,7 @@ _GENERATORS = {
     "bumpy_25k.obj": lambda: bumpy_sphere_obj(160, 81),
     "bumpy_4k.obj": lambda: bumpy_sphere_obj(64, 33),
     "torus_1536.obj": lambda: torus_obj(32, 24),
+    "torus_uvwild.obj": lambda: torus_obj(32, 24, uv=(2.5, -0.75, -1.5, 1.2)),
     "coincident_4k.obj": coincident_obj,
     "quad.obj": quad_poly_obj,
     "diffuse_1024.bmp": lambda: bmp24(diffuse_map(1024)),

@@ -59,3 +59,27 @@ def test_hip_path_matches_reference_golden(ra, name):
         assert list(g["bvh%d_counts" % i]) == [b["n_nodes"], b["n_leaves"], b["n_refs"], b["max_depth"], b["n_tris"]]
         for k in ("bounds", "skip", "leaf_begin", "leaf_count", "refs", "tris"):
             assert sha(b[k]) == str(g["bvh%d_%s_sha1" % (i, k)]), k
+
+
+def test_headline_250k_mesh_matches_reference_digest(ra):
+    """The headline mesh pinned to the REFERENCE directly on the GPU (no oracle in between): device-built acceleration
+    structure sha1s, the 128x128 pass-1 framebuffer sha1 and the 64-bit statistics recorded from oracle/_ref
+    (tests/golden/cfg2_smooth_250k_digest.json, tools/make_golden.py)."""
+    import json
+    from rendering_amd import assets
+    assets.ensure(["bumpy_250k.obj"])
+    d = json.load(open(os.path.join(GOLD, "cfg2_smooth_250k_digest.json")))
+    assert assets.md5("bumpy_250k.obj") == d["asset_md5"]
+    s = ra.Scene("scenes/cfg2_smooth_250k.scene", 128, 128)
+    b = s.bvh(1)
+    assert b["built_on_device"]
+    assert d["counts"] == [b["n_nodes"], b["n_leaves"], b["n_refs"], b["max_depth"], b["n_tris"]]
+    for k, v in d["sha1"].items():
+        assert sha(b[k]) == v, k
+    s.counters_enable(True)
+    s.counters_reset()
+    fb = s.render_host(ssaa=False)
+    st = s.counters()
+    s.counters_enable(False)
+    assert [int(x) for x in st] == d["pass1_128x128_stats"]
+    assert sha(fb) == d["pass1_128x128_sha1"]

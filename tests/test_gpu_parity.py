@@ -20,6 +20,7 @@ BITEXACT = [
     ("cfg4_textured_256", 256, 256),
     ("area_light", 320, 240),
     ("coincident", 320, 240),     # every hit is an exact t tie between two triangles with different normals
+    ("uv_out_of_range", 256, 256),   # texture coordinates < 0 and > 1: both sides clamp to the edge texel
 ]
 
 
