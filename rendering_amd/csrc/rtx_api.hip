@@ -55,135 +55,13 @@ template <typename T> int upload(std::vector<void*>& owned, const T* src, size_t
 namespace {
 
 // (v0, e1, e2, tri) of leaf reference r (objects.cpp:70-71: v0v1 = v1 - v0, v0v2 = v2 - v0)
-struct LeafTri { float e1x, e1y, e1z, e2x, e2y, e2z, v0x, v0y, v0z; uint32_t tri; };
-
-LeafTri makeLeafTri(const rtx_mesh& m, uint32_t ref)
+void makeRef(const rtx_mesh& m, uint32_t ref, RefA& a, RefB& b, RefC& c)
 {
 	const uint32_t t = m.refs[ref];
 	const float* p = m.tri_pos + (size_t)t * 9;
-	LeafTri lt;
-	lt.e1x = p[3] - p[0]; lt.e1y = p[4] - p[1]; lt.e1z = p[5] - p[2];
-	lt.e2x = p[6] - p[0]; lt.e2y = p[7] - p[1]; lt.e2z = p[8] - p[2];
-	lt.v0x = p[0]; lt.v0y = p[1]; lt.v0z = p[2];
-	lt.tri = t;
-	return lt;
-}
-
-// Storage order of the references of one leaf: positions (relative to the leaf's first reference) sorted by the
-// 30-bit Morton code of the triangle centroids, so that consecutive references form compact patches.  Equal codes
-// are stored in DESCENDING reference order on purpose: coincident triangles then always exercise the tie-break that
-// restores the reference's winner (tests/test_gpu_parity.py, scenes/coincident.scene).
-std::vector<uint32_t> leafOrder(const rtx_mesh& m, uint32_t begin, uint32_t count, uint32_t maxOrd, bool& reordered)
-{
-	reordered = false;
-	std::vector<uint32_t> order(count);
-	for (uint32_t i = 0; i < count; i++) order[i] = i;
-	if (count <= kChunkTris || count - 1 > maxOrd) return order;    // one chunk / too long for the position field: reference order
-	std::vector<double> c((size_t)count * 3);
-	double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
-	for (uint32_t i = 0; i < count; i++) {
-		const float* p = m.tri_pos + (size_t)m.refs[begin + i] * 9;
-		for (int a = 0; a < 3; a++) {
-			const double v = ((double)p[a] + (double)p[3 + a] + (double)p[6 + a]) / 3.0;
-			c[(size_t)i * 3 + a] = v;
-			if (v < lo[a]) lo[a] = v;
-			if (v > hi[a]) hi[a] = v;
-		}
-	}
-	const double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
-	if (!(ext > 0) || !std::isfinite(ext)) return order;
-	auto spread = [](uint32_t v) { v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; return (v | (v << 2)) & 0x09249249u; };
-	std::vector<uint32_t> code(count);
-	for (uint32_t i = 0; i < count; i++) {
-		uint32_t q[3];
-		for (int a = 0; a < 3; a++) {
-			const double f = (c[(size_t)i * 3 + a] - lo[a]) / ext * 1023.0;
-			q[a] = f > 0 ? (f < 1023 ? (uint32_t)f : 1023u) : 0u;
-		}
-		code[i] = spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2;
-	}
-	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return code[a] != code[b] ? code[a] < code[b] : a > b; });
-	reordered = true;
-	return order;
-}
-
-// pairs of the references begin + order[k0 .. k0+count)
-// (triBits == 32: the leaf is stored in reference order and its records carry no position)
-void appendPairs(std::vector<LeafPair>& leaf, const rtx_mesh& m, uint32_t begin, const uint32_t* order, uint32_t count, uint32_t triBits)
-{
-	for (uint32_t k = 0; k < count; k += 2) {
-		LeafPair lp;
-		memset(&lp, 0, sizeof(lp));          // odd count: the second triangle stays degenerate (det == 0)
-		for (uint32_t h = 0; h < 2 && k + h < count; h++) {
-			const LeafTri lt = makeLeafTri(m, begin + order[k + h]);
-			lp.e2x[h] = lt.e2x; lp.e2y[h] = lt.e2y; lp.e2z[h] = lt.e2z;
-			lp.e1x[h] = lt.e1x; lp.e1y[h] = lt.e1y; lp.e1z[h] = lt.e1z;
-			lp.v0x[h] = lt.v0x; lp.v0y[h] = lt.v0y; lp.v0z[h] = lt.v0z;
-			lp.tri[h] = lt.tri | (triBits < 32 ? order[k + h] << triBits : 0u);
-		}
-		leaf.push_back(lp);
-	}
-}
-
-// Certificate header (rtxd::LeafHeader) over leaf references [begin, begin+count), as a pair slot.
-LeafPair makeHeader(const rtx_mesh& m, uint32_t begin, const uint32_t* order, uint32_t count)
-{
-	double mlo[3] = { 1e300, 1e300, 1e300 }, mhi[3] = { -1e300, -1e300, -1e300 };
-	double blo[3] = { 1e300, 1e300, 1e300 }, bhi[3] = { -1e300, -1e300, -1e300 };
-	double qmax = 0, q2max = 0, e1L1 = 0, e2L1 = 0, e1Len = 0, e2Len = 0;
-	for (uint32_t r = 0; r < count; r++) {
-		const LeafTri lt = makeLeafTri(m, begin + order[r]);
-		const float* p = m.tri_pos + (size_t)lt.tri * 9;
-		// m = e2 x e1 and the error scales, in fp64 from the fp32 edges
-		const double e1[3] = { lt.e1x, lt.e1y, lt.e1z }, e2[3] = { lt.e2x, lt.e2y, lt.e2z };
-		const double mm[3] = { e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0] };
-		double q = 0, q2 = 0;
-		for (int c = 0; c < 3; c++) {
-			mlo[c] = std::min(mlo[c], mm[c]); mhi[c] = std::max(mhi[c], mm[c]);
-			q += std::fabs(e1[c]) * (std::fabs(e2[(c + 1) % 3]) + std::fabs(e2[(c + 2) % 3]));
-			q2 += std::fabs(e2[c]) * (std::fabs(e1[(c + 1) % 3]) + std::fabs(e1[(c + 2) % 3]));
-			for (int v = 0; v < 3; v++) { blo[c] = std::min(blo[c], (double)p[v * 3 + c]); bhi[c] = std::max(bhi[c], (double)p[v * 3 + c]); }
-		}
-		qmax = std::max(qmax, q); q2max = std::max(q2max, q2);
-		e1L1 = std::max(e1L1, std::fabs(e1[0]) + std::fabs(e1[1]) + std::fabs(e1[2]));
-		e2L1 = std::max(e2L1, std::fabs(e2[0]) + std::fabs(e2[1]) + std::fabs(e2[2]));
-		e1Len = std::max(e1Len, std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]));
-		e2Len = std::max(e2Len, std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]));
-	}
-	LeafHeader h;
-	memset(&h, 0, sizeof(h));
-	double mabs = 0;
-	bool finite = count > 0;
-	for (int c = 0; c < 3 && finite; c++) {
-		if (!std::isfinite(mlo[c]) || !std::isfinite(mhi[c]) || std::fabs(mlo[c]) > 1e30 || std::fabs(mhi[c]) > 1e30) finite = false;
-		else {
-			// outward rounding to fp32 (one extra ulp absorbs the fp64 rounding of mm)
-			float lo = (float)mlo[c], hi = (float)mhi[c];
-			lo = std::nextafterf(std::nextafterf(lo, -INFINITY), -INFINITY);
-			hi = std::nextafterf(std::nextafterf(hi, INFINITY), INFINITY);
-			h.m[c][0] = lo; h.m[c][1] = hi;
-			mabs += std::max(std::fabs((double)lo), std::fabs((double)hi));
-		}
-	}
-	const double u = 5.9604644775390625e-08;      // 2^-24
-	const double err = (8 * u * qmax + 4 * u * mabs) * 1.001 + 1e-30;
-	if (!finite || !(err < 1e30)) { for (int c = 0; c < 3; c++) { h.m[c][0] = -INFINITY; h.m[c][1] = INFINITY; } h.err = INFINITY; finite = false; }
-	else h.err = std::nextafterf((float)err, INFINITY);
-	// certificate (2): coefficients of the error budget, rounded up; disabled (inf) for headers whose magnitudes
-	// leave the range the derivation assumes
-	const double r3 = 1.7320508075688772;
-	const double A1 = (r3 * 32 * u * (e2L1 * e1Len + e1L1 * e2Len) + 24 * u * q2max + 13 * u * mabs) * 1.05;
-	const double A2 = (r3 * (16 * u * qmax + 6 * u * mabs) * (e1Len + e2Len)) * 1.05 + 1e-30;
-	const bool ok2 = finite && qmax < 1048576.0 && q2max < 1048576.0 && A1 < 1e30 && A2 < 1e30;
-	for (int c = 0; c < 3; c++) {
-		h.b[c][0] = ok2 ? std::nextafterf((float)blo[c], -INFINITY) : -INFINITY;
-		h.b[c][1] = ok2 ? std::nextafterf((float)bhi[c], INFINITY) : INFINITY;
-	}
-	h.a1 = ok2 ? std::nextafterf((float)A1, INFINITY) : INFINITY;
-	h.a2 = ok2 ? std::nextafterf((float)A2, INFINITY) : INFINITY;
-	LeafPair out;
-	memcpy(&out, &h, sizeof(out));
-	return out;
+	a.v0x = p[0]; a.v0y = p[1]; a.v0z = p[2]; a.tri = t;
+	b.e1x = p[3] - p[0]; b.e1y = p[4] - p[1]; b.e1z = p[5] - p[2];
+	b.e2x = p[6] - p[0]; c.e2y = p[7] - p[1]; c.e2z = p[8] - p[2];
 }
 
 } // namespace
@@ -228,7 +106,7 @@ int setView(rtx_scene* s, const rtx_view* v)
 	memcpy(d.camPos, v->cam_pos, 12);
 	memcpy(d.camM, v->cam_matrix, 64);
 	d.scale = v->scale; d.aspect = v->aspect;
-	if ((d.flags & RTX_FLAG_SKYBOX) && !s->params.sky[0]) return fail(RTX_ERR_ARG, "view: skybox flag without skybox faces");
+	if ((d.flags & RTX_FLAG_SKYBOX) && !s->params.sky) return fail(RTX_ERR_ARG, "view: skybox flag without skybox faces");
 	if (d.maxDepth < 0) d.maxDepth = -1;
 	return RTX_OK;
 }
@@ -334,7 +212,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 	memset(&s->params, 0, sizeof(Params));
 	auto bail = [&](int code) { rtx_scene_destroy(s); return code; };
 
-	// meshes: nodes -> 32-byte records, leaf references -> 64-byte (v0, e1, e2, tri) lines
+	// meshes: nodes -> 32-byte records, leaf references -> (v0, e1, e2, tri) in three parallel arrays
 	std::vector<Mesh> meshes(desc->n_meshes);
 	for (uint32_t mi = 0; mi < desc->n_meshes; mi++) {
 		const rtx_mesh& m = desc->meshes[mi];
@@ -342,12 +220,6 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			return bail(fail(RTX_ERR_ARG, "mesh arrays missing"));
 		if (m.normal_map && !m.tri_tb) return bail(fail(RTX_ERR_ARG, "normal map without tangents"));
 		std::vector<Node> nodes(m.n_nodes);
-		std::vector<LeafPair> leaf;
-		// LeafPair::tri = triangle index | position in the reference's leaf order << triBits
-		uint32_t triBits = 1;
-		while (triBits < 32 && (m.n_tris >> triBits) != 0) triBits++;
-		const uint32_t maxOrd = triBits < 31 ? (1u << (32 - triBits)) - 2u : 0u;
-		leaf.reserve(m.n_refs / 2 + m.n_nodes / 2 + 2);
 		for (uint32_t i = 0; i < m.n_nodes; i++) {
 			Node& nd = nodes[i];
 			for (int c = 0; c < 3; c++) { nd.b[2 * c] = m.node_bounds[(size_t)i * 6 + c]; nd.b[2 * c + 1] = m.node_bounds[(size_t)i * 6 + 3 + c]; }
@@ -358,48 +230,32 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			}
 			const uint32_t begin = (uint32_t)m.leaf_begin[i], count = (uint32_t)m.leaf_count[i];
 			if (begin + count > m.n_refs) return bail(fail(RTX_ERR_ARG, "leaf range out of bounds"));
-			nd.link = ~m.leaf_count[i]; nd.first = (int32_t)leaf.size();
-			for (uint32_t r = 0; r < count; r++)
-				if (m.refs[begin + r] >= m.n_tris) return bail(fail(RTX_ERR_ARG, "leaf reference out of range"));
-			// [leaf header] pairs...   or   [leaf header] { [chunk header] 8 pairs }...   in the leaf's storage order
-			bool reordered;
-			const std::vector<uint32_t> order = leafOrder(m, begin, count, maxOrd, reordered);
-			const uint32_t tb = reordered ? triBits : 32u;
-			leaf.push_back(makeHeader(m, begin, order.data(), count));
-			if (count <= kChunkTris) appendPairs(leaf, m, begin, order.data(), count, tb);
-			else {
-				for (uint32_t g0 = 0; g0 < count; g0 += kGroupTris) {
-					const uint32_t gn = std::min(kGroupTris, count - g0);
-					size_t groupAt = 0;
-					if (count > kGroupTris) { groupAt = leaf.size(); leaf.push_back(makeHeader(m, begin, order.data() + g0, gn)); }
-					for (uint32_t c = g0; c < g0 + gn; c += kChunkTris) {
-						const uint32_t cn = std::min(kChunkTris, g0 + gn - c);
-						leaf.push_back(makeHeader(m, begin, order.data() + c, cn));
-						appendPairs(leaf, m, begin, order.data() + c, cn, tb);
-					}
-					if (count > kGroupTris) {
-						LeafHeader h;
-						memcpy(&h, &leaf[groupAt], sizeof(h));
-						h.pad[0] = (uint32_t)(leaf.size() - groupAt - 1);     // slots of the group: what a wave jumps over
-						memcpy(&leaf[groupAt], &h, sizeof(h));
-					}
-				}
-			}
+			nd.link = ~m.leaf_count[i]; nd.first = (int32_t)begin;
 		}
-		{ LeafPair z; memset(&z, 0, sizeof(z)); leaf.push_back(z); leaf.push_back(z); }
+		// leaf references in the reference's order, three parallel arrays padded by one wave
+		std::vector<RefA> refA((size_t)m.n_refs + 64);
+		std::vector<RefB> refB((size_t)m.n_refs + 64);
+		std::vector<RefC> refC((size_t)m.n_refs + 64);
+		memset(refA.data(), 0, refA.size() * sizeof(RefA)); memset(refB.data(), 0, refB.size() * sizeof(RefB)); memset(refC.data(), 0, refC.size() * sizeof(RefC));
+		for (uint32_t r = 0; r < m.n_refs; r++) {
+			if (m.refs[r] >= m.n_tris) return bail(fail(RTX_ERR_ARG, "leaf reference out of range"));
+			makeRef(m, r, refA[r], refB[r], refC[r]);
+		}
 		for (int c = 0; c < 6; c++) s->meshBounds.push_back(m.n_nodes ? m.node_bounds[c] : 0.0f);
 		Mesh& dm = meshes[mi];
 		memset(&dm, 0, sizeof(dm));
 		int rc;
 		if ((rc = upload(s->owned, nodes.data(), nodes.size(), &dm.nodes))) return bail(rc);
-		if ((rc = upload(s->owned, leaf.data(), leaf.size(), &dm.leaf))) return bail(rc);
+		if ((rc = upload(s->owned, refA.data(), refA.size(), &dm.refA))) return bail(rc);
+		if ((rc = upload(s->owned, refB.data(), refB.size(), &dm.refB))) return bail(rc);
+		if ((rc = upload(s->owned, refC.data(), refC.size(), &dm.refC))) return bail(rc);
 		if ((rc = upload(s->owned, m.tri_nrm, (size_t)m.n_tris * 9, &dm.nrm))) return bail(rc);
 		if ((rc = upload(s->owned, m.tri_uv, (size_t)m.n_tris * 6, &dm.uv))) return bail(rc);
 		if ((rc = upload(s->owned, m.tri_tb, m.tri_tb ? (size_t)m.n_tris * 6 : 0, &dm.tb))) return bail(rc);
 		if ((rc = upload(s->owned, m.diffuse_map, (size_t)m.diffuse_w * m.diffuse_h * 3, &dm.diffuse))) return bail(rc);
 		if ((rc = upload(s->owned, m.normal_map, (size_t)m.normal_w * m.normal_h * 3, &dm.normal))) return bail(rc);
 		if ((rc = upload(s->owned, m.specular_map, (size_t)m.specular_w * m.specular_h, &dm.specular))) return bail(rc);
-		dm.nNodes = m.n_nodes; dm.nRefs = m.n_refs; dm.nTris = m.n_tris; dm.triBits = triBits;
+		dm.nNodes = m.n_nodes; dm.nRefs = m.n_refs; dm.nTris = m.n_tris;
 		dm.dW = m.diffuse_w; dm.dH = m.diffuse_h; dm.nW = m.normal_w; dm.nH = m.normal_h; dm.sW = m.specular_w; dm.sH = m.specular_h;
 	}
 	std::vector<Object> objs(desc->n_objects);
@@ -436,10 +292,12 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 	if ((rc = upload(s->owned, lights.data(), lights.size(), &s->params.lights))) return bail(rc);
 	s->params.nObjects = desc->n_objects; s->params.nLights = desc->n_lights;
 	if (desc->sky_w && desc->sky_h && desc->sky[0]) {
+		const float* faces[6];
 		for (int k = 0; k < 6; k++) {
 			if (!desc->sky[k]) return bail(fail(RTX_ERR_ARG, "skybox face missing"));
-			if ((rc = upload(s->owned, desc->sky[k], (size_t)desc->sky_w * desc->sky_h * 3, &s->params.sky[k]))) return bail(rc);
+			if ((rc = upload(s->owned, desc->sky[k], (size_t)desc->sky_w * desc->sky_h * 3, &faces[k]))) return bail(rc);
 		}
+		if ((rc = upload(s->owned, faces, 6, &s->params.sky))) return bail(rc);
 		s->params.skyW = desc->sky_w; s->params.skyH = desc->sky_h;
 	}
 	if ((rc = setView(s, &desc->view))) return bail(rc);

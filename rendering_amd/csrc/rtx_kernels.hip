@@ -33,7 +33,7 @@ using namespace rtxd;
 #define RTX_DBG 0     // 1: wave-level stage counters + per-wave pass-1 timeline, 2: + sampled certificate outcomes / leaf-size histograms (slow) (RTX_DEBUG_ITEMS=1 prints them)
 #endif
 #ifndef RTX_WAVES
-#define RTX_WAVES 8   // target waves per SIMD of the two ray kernels (register budget = 512 / RTX_WAVES VGPRs)
+#define RTX_WAVES 6   // target waves per SIMD of the two ray kernels (register budget = 512 / RTX_WAVES VGPRs)
 #endif
 
 namespace {
@@ -43,7 +43,6 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-struct TriPair { u32x16 a; u32x4 b; };   // 20 dwords: two 10-dword leaf records (rtxd::LeafPair)
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Wave-uniform loads through the constant address space -> SMEM instructions.
@@ -51,13 +50,6 @@ __device__ __forceinline__ uint32_t sload1(const void* p) { return *(const RTX_A
 __device__ __forceinline__ u32x8 sload8(const void* p) { return *(const RTX_AS4 u32x8*)(uintptr_t)p; }
 __device__ __forceinline__ u32x16 sload16(const void* p) { return *(const RTX_AS4 u32x16*)(uintptr_t)p; }
 __device__ __forceinline__ u32x4 sload4(const void* p) { return *(const RTX_AS4 u32x4*)(uintptr_t)p; }
-__device__ __forceinline__ TriPair sloadPair(const void* p)
-{
-	TriPair t;
-	t.a = sload16(p);
-	t.b = sload4((const char*)p + 64);
-	return t;
-}
 __device__ __forceinline__ float sloadf(const float* p) { return __uint_as_float(sload1(p)); }
 __device__ __forceinline__ const void* sloadp(const void* p)
 {
@@ -74,6 +66,32 @@ template <typename T> __device__ __forceinline__ const T* uni(const T* p)
 	return (const T*)(((uint64_t)uni((uint32_t)(a >> 32)) << 32) | uni((uint32_t)a));
 }
 
+__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+// lane index, recomputed where it is needed (two VALU instructions) instead of being kept live / spilled across the walk
+__device__ __forceinline__ uint32_t laneNow()
+{
+	uint32_t l;
+	asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+	return l;
+}
+// lane `lane` (wave-uniform) of v := val (wave-uniform); the lane select goes through m0 (constant-bus limit of gfx9)
+__device__ __forceinline__ uint32_t writeLane(uint32_t val, uint32_t lane, uint32_t v)
+{
+	asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(lane) : "m0");
+	return v;
+}
+#define RTX_AS1 __attribute__((address_space(1)))
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+// leaf reference r of a mesh through global (address space 1) vector loads: dwordx4 + dwordx4 + dwordx2 per lane
+__device__ __forceinline__ void loadRef(const RTX_AS1 f4v* A, const RTX_AS1 f4v* Bp, const RTX_AS1 f2v* Cp, uint32_t r, RefA& a, RefB& b, RefC& c)
+{
+	const f4v va = A[r], vb = Bp[r];
+	const f2v vc = Cp[r];
+	a.v0x = va.x; a.v0y = va.y; a.v0z = va.z; a.tri = __float_as_uint(va.w);
+	b.e1x = vb.x; b.e1y = vb.y; b.e1z = vb.z; b.e2x = vb.w;
+	c.e2y = vc.x; c.e2z = vc.y;
+}
 __device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
 constexpr float kFltMax = 3.402823466e+38f;
@@ -252,10 +270,9 @@ __device__ __forceinline__ int toPixel(float v, int mx)               // scene.c
 }
 __device__ __forceinline__ V3 load3(const float* p) { return mk(p[0], p[1], p[2]); }
 
-__device__ __noinline__ V3 skyColor(const Params& P, V3 dir)           // scene.cpp:381-442
+// (takes the few fields it needs by value: a kernel-argument struct whose address escapes into a call is copied to scratch)
+__device__ __noinline__ V3 skyFetch(const float* const* sky, int W, int H, V3 dir)           // scene.cpp:394-441
 {
-	if (!(P.view.flags & 2u)) return mk(P.view.bg[0], P.view.bg[1], P.view.bg[2]);
-	const int W = (int)P.skyW, H = (int)P.skyH;
 	float ax = fabsf(dir.x), ay = fabsf(dir.y), az = fabsf(dir.z);
 	float m = fmaxRef(ax, fmaxRef(ay, az));
 	V3 a; int face, i, j;
@@ -271,7 +288,13 @@ __device__ __noinline__ V3 skyColor(const Params& P, V3 dir)           // scene.
 		if (dir.y < 0) { a = dir * (1 / -dir.y); face = 5; i = toPixel(a.z, H); j = toPixel(a.x, W); }
 		else { a = dir * (1 / dir.y); face = 4; i = toPixel(a.z, H); j = toPixel(a.x, W); }
 	}
-	return load3(P.sky[face] + ((size_t)i * W + j) * 3);
+	return load3(sky[face] + ((size_t)i * W + j) * 3);
+}
+
+__device__ __forceinline__ V3 skyColor(const Params& P, V3 dir)           // scene.cpp:381-442
+{
+	if (!(P.view.flags & 2u)) return mk(P.view.bg[0], P.view.bg[1], P.view.bg[2]);
+	return skyFetch(P.sky, (int)P.skyW, (int)P.skyH, dir);
 }
 
 // (int)(dim * coord), clamped on the high side like the reference (objects.cpp:144-147, 156-159).  The low-side clamp is
@@ -305,263 +328,301 @@ template <typename T> __device__ __forceinline__ T after(T x, uint32_t v)
 	return x;
 }
 
-// Triangle::rayTriangleIntersect (objects.cpp:59-95) for the TWO triangles of a leaf-reference pair at once: the pair
-// record interleaves the two triangles (rtxd::LeafPair), so every fp32 operation of the reference is issued once as a
-// packed instruction (v_pk_mul_f32 / v_pk_add_f32: two independent IEEE operations, no contraction) with triangle A
-// in the low and triangle B in the high half.  Runs with exec = the lanes that passed the leaf's box, so every
-// ballot is already restricted to them; the wave leaves a stage as soon as no lane survives it for either triangle.
-// Ballots are taken of the raw compares and combined with scalar mask arithmetic.
-struct PackedRay { f2 dxx, dyy, dzz, oxx, oyy, ozz; };
-
-// The tail of the test for one triangle (objects.cpp:81-94) for the lanes in m (a wave-uniform mask).
-// w = triangle index | (position in the reference's leaf order) << bits.  `best` = 1 + that position for the lanes whose
-// closest hit so far was found in THIS leaf, 0 otherwise: of several triangles accepted with exactly the same t the
-// reference keeps the one it meets first (strict `<`, objects.cpp:623), whatever order they are stored in here.
-struct Best { float t, u, v; uint32_t tri, ord; };
-
-template <bool STATS>
-__device__ __forceinline__ void triTail(uint64_t m, float det, float nu, float tx, float ty, float tz, float e1x, float e1y, float e1z,
-                                        float e2x, float e2y, float e2z, uint32_t w, uint32_t bits, float dx, float dy, float dz,
-                                        Best& b, Counts& cnt)
+// ------------------------------------------------------------------------------------------------
+// The ray bundle of one Render::trace of the wave, and the bundle filter
+// ------------------------------------------------------------------------------------------------
+// Wave-wide maximum over the lanes (all 64 lanes execute this; lanes that must not contribute pass -inf).  Four DPP
+// steps inside each row of 16, two row broadcasts, the result is read from lane 63.
+__device__ __forceinline__ float waveMax(float v)
 {
-	if (STATS && RTX_DBG) cnt.wS3++;
-	const float inv = 1 / det;
-	const float u = nu * inv;
-	const uint64_t m2 = m & ballot(!(u < 0)) & ballot(!(u > 1));
-	if (m2 == 0) return;
-	if (STATS && RTX_DBG) cnt.wS4++;
-	const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;   // tvec x v0v1
-	const float v = (dx * qx + dy * qy + dz * qz) * inv;
-	const uint64_t m3 = m2 & ballot(!(v < 0)) & ballot(!(u + v > 1));
-	if (m3 == 0) return;
-	const float t = (e2x * qx + e2y * qy + e2z * qz) * inv;
-	const uint32_t ord = (w >> bits) + 1u;
-	const uint64_t m4 = m3 & ballot(!(t < 0)) & (ballot(t < b.t) | (ballot(t == b.t) & ballot(ord < b.ord)));     // objects.cpp:91, 623
-	if ((m4 >> __lane_id()) & 1ull) { b.t = t; b.u = u; b.v = v; b.tri = w & ((1u << bits) - 1u); b.ord = ord; }
+	const int neg = (int)0xff800000u;
+#define RTX_DPP_MAX(ctrl, rowmask) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(neg, __float_as_int(v), ctrl, rowmask, 0xf, false)))
+	RTX_DPP_MAX(0xB1, 0xf);    // quad_perm [1,0,3,2]
+	RTX_DPP_MAX(0x4E, 0xf);    // quad_perm [2,3,0,1]
+	RTX_DPP_MAX(0x141, 0xf);   // row_half_mirror
+	RTX_DPP_MAX(0x140, 0xf);   // row_mirror
+	RTX_DPP_MAX(0x142, 0xa);   // row_bcast15 -> rows 1, 3
+	RTX_DPP_MAX(0x143, 0xc);   // row_bcast31 -> rows 2, 3
+#undef RTX_DPP_MAX
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-template <bool CULL, bool STATS>
-__device__ __forceinline__ void triTestPair(const TriPair& T, uint32_t bits, const PackedRay& r, Best& b, Counts& cnt)
+// Box of origins x box of directions of the active rays of the wave, as centre / half-width (wave-uniform values,
+// kept in SGPRs).  The half-widths are inflated so that every lane's fp32 origin / direction really lies inside
+// [c - r, c + r] despite the rounding of c and r themselves.
+struct Bundle {
+	float ocx, ocy, ocz, rox, roy, roz;
+	float dcx, dcy, dcz, rdx, rdy, rdz;
+	float kd;          // K * dmax            (K = 2^-18, dmax = max |dir_i| over the bundle)
+	float roMax;       // max_i ro_i
+	float kdRoSum;     // dmax * (rox + roy + roz)
+	bool sane;         // every active lane has finite, moderate coordinates (|orig_i| < 2^40, |dir_i| < 2^20)
+};
+constexpr float kFilterK = 0x1p-18f;     // 64 u: covers the reference's rounding errors AND the filter's own (see bundleRejects)
+constexpr float kFilterEta = 1e-30f;     // absolute slack for underflow in either computation
+
+__device__ __forceinline__ void centreRadius(float lo, float hi, float& c, float& r)
 {
-	// record dwords (A, B interleaved): e2x | e2y | e2z | e1x | e1y | e1z | v0x | v0y || v0z | tri
-	const f2 e2x = { F(T.a[0]), F(T.a[1]) }, e2y = { F(T.a[2]), F(T.a[3]) }, e2z = { F(T.a[4]), F(T.a[5]) };
-	const f2 e1x = { F(T.a[6]), F(T.a[7]) }, e1y = { F(T.a[8]), F(T.a[9]) }, e1z = { F(T.a[10]), F(T.a[11]) };
-	const f2 v0x = { F(T.a[12]), F(T.a[13]) }, v0y = { F(T.a[14]), F(T.a[15]) }, v0z = { F(T.b[0]), F(T.b[1]) };
-	// pvec = dir x v0v2 (objects.cpp:72), det = v0v1 . pvec (objects.cpp:73)
-	const f2 px = r.dyy * e2z - r.dzz * e2y;
-	const f2 py = r.dzz * e2x - r.dxx * e2z;
-	const f2 pz = r.dxx * e2y - r.dyy * e2x;
-	const f2 det = e1x * px + e1y * py + e1z * pz;
-	// culling on:  reject iff det < 1e-8 (then |det| < 1e-8 is implied);  off: reject iff |det| < 1e-8.
-	// Both compares are false for NaN, exactly like the reference's two ifs (objects.cpp:75-79).
-	const uint64_t mA = ballot(!((CULL ? det.x : fabsf(det.x)) < RTX_EPS8));
-	const uint64_t mB = ballot(!((CULL ? det.y : fabsf(det.y)) < RTX_EPS8));
-	if (STATS && RTX_DBG) { cnt.wTri++; cnt.triLanes += __popcll(ballot(true)); }
-	if ((mA | mB) == 0) return;
-	if (STATS && RTX_DBG) cnt.wS2++;
-	const f2 tx = r.oxx - v0x, ty = r.oyy - v0y, tz = r.ozz - v0z;            // tvec = orig - v0 (objects.cpp:82)
-	const f2 nu = tx * px + ty * py + tz * pz;                                // tvec . pvec (objects.cpp:83)
-	uint64_t goA = mA, goB = mB;
-	if (CULL) {
-		// Exact-safe rejection before the IEEE division.  Here 1e-8 <= det, so inv = RN(1/det) > 0 with relative
-		// error <= 2^-22 (2^-24 while 1/det is normal, <= 2^-22 in the denormal range det > 2^126), and u = RN(nu*inv):
-		//   nu < -2^-20            =>  |nu*inv| >= 2^-20 * 2^-128 * (1 - 2^-3) > 2^-149: no underflow to -0  =>  u < 0;
-		//   nu > RN(det*(1+2^-20)) =>  nu/det > 1+2^-21, and the roundings lose < 2^-21                    =>  u > 1.
-		// Lanes outside these sure cases (and every lane of the !CULL variant) take the division, which then
-		// re-derives the same verdict for the sure cases, so the result is bit-identical either way.
-		const f2 hi = det * (1.0f + 0x1p-20f);
-		goA &= ~(ballot(nu.x < -0x1p-20f) | ballot(nu.x > hi.x));
-		goB &= ~(ballot(nu.y < -0x1p-20f) | ballot(nu.y > hi.y));
-		if ((goA | goB) == 0) return;
-	}
-	// first-hit-wins needs A before B (objects.cpp:622-629)
-	if (goA != 0) triTail<STATS>(goA, det.x, nu.x, tx.x, ty.x, tz.x, e1x.x, e1y.x, e1z.x, e2x.x, e2y.x, e2z.x, T.b[2], bits, r.dxx.x, r.dyy.x, r.dzz.x, b, cnt);
-	if (goB != 0) triTail<STATS>(goB, det.y, nu.y, tx.y, ty.y, tz.y, e1x.y, e1y.y, e1z.y, e2x.y, e2y.y, e2z.y, T.b[3], bits, r.dxx.x, r.dyy.x, r.dzz.x, b, cnt);
+	c = unif(0.5f * (lo + hi));
+	r = unif((0.5f * (hi - lo)) * (1.0f + 0x1p-19f) + 0x1p-21f * fmaxf(fabsf(lo), fabsf(hi)));
 }
 
-// Leaf / chunk certificates (rtxd::LeafHeader): true when the reference is CERTAIN to reject every
-// triangle the header covers for this ray, so the lane may be masked out of them.
+__device__ __forceinline__ Bundle makeBundle(bool active, const V3& o, const V3& d)
+{
+	const float ninf = -__builtin_inff();
+	Bundle B;
+	float lo, hi;
+#define RTX_RANGE(x, c, r) hi = waveMax(active ? (x) : ninf); lo = -waveMax(active ? -(x) : ninf); centreRadius(lo, hi, c, r)
+	RTX_RANGE(o.x, B.ocx, B.rox); RTX_RANGE(o.y, B.ocy, B.roy); RTX_RANGE(o.z, B.ocz, B.roz);
+	RTX_RANGE(d.x, B.dcx, B.rdx); RTX_RANGE(d.y, B.dcy, B.rdy); RTX_RANGE(d.z, B.dcz, B.rdz);
+#undef RTX_RANGE
+	const float dmax = fmaxf(fmaxf(fabsf(B.dcx) + B.rdx, fabsf(B.dcy) + B.rdy), fabsf(B.dcz) + B.rdz) * (1.0f + 0x1p-20f);
+	B.kd = unif(kFilterK * dmax);
+	B.roMax = unif(fmaxf(fmaxf(B.rox, B.roy), B.roz));
+	B.kdRoSum = unif(dmax * (B.rox + B.roy + B.roz) * (1.0f + 0x1p-20f));
+	// NaN / inf / huge coordinates fail these compares: the filter then rejects nothing and the lanes run the exact path
+	const bool tame = fabsf(o.x) < 0x1p40f && fabsf(o.y) < 0x1p40f && fabsf(o.z) < 0x1p40f && fabsf(d.x) < 0x1p20f && fabsf(d.y) < 0x1p20f && fabsf(d.z) < 0x1p20f;
+	B.sane = ballot(active && !tame) == 0;
+	return B;
+}
+
+// Bundle filter for ONE leaf reference (v0, e1, e2) -- this lane's -- against the whole bundle: true when
+// Triangle::rayTriangleIntersect (objects.cpp:59-95) is CERTAIN to return false, or to return a t that is not below the
+// ray's limit, for EVERY ray (o, d) with o in [oc - ro, oc + ro], d in [dc - rd, dc + rd].  Division-free: with
+//     m = e2 x e1,  a = o - v0:    det = d . m,   Nu = tvec . pvec = d . (e2 x a),   Nv = d . qvec = d . (a x e1),
+//     Nt = e2 . qvec = -(a . m)    (u = Nu / det, v = Nv / det, t = Nt / det)
+// the four numerators are (bi)linear in (o, d), so their range over the bundle is centre +- radius.  Error budget, in units
+// of the natural scales (s1 = |e1|_1, s2 = |e2|_1, ainf >= max_i |o_i - v0_i| over the bundle, dmax >= max |d_i|):
+//     reference:  |det_c - det| <= 5.1 u dmax s1 s2,  |Nu_c - Nu| <= 12.2 u dmax ainf s2,  |Nv_c - Nv| <= 12.2 u dmax ainf s1,
+//                 |Nt_c - Nt| <= 6.1 u ainf s1 s2      (u = 2^-24; two roundings per cross-product component, one per tvec
+//                 component, three per dot product; fp32, no FMA, objects.cpp:70-90)
+//     this filter: the same expressions evaluated once at the bundle centre, with FMAs: at most as much again.
+// K = 64 u covers both with a margin of more than two; kFilterEta covers underflow.  With det_c >= 1e-8 > 0 (culling on, or
+// the sign of det certain) inv = RN(1 / det_c) > 0 and every product below is rounded at most three times (relative
+// 4 u), hence the factor (1 + 2^-18) on the right-hand sides:
+//     det + Ed < 0                          =>  det_c < 1e-8                 (objects.cpp:75-77, culling on)
+//     Nu + Eu < 0  /  Nv + Ev < 0           =>  u_c < 0  /  v_c < 0          (objects.cpp:84, 88; |Nu_c| > eta: no underflow to -0)
+//     Nu - Eu > (det + Ed)(1 + 2^-18)       =>  u_c > 1                      (objects.cpp:84)
+//     Nu + Nv - Eu - Ev > (det + Ed)(1+2^-18)  =>  u_c + v_c > 1             (objects.cpp:88; u_c, v_c >= 0 at that point)
+//     Nt + Et < 0                           =>  t_c < 0                      (objects.cpp:91)
+//     Nt - Et >= tmax (det + Ed)(1 + 2^-18) =>  t_c >= tmax >= the lane's limit  (objects.cpp:623 / scene.cpp:740: strict <)
+// Magnitudes outside the assumed range (or NaN) make the compares false: nothing is rejected.
+// Evaluated in two stages so that a wave whose 64 references all fail the cheap first stage (orientation and t range:
+// the back of the mesh, everything behind a shadow ray's origin) skips the second (u, v).
+struct FilterState { float ax, ay, az, s1, s2, kda, detHi1, sg; bool ok; };
+
 template <bool CULL>
-__device__ __forceinline__ bool certainlyRejected(const u32x16& hd, const V3& o, const V3& d, float ix, float iy, float iz, float dmax)
+__device__ __forceinline__ bool bundleRejects1(const Bundle& B, float tmaxB, const RefA& ra, const RefB& rb, const RefC& rc, FilterState& f)
 {
-	// header dwords: (mlo.x mhi.x) (mlo.y mhi.y) (mlo.z mhi.z) err a1 (blo.x bhi.x) (blo.y bhi.y) (blo.z bhi.z) a2 span:
-	// the (lo, hi) pairs are operands of packed instructions
-	const f2 mx = f2{ F(hd[0]), F(hd[1]) } * f2{ d.x, d.x }, my = f2{ F(hd[2]), F(hd[3]) } * f2{ d.y, d.y }, mz = f2{ F(hd[4]), F(hd[5]) } * f2{ d.z, d.z };
-	const float ax = mx.x, bx = mx.y, ay = my.x, by = my.y, az = mz.x, bz = mz.y;
-	const float errd = F(hd[6]) * dmax;
-	bool skip = false;
-	// (1) certainly back-facing: U >= dir . (v0v2 x v0v1) = det for every triangle
-	if (CULL) skip = fmaxf(ax, bx) + fmaxf(ay, by) + fmaxf(az, bz) < -errd;
-	// certainly front-facing: det >= g > 0 for every triangle
-	const float lc = fminf(ax, bx) + fminf(ay, by) + fminf(az, bz);
-	const bool facing = lc >= 4 * errd;
-	if (ballot(facing) != 0) {
-		const f2 bxp = f2{ F(hd[8]), F(hd[9]) } - f2{ o.x, o.x }, byp = f2{ F(hd[10]), F(hd[11]) } - f2{ o.y, o.y }, bzp = f2{ F(hd[12]), F(hd[13]) } - f2{ o.z, o.z };
-		const float lox = bxp.x, hix = bxp.y, loy = byp.x, hiy = byp.y, loz = bzp.x, hiz = bzp.y;
-		const float dinf = fmaxf(fmaxf(fmaxf(fabsf(lox), fabsf(hix)), fmaxf(fabsf(loy), fabsf(hiy))), fmaxf(fabsf(loz), fabsf(hiz)));
-		const float g = lc - 2 * errd;
-		const float budget = dmax * (dinf * F(hd[7]) + F(hd[14]));      // g * (error radius) / 2, see DESIGN.md 3.3
-		// (magnitude guards: the error budget assumes no overflow / NaN in the reference's intermediate products)
-		const bool sane = facing && dmax < 0x1p20f && dinf < 0x1p40f;
-		// (2) entirely behind the ray origin: computed t < 0 for every triangle
-		const f2 dxp = bxp * f2{ d.x, d.x }, dyp = byp * f2{ d.y, d.y }, dzp = bzp * f2{ d.z, d.z };
-		const float boxdot = fmaxf(dxp.x, dxp.y) + fmaxf(dyp.x, dyp.y) + fmaxf(dzp.x, dzp.y);
-		const bool behind = sane && -boxdot * g > dmax * budget * 1.02f + 1e-30f;
-		// (3) the ray's line misses the AABB inflated by the error radius rho <= 2 * budget / g (+ fp32 slack): no
-		//     triangle can pass the reference's u / v tests
-		const float rho = 2 * budget * __builtin_amdgcn_rcpf(g) * (1.0f + 0x1p-10f) + dinf * 0x1p-20f;
-		const f2 inflate = { -rho, rho };
-		const f2 tx = (bxp + inflate) * f2{ ix, ix }, ty = (byp + inflate) * f2{ iy, iy }, tz = (bzp + inflate) * f2{ iz, iz };
-		const float tnear = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
-		const float tfar = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
-		const bool miss = sane && tnear > tfar;
-#if RTX_DBG >= 2
-		if ((int)__lane_id() == __builtin_ctzll(ballot(true))) {      // the first lane in exec reports for itself
-			atomicAdd(gDbgHist + 2, (unsigned long long)(facing && !skip)); atomicAdd(gDbgHist + 4, (unsigned long long)(behind && !skip));
-			atomicAdd(gDbgHist + 5, (unsigned long long)(miss && !behind && !skip)); atomicAdd(gDbgHist + 6, (unsigned long long)(sane && !behind && !miss && !skip));
-		}
-#endif
-		skip = skip || behind || miss;
+	const float e1x = rb.e1x, e1y = rb.e1y, e1z = rb.e1z, e2x = rb.e2x, e2y = rc.e2y, e2z = rc.e2z;
+	const float ax = B.ocx - ra.v0x, ay = B.ocy - ra.v0y, az = B.ocz - ra.v0z;
+	// m = e2 x e1
+	const float mx = __builtin_fmaf(e2y, e1z, -(e2z * e1y)), my = __builtin_fmaf(e2z, e1x, -(e2x * e1z)), mz = __builtin_fmaf(e2x, e1y, -(e2y * e1x));
+	const float s1 = fabsf(e1x) + fabsf(e1y) + fabsf(e1z), s2 = fabsf(e2x) + fabsf(e2y) + fabsf(e2z);
+	const float s12 = s1 * s2;
+	const float ainf = (fmaxf(fmaxf(fabsf(ax), fabsf(ay)), fabsf(az)) + B.roMax) * (1.0f + 0x1p-20f);
+	const bool tame = s1 < 0x1p20f && s2 < 0x1p20f && ainf < 0x1p41f;
+	// det over the bundle
+	float detc = __builtin_fmaf(B.dcz, mz, __builtin_fmaf(B.dcy, my, B.dcx * mx));
+	const float detr = __builtin_fmaf(B.rdz, fabsf(mz), __builtin_fmaf(B.rdy, fabsf(my), B.rdx * fabsf(mx)));
+	const float Ed = __builtin_fmaf(B.kd, s12, kFilterEta);
+	float sg = 1.0f;
+	bool usable = true;
+	if (!CULL) {
+		// culling off: the tests need the sign of det_c; both signs are handled by mirroring, an uncertain sign by not testing
+		const bool neg = detc + detr + Ed < 0;
+		usable = neg || detc - detr - Ed > 0;
+		sg = neg ? -1.0f : 1.0f;
+		detc *= sg;
 	}
-#if RTX_DBG >= 2
-	if ((int)__lane_id() == __builtin_ctzll(ballot(true))) {
-		atomicAdd(gDbgHist + 0, 1ull);
-		atomicAdd(gDbgHist + 1, (unsigned long long)(CULL && fmaxf(ax, bx) + fmaxf(ay, by) + fmaxf(az, bz) < -errd));
-		atomicAdd(gDbgHist + 7, (unsigned long long)skip);
-	}
-#endif
-	return skip;
+	const float detHi = detc + detr + Ed;
+	// t: Nt = -(a . m), radius from the origin box
+	const float ntc = -sg * __builtin_fmaf(az, mz, __builtin_fmaf(ay, my, ax * mx));
+	const float ntr = __builtin_fmaf(B.roz, fabsf(mz), __builtin_fmaf(B.roy, fabsf(my), B.rox * fabsf(mx)));
+	const float Et = __builtin_fmaf(kFilterK * ainf, s12, kFilterEta);
+	const float detHi1 = detHi * (1.0f + 0x1p-18f);
+	const bool rej = (CULL && detHi < 0) || ntc + ntr < -Et || ntc - ntr - Et >= tmaxB * detHi1;
+	f.ax = ax; f.ay = ay; f.az = az; f.s1 = s1; f.s2 = s2; f.kda = B.kd * ainf; f.detHi1 = detHi1; f.sg = sg;
+	f.ok = usable && tame && B.sane;
+	return rej && f.ok;
 }
 
-// Streams `pairs` leaf-reference pairs starting at p through triTest for the lanes in exec: wait(pair) -> issue(next
-// pair) -> test both.  The pair after the last one is fetched and ignored (a header, the next leaf, or padding).
+template <bool CULL>
+__device__ __forceinline__ bool bundleRejects2(const Bundle& B, const RefB& rb, const RefC& rc, const FilterState& f)
+{
+	const float e1x = rb.e1x, e1y = rb.e1y, e1z = rb.e1z, e2x = rb.e2x, e2y = rc.e2y, e2z = rc.e2z;
+	const float ax = f.ax, ay = f.ay, az = f.az;
+	// u: Nu = d . (e2 x a)
+	const float wux = __builtin_fmaf(e2y, az, -(e2z * ay)), wuy = __builtin_fmaf(e2z, ax, -(e2x * az)), wuz = __builtin_fmaf(e2x, ay, -(e2y * ax));
+	float nuc = __builtin_fmaf(B.dcz, wuz, __builtin_fmaf(B.dcy, wuy, B.dcx * wux));
+	const float nur = __builtin_fmaf(B.kdRoSum, f.s2, __builtin_fmaf(B.rdz, fabsf(wuz), __builtin_fmaf(B.rdy, fabsf(wuy), B.rdx * fabsf(wux)))) * (1.0f + 0x1p-20f);
+	const float Eu = __builtin_fmaf(f.kda, f.s2, kFilterEta);
+	// v: Nv = d . (a x e1)
+	const float wvx = __builtin_fmaf(ay, e1z, -(az * e1y)), wvy = __builtin_fmaf(az, e1x, -(ax * e1z)), wvz = __builtin_fmaf(ax, e1y, -(ay * e1x));
+	float nvc = __builtin_fmaf(B.dcz, wvz, __builtin_fmaf(B.dcy, wvy, B.dcx * wvx));
+	const float nvr = __builtin_fmaf(B.kdRoSum, f.s1, __builtin_fmaf(B.rdz, fabsf(wvz), __builtin_fmaf(B.rdy, fabsf(wvy), B.rdx * fabsf(wvx)))) * (1.0f + 0x1p-20f);
+	const float Ev = __builtin_fmaf(f.kda, f.s1, kFilterEta);
+	if (!CULL) { nuc *= f.sg; nvc *= f.sg; }
+	const float nuLo = nuc - nur - Eu;
+	const bool rej = nuc + nur < -Eu || nuLo > f.detHi1 || nvc + nvr < -Ev || nuLo + (nvc - nvr - Ev) > f.detHi1;
+	return rej && f.ok;
+}
+
+// The reference's test (objects.cpp:59-95) of the rays in exec against ONE triangle whose record is wave-uniform (read
+// from the surviving lane with v_readlane): the reference's own arithmetic, operation by operation.
 template <bool CULL, bool STATS>
-__device__ __forceinline__ void testPairs(const LeafPair* p, uint32_t pairs, uint32_t bits, const PackedRay& pr, Best& b, Counts& cnt)
+__device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
+                                           uint32_t tri, const V3& o, const V3& d, float& bt, float& bu, float& bv, uint32_t& btri)
 {
-	TriPair t0 = sloadPair(p);
-	for (uint32_t left = pairs;;) {
-		p = after(p, t0.b[3]);
-		const TriPair t1 = sloadPair(p + 1);
-		triTestPair<CULL, STATS>(t0, bits, pr, b, cnt);
-		if (left == 1) break;
-		left = uni(left - 1);
-		p += 1;
-		t0 = t1;
-	}
+	// pvec = dir x v0v2 (objects.cpp:72), det = v0v1 . pvec (objects.cpp:73)
+	const float px = d.y * e2z - d.z * e2y, py = d.z * e2x - d.x * e2z, pz = d.x * e2y - d.y * e2x;
+	const float det = e1x * px + e1y * py + e1z * pz;
+	// culling on: reject iff det < 1e-8 (then |det| < 1e-8 is implied); off: reject iff |det| < 1e-8.  Both compares
+	// are false for NaN, exactly like the reference's two ifs (objects.cpp:75-79).
+	if ((CULL ? det : fabsf(det)) < RTX_EPS8) return;
+	const float inv = 1 / det;
+	const float tx = o.x - v0x, ty = o.y - v0y, tz = o.z - v0z;                    // tvec = orig - v0 (objects.cpp:82)
+	const float u = (tx * px + ty * py + tz * pz) * inv;
+	if (u < 0 || u > 1) return;
+	const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;   // tvec x v0v1
+	const float v = (d.x * qx + d.y * qy + d.z * qz) * inv;
+	if (v < 0 || u + v > 1) return;
+	const float t = (e2x * qx + e2y * qy + e2z * qz) * inv;
+	if (t < 0) return;
+	if (t < bt) { bt = t; bu = u; bv = v; btri = tri; }                             // objects.cpp:623: strict <, first wins
 }
 
-// AccelerationStructure::intersectAccelStruct (objects.cpp:587-631) for a whole wave: stackless pre-order walk.
+// AccelerationStructure::intersectAccelStruct (objects.cpp:587-631) for a whole wave: stackless pre-order walk of the
+// nodes (phase 1: scalar-fed box tests, reached leaves are noted), then the noted leaves are processed in the same
+// order (phase 2: bundle filter with the lanes acting as triangles, exact test of the survivors with the lanes acting as
+// rays).  The two phases alternate every RTX_LEAF_BATCH leaves so that any-hit shadow rays still stop early.
 // A hit exists iff bt < FLT_MAX on return (the first accepted t is < FLT_MAX by objects.cpp:598,623).
+#ifndef RTX_LEAF_BATCH
+#define RTX_LEAF_BATCH 16
+#endif
 template <bool STATS, bool CULL>
-__device__ __forceinline__ void meshWalk(const Mesh* M, bool consider, bool shadow, const V3& o, const V3& d,
+__device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
                                          float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
                                          float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
 {
 	const Node* nodes = uni((const Node*)sloadp(&M->nodes));
-	const LeafPair* leaf = uni((const LeafPair*)sloadp(&M->leaf));
+	const RTX_AS1 char* refA = (const RTX_AS1 char*)(uintptr_t)uni((const RefA*)sloadp(&M->refA));
+	const RTX_AS1 char* refB = (const RTX_AS1 char*)(uintptr_t)uni((const RefB*)sloadp(&M->refB));
+	const RTX_AS1 char* refC = (const RTX_AS1 char*)(uintptr_t)uni((const RefC*)sloadp(&M->refC));
 	const uint32_t nN = uni(sload1(&M->nNodes));
-	Best b;
-	b.t = kFltMax; b.u = 0; b.v = 0; b.tri = 0; b.ord = 0;
 	bt = kFltMax; bu = 0; bv = 0; btri = 0;
 	if (nN == 0) return;
-	const uint32_t bits = uni(sload1(&M->triBits));
+	// the largest limit of any ray of the wave: a triangle whose t is certainly not below it cannot be recorded by any
+	// lane (tightened whenever a lane finds a closer hit)
+	float tmaxB = unif(waveMax(consider ? tLimit : -__builtin_inff()));
 	uint32_t resume = consider ? 0u : kNever;
 	uint32_t i = 0;
 	const uint32_t last = nN - 1;
-	PackedRay pr;
-	pr.dxx = f2{ d.x, d.x }; pr.dyy = f2{ d.y, d.y }; pr.dzz = f2{ d.z, d.z };
-	pr.oxx = f2{ o.x, o.x }; pr.oyy = f2{ o.y, o.y }; pr.ozz = f2{ o.z, o.z };
-	const f2 oxx = { o.x, o.x }, oyy = { o.y, o.y }, ozz = { o.z, o.z }, ixx = { ix, ix }, iyy = { iy, iy }, izz = { iz, iz };
-	// max |dir_i|, rounded up a little: scales the leaf headers' error bound
-	const float dmax = fmaxf(fabsf(d.x), fmaxf(fabsf(d.y), fabsf(d.z))) * (1.0f + 0x1p-20f);
 	u32x8 nd = sload8(nodes);
-	while (i < nN) {
-		const int32_t link = (int32_t)nd[6];
-		const uint32_t next = uni(i + 1);
-		const uint32_t nxt = link > 0 ? (uint32_t)link : next;
-		// speculative prefetch of both possible successors (clamped to the array), issued after nd has arrived
-		// (written as two unconditional loads; the compiler sinks each into the branch that consumes it, so one
-		// node record is fetched per visit -- measured faster than keeping both speculative loads in flight)
-		const Node* nb = after(nodes, nd[7]);
-		const u32x8 nxA = sload8(nb + (next < last ? next : last));
-		const u32x8 nxB = sload8(nb + (nxt < last ? nxt : last));
-		const bool act = i >= resume;
-		// slab test, objects.cpp:546-567: (bounds[sign] - orig) * invdir per axis, sequential compares.
-		// ((lo_i, hi_i) - orig_i) * invdir_i as one packed subtract + one packed multiply per axis
-		const f2 bx = (f2{ F(nd[0]), F(nd[1]) } - oxx) * ixx;
-		const f2 by = (f2{ F(nd[2]), F(nd[3]) } - oyy) * iyy;
-		const f2 bz = (f2{ F(nd[4]), F(nd[5]) } - ozz) * izz;
-		const float xlo = bx.x, xhi = bx.y, ylo = by.x, yhi = by.y, zlo = bz.x, zhi = bz.y;
-		float tmin = sx ? xhi : xlo, tmx = sx ? xlo : xhi;
-		const float tymin = sy ? yhi : ylo, tymax = sy ? ylo : yhi;
-		bool fail = (tmin > tymax) || (tymin > tmx);
-		if (tymin > tmin) tmin = tymin;
-		if (tymax < tmx) tmx = tymax;
-		const float tzmin = sz ? zhi : zlo, tzmax = sz ? zlo : zhi;
-		fail = fail || (tmin > tzmax) || (tzmin > tmx);
-		const bool pass = act && !fail;
-		if (act && fail) resume = nxt;
-		if (STATS) { cnt.box += __popcll(ballot(act)); if (RTX_DBG) cnt.wNodes++; }
-		const uint64_t m = ballot(pass);
-		if (m == 0) {
-			nd = nxB;
-			i = uni(nxt);
-			continue;
-		}
-		if (link < 0) {
-			const uint32_t n = (uint32_t)~link;
-			if (STATS) cnt.tri += (unsigned long long)__popcll(m) * n;
-			if (n != 0 && pass) {
-				// exec = the lanes that passed this leaf's box.  Leaf layout: [leaf header] pairs...  for n <= kChunkTris, and
-				// [leaf header] { [chunk header] kChunkTris/2 pairs }...  for larger leaves (rtxd::kChunkTris triangles per chunk).
-				const LeafPair* p = leaf + nd[7];
-				b.ord = 0;          // the closest hit so far (if any) comes from an earlier leaf: it wins every tie
-				const bool skip = certainlyRejected<CULL>(sload16(p), o, d, ix, iy, iz, dmax);
-				p += 1;
-#if RTX_DBG >= 2
-				if (STATS) {
-					cnt.wLeaves++; if (ballot(!skip) == 0) cnt.wLeafSkips++;
-					if (ballot(!skip) != 0 && (int)__lane_id() == __builtin_ctzll(ballot(true))) atomicAdd(gDbgHist + 16 + (31 - __builtin_clz(n)), 1ull);
+	for (;;) {
+		// ---- phase 1: nodes.  Entry k of the batch lives in lane k of four VGPRs (v_writelane / v_readlane).
+		uint32_t eFirst = 0, eCount = 0, eMaskLo = 0, eMaskHi = 0;
+		uint32_t batch = 0;
+		{
+			const f2 oxx = { o.x, o.x }, oyy = { o.y, o.y }, ozz = { o.z, o.z }, ixx = { ix, ix }, iyy = { iy, iy }, izz = { iz, iz };
+			while (i < nN && batch < RTX_LEAF_BATCH) {
+				const int32_t link = (int32_t)nd[6];
+				const uint32_t next = uni(i + 1);
+				const uint32_t nxt = link > 0 ? (uint32_t)link : next;
+				// speculative prefetch of both possible successors (clamped to the array), issued after nd has arrived
+				// (written as two unconditional loads; the compiler sinks each into the branch that consumes it, so one
+				// node record is fetched per visit -- measured faster than keeping both speculative loads in flight)
+				const Node* nb = after(nodes, nd[7]);
+				const u32x8 nxA = sload8(nb + (next < last ? next : last));
+				const u32x8 nxB = sload8(nb + (nxt < last ? nxt : last));
+				const bool act = i >= resume;
+				// slab test, objects.cpp:546-567: (bounds[sign] - orig) * invdir per axis, sequential compares.
+				// ((lo_i, hi_i) - orig_i) * invdir_i as one packed subtract + one packed multiply per axis
+				const f2 bx = (f2{ F(nd[0]), F(nd[1]) } - oxx) * ixx;
+				const f2 by = (f2{ F(nd[2]), F(nd[3]) } - oyy) * iyy;
+				const f2 bz = (f2{ F(nd[4]), F(nd[5]) } - ozz) * izz;
+				const float xlo = bx.x, xhi = bx.y, ylo = by.x, yhi = by.y, zlo = bz.x, zhi = bz.y;
+				float tmin = sx ? xhi : xlo, tmx = sx ? xlo : xhi;
+				const float tymin = sy ? yhi : ylo, tymax = sy ? ylo : yhi;
+				bool fail = (tmin > tymax) || (tymin > tmx);
+				if (tymin > tmin) tmin = tymin;
+				if (tymax < tmx) tmx = tymax;
+				const float tzmin = sz ? zhi : zlo, tzmax = sz ? zlo : zhi;
+				fail = fail || (tmin > tzmax) || (tzmin > tmx);
+				const bool pass = act && !fail;
+				if (act && fail) resume = nxt;
+				if (STATS) { cnt.box += __popcll(ballot(act)); if (RTX_DBG) cnt.wNodes++; }
+				const uint64_t m = ballot(pass);
+				if (m == 0) {
+					nd = nxB;
+					i = uni(nxt);
+					continue;
 				}
-#endif
-				if (!skip) {
-					// exec = lanes for which some triangle of the leaf may be accepted
-					if (n <= kChunkTris) testPairs<CULL, STATS>(p, (n + 1) / 2, bits, pr, b, cnt);
-					else {
-						// leaves of more than kGroupTris references: every kGroupTris references (kGroupTris / kChunkTris chunks)
-						// are preceded by a group header; a lane holding its certificate sits the group out, the wave jumps
-						// over it when every lane does
-						const bool grouped = n > kGroupTris;
-						bool skipGroup = false;
-						uint32_t groupEnd = 0;
-						for (uint32_t done = 0; done < n;) {
-							if (grouped && done == groupEnd) {
-								const u32x16 gh = sload16(p);
-								skipGroup = certainlyRejected<CULL>(gh, o, d, ix, iy, iz, dmax);
-								p += 1;
-								groupEnd = uni(n - done < kGroupTris ? n : done + kGroupTris);
-								if (STATS && RTX_DBG) { cnt.wChunks++; if (ballot(!skipGroup) == 0) cnt.wChunkSkips++; }
-								if (ballot(!skipGroup) == 0) { p += gh[15]; done = groupEnd; continue; }
-							}
-							const uint32_t cn = n - done < kChunkTris ? n - done : kChunkTris;
-							const bool skipChunk = certainlyRejected<CULL>(sload16(p), o, d, ix, iy, iz, dmax);
-							p += 1;
-							if (STATS && RTX_DBG) { cnt.wChunks++; if (ballot(!(skipChunk || skipGroup)) == 0) cnt.wChunkSkips++; }
-							if (!(skipChunk || skipGroup)) testPairs<CULL, STATS>(p, (cn + 1) / 2, bits, pr, b, cnt);
-							p += (cn + 1) / 2;
-							done = uni(done + kChunkTris);
-						}
+				if (link < 0) {
+					const uint32_t n = (uint32_t)~link;
+					if (STATS) { cnt.tri += (unsigned long long)__popcll(m) * n; if (RTX_DBG) cnt.wLeaves++; }
+					if (n != 0) {
+						eFirst = writeLane(nd[7], batch, eFirst);
+						eCount = writeLane(n, batch, eCount);
+						eMaskLo = writeLane((uint32_t)m, batch, eMaskLo);
+						eMaskHi = writeLane((uint32_t)(m >> 32), batch, eMaskHi);
+						batch = uni(batch + 1);
 					}
+				}
+				nd = nxA;
+				i = next;
+			}
+		}
+		// ---- phase 2: the noted leaves, in order.  ALL 64 lanes take part (uniform control flow): 64 references at a
+		// time, lane k classifies reference base + k against the bundle; the survivors are then tested, in the reference's
+		// order, by the lanes that passed the leaf's box.
+		const uint32_t lane = laneNow();
+		for (uint32_t e = 0; e < batch; e = uni(e + 1)) {
+			const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)eFirst, e), n = (uint32_t)__builtin_amdgcn_readlane((int)eCount, e);
+			const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)eMaskLo, e) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)eMaskHi, e) << 32;
+			const bool pass = (m >> lane) & 1ull;
+			bool improved = false;
+			for (uint32_t base = 0; base < n; base = uni(base + 64)) {
+				const uint32_t r = first + base + lane;
+				const f4v va = *(const RTX_AS1 f4v*)(refA + (r << 4)), vb = *(const RTX_AS1 f4v*)(refB + (r << 4));
+				const f2v vc = *(const RTX_AS1 f2v*)(refC + (r << 3));
+				RefA ra; RefB rb; RefC rc;
+				ra.v0x = va.x; ra.v0y = va.y; ra.v0z = va.z; ra.tri = __float_as_uint(va.w);
+				rb.e1x = vb.x; rb.e1y = vb.y; rb.e1z = vb.z; rb.e2x = vb.w; rc.e2y = vc.x; rc.e2z = vc.y;
+				FilterState fs;
+				const bool valid = base + lane < n;
+				const bool rej1 = bundleRejects1<CULL>(B, tmaxB, ra, rb, rc, fs);
+				if (STATS && RTX_DBG) cnt.wChunks++;
+				if (ballot(valid && !rej1) == 0) { if (STATS && RTX_DBG) cnt.wChunkSkips++; continue; }
+				const bool rej2 = bundleRejects2<CULL>(B, rb, rc, fs);
+				uint64_t cand = ballot(valid && !rej1 && !rej2);
+				if (STATS && RTX_DBG) { cnt.wTri += __popcll(cand); if (cand == 0) cnt.wS2++; }
+				while (cand != 0) {
+					const int c = __builtin_ctzll(cand);
+					cand &= cand - 1;
+#define RTX_RL(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), c))
+					const float v0x = RTX_RL(ra.v0x), v0y = RTX_RL(ra.v0y), v0z = RTX_RL(ra.v0z);
+					const float e1x = RTX_RL(rb.e1x), e1y = RTX_RL(rb.e1y), e1z = RTX_RL(rb.e1z);
+					const float e2x = RTX_RL(rb.e2x), e2y = RTX_RL(rc.e2y), e2z = RTX_RL(rc.e2z);
+#undef RTX_RL
+					const uint32_t tri = (uint32_t)__builtin_amdgcn_readlane((int)ra.tri, c);
+					const float before = bt;
+					if (pass) triTestOne<CULL, STATS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, tri, o, d, bt, bu, bv, btri);
+					improved = improved || bt < before;
 				}
 			}
 			// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is true
 			// for this lane no later triangle or object can change the answer.
-			if (!STATS) { if (shadow && b.t < tLimit) resume = kNever; }
+			if (!STATS) { if (shadow && bt < tLimit) resume = kNever; }
+			if (ballot(improved) != 0) {
+				// no lane can record a t that is not below its own current limit any more
+				const bool open = resume != kNever;
+				tmaxB = unif(waveMax(open ? fminf(bt, tLimit) : -__builtin_inff()));
+				if (!STATS && ballot(open) == 0) return;
+			}
 		}
-		nd = nxA;
-		i = next;
+		if (i >= nN) break;
 	}
-	bt = b.t; bu = b.u; bv = b.v; btri = b.tri;
 }
 
 template <bool STATS>
@@ -575,6 +636,7 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 	const float ix = 1 / d.x, iy = 1 / d.y, iz = 1 / d.z;
 	const bool sx = ix < 0, sy = iy < 0, sz = iz < 0;
 	bool live = active;
+	const Bundle B = makeBundle(active, o, d);
 	const uint32_t nObj = uni(P.nObjects);
 	for (uint32_t oi = 0; oi < nObj; oi = uni(oi + 1)) {
 		const Object* ob = uni(P.objects + oi);
@@ -586,8 +648,8 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 		if (type == 3) {
 			const Mesh* M = uni(P.meshes + (int)sload1(&ob->mesh));
 			float bt, bu, bv; uint32_t btri;
-			if (cull) meshWalk<STATS, true>(M, consider, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
-			else meshWalk<STATS, false>(M, consider, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+			if (cull) meshWalk<STATS, true>(M, B, consider, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+			else meshWalk<STATS, false>(M, B, consider, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 			if (bt < kFltMax && bt < h.t) { h.obj = (int)oi; h.t = bt; h.tri = btri; h.u = bu; h.v = bv; }   // scene.cpp:740-745
 		}
 		else {

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds librtx_hip.so variants for A/B runs on the GPU box: tools/build_variants.sh "name1:-DFLAGS" "name2:-DFLAGS" ...
+# -> rendering_amd/_variants/librtx_<name>.so (benchmarked by tools/bench_variants.sh)
+cd "$(dirname "$0")/.."
+mkdir -p rendering_amd/_variants build/var
+rm -f rendering_amd/_variants/librtx_*.so
+for spec in "$@"; do
+  name=${spec%%:*}; defs=${spec#*:}
+  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Rpass-analysis=kernel-resource-usage $defs \
+    -o rendering_amd/_variants/librtx_$name.so rendering_amd/csrc/rtx_api.hip 2> build/var/$name.log || { echo "$name FAILED"; tail -5 build/var/$name.log; }
+    grep -E 'Function Name|VGPRs:|ScratchSize|Occupancy' build/var/$name.log | sed -e 's/.*usage-analysis..//' -e 's/remark: [^ ]* *//' -e 's/ \[-Rpass.*//' | paste - - - - | grep -E 'Pass1KernelILb0' | sed "s/^/$name: /" ) &
+done
+wait
