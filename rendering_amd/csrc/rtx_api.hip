@@ -578,7 +578,7 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	HIPCHK(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
 	out->rays = c[0]; out->box_tests = c[1]; out->tri_tests = c[2]; out->moot_rays = c[15];
 	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] slowest work item %.3f ms, sum of items %.3f ms (100 MHz wall clock)\n", c[3] * 1e-5, c[4] * 1e-5);
-	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] wave-level: node visits %llu, triangle iterations %llu (%.1f lanes in exec), reached u-stage %llu, division %llu, v-stage %llu; leaf visits %llu, skipped whole by certificate %llu; chunk visits %llu, skipped %llu\n", c[5], c[6], c[6] ? (double)c[14] / c[6] : 0.0, c[7], c[8], c[9], c[10], c[11], c[12], c[13]);
+	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] wave-level: node visits %llu, reached leaves %llu, filter passes (64 references) %llu, of which rejected whole by stage 1 %llu, by stage 2 %llu; survivors tested exactly %llu\n", c[5], c[10], c[12], c[13], c[7], c[6]);
 #if RTX_DBG
 	if (getenv("RTX_DEBUG_ITEMS")) {
 		std::vector<unsigned long long> w(3 * 16384);

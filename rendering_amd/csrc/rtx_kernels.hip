@@ -480,9 +480,19 @@ __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, floa
 	// culling on: reject iff det < 1e-8 (then |det| < 1e-8 is implied); off: reject iff |det| < 1e-8.  Both compares
 	// are false for NaN, exactly like the reference's two ifs (objects.cpp:75-79).
 	if ((CULL ? det : fabsf(det)) < RTX_EPS8) return;
-	const float inv = 1 / det;
 	const float tx = o.x - v0x, ty = o.y - v0y, tz = o.z - v0z;                    // tvec = orig - v0 (objects.cpp:82)
-	const float u = (tx * px + ty * py + tz * pz) * inv;
+	const float nu = tx * px + ty * py + tz * pz;
+	if (CULL) {
+		// Exact-safe rejection before the IEEE division.  Here 1e-8 <= det, so inv = RN(1/det) > 0 with relative
+		// error <= 2^-22 (2^-24 while 1/det is normal, <= 2^-22 in the denormal range det > 2^126), and u = RN(nu*inv):
+		//   nu < -2^-20            =>  |nu*inv| >= 2^-20 * 2^-128 * (1 - 2^-3) > 2^-149: no underflow to -0  =>  u < 0;
+		//   nu > RN(det*(1+2^-20)) =>  nu/det > 1+2^-21, and the roundings lose < 2^-21                    =>  u > 1.
+		// Lanes outside these sure cases take the division, which re-derives the same verdict for the sure cases, so the
+		// result is bit-identical either way; the wave skips the division when no lane needs it.
+		if (nu < -0x1p-20f || nu > det * (1.0f + 0x1p-20f)) return;
+	}
+	const float inv = 1 / det;
+	const float u = nu * inv;
 	if (u < 0 || u > 1) return;
 	const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;   // tvec x v0v1
 	const float v = (d.x * qx + d.y * qy + d.z * qz) * inv;
@@ -498,7 +508,7 @@ __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, floa
 // rays).  The two phases alternate every RTX_LEAF_BATCH leaves so that any-hit shadow rays still stop early.
 // A hit exists iff bt < FLT_MAX on return (the first accepted t is < FLT_MAX by objects.cpp:598,623).
 #ifndef RTX_LEAF_BATCH
-#define RTX_LEAF_BATCH 16
+#define RTX_LEAF_BATCH 8
 #endif
 template <bool STATS, bool CULL>
 __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
@@ -551,7 +561,8 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				fail = fail || (tmin > tzmax) || (tzmin > tmx);
 				const bool pass = act && !fail;
 				if (act && fail) resume = nxt;
-				if (STATS) { cnt.box += __popcll(ballot(act)); if (RTX_DBG) cnt.wNodes++; }
+				if (STATS) cnt.box += __popcll(ballot(act));
+				if (RTX_DBG) cnt.wNodes++;
 				const uint64_t m = ballot(pass);
 				if (m == 0) {
 					nd = nxB;
@@ -560,7 +571,8 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				}
 				if (link < 0) {
 					const uint32_t n = (uint32_t)~link;
-					if (STATS) { cnt.tri += (unsigned long long)__popcll(m) * n; if (RTX_DBG) cnt.wLeaves++; }
+					if (STATS) cnt.tri += (unsigned long long)__popcll(m) * n;
+					if (RTX_DBG) cnt.wLeaves++;
 					if (n != 0) {
 						eFirst = writeLane(nd[7], batch, eFirst);
 						eCount = writeLane(n, batch, eCount);
@@ -592,11 +604,11 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				FilterState fs;
 				const bool valid = base + lane < n;
 				const bool rej1 = bundleRejects1<CULL>(B, tmaxB, ra, rb, rc, fs);
-				if (STATS && RTX_DBG) cnt.wChunks++;
-				if (ballot(valid && !rej1) == 0) { if (STATS && RTX_DBG) cnt.wChunkSkips++; continue; }
+				if (RTX_DBG) cnt.wChunks++;
+				if (ballot(valid && !rej1) == 0) { if (RTX_DBG) cnt.wChunkSkips++; continue; }
 				const bool rej2 = bundleRejects2<CULL>(B, rb, rc, fs);
 				uint64_t cand = ballot(valid && !rej1 && !rej2);
-				if (STATS && RTX_DBG) { cnt.wTri += __popcll(cand); if (cand == 0) cnt.wS2++; }
+				if (RTX_DBG) { cnt.wTri += __popcll(cand); if (cand == 0) cnt.wS2++; }
 				while (cand != 0) {
 					const int c = __builtin_ctzll(cand);
 					cand &= cand - 1;
@@ -1046,7 +1058,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 #if RTX_DBG
 	if (lane == 0 && (gl >> 6) < 16384) { gDbgWave[3 * (gl >> 6)] = dbgStart; gDbgWave[3 * (gl >> 6) + 1] = dbgEnd; gDbgWave[3 * (gl >> 6) + 2] = dbgBusy; }
 #endif
-	if (STATS) flushCounts(P, cnt);
+	if (STATS || RTX_DBG) flushCounts(P, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1102,7 +1114,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
 			px[0] = sum.x / 4; px[1] = sum.y / 4; px[2] = sum.z / 4;
 		}
 	}
-	if (STATS) flushCounts(P, cnt);
+	if (STATS || RTX_DBG) flushCounts(P, cnt);
 }
 
 // Re-orders the eight pass-1 queues by the cost the tiles had in the previous launch of the same view (heaviest first:

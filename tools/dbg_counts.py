@@ -11,7 +11,7 @@ g = RA.Scene(scene, W, H)
 fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
 g.render_pass1(fb)
 torch.cuda.synchronize()
-g.counters_enable(True)
+g.counters_enable(not os.environ.get('DBG_PRODUCT'))
 g.counters_reset()
 g.render_pass1(fb)
 torch.cuda.synchronize()

@@ -1,4 +1,4 @@
 # GPU box: RTX_DBG build -> wave-level counters of one instrumented pass 1, then restores the product build
 RTX_DEFS="-DRTX_DBG=${1:-1}" ./build.sh > gpurun_out/build_dbg.log 2>&1
-RTX_DEBUG_ITEMS=1 python tools/dbg_counts.py 2>&1 | grep -v amdgpu.ids
+DBG_PRODUCT=$2 RTX_DEBUG_ITEMS=1 python tools/dbg_counts.py 2>&1 | grep -v amdgpu.ids
 ./build.sh > /dev/null 2>&1
