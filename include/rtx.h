@@ -197,6 +197,32 @@ int rtx_tile_cost_read(rtx_scene* scene, uint32_t* out, size_t n);
  * rtx_sobel needs no exchange of pass-1 results.  band_height == 0 restores "all rows" (the default). */
 int rtx_set_row_ownership(rtx_scene* scene, uint32_t band_height, uint32_t n_parts, uint32_t part, int halo);
 
+/* Multi-GPU (SURVEY.md 8e, 8b `rtx_gather`): one process per GPU; the scene is replicated, the rows of a frame are dealt
+ * out with rtx_set_row_ownership(band, n_ranks, rank, halo = 1), every rank renders / masks / re-renders its own rows, and
+ * rtx_gather delivers all rows to ONE rank.  The reference's Scene::render (scene.cpp:595-606) runs in one address
+ * space, so it has no counterpart of this step; a maintainer calls it between launchSSAA and saveImage.
+ * Transport: RCCL (librccl.so.1, loaded on first use) -- every owned band is one ncclSend from its owner straight into
+ * its final place in root's buffer (a band of rows is a contiguous slab), all inside one ncclGroup: xGMI links are
+ * point-to-point, so the owners' transfers use different links in parallel.  Bootstrap: rank 0 obtains an id with
+ * rtx_comm_unique_id and hands its RTX_COMM_ID_BYTES bytes to the other ranks by any means (pipe, file, MPI,
+ * torch.distributed); every rank then calls rtx_comm_create.  One GPU per rank (RCCL refuses two ranks on one device). */
+#define RTX_COMM_ID_BYTES 128
+typedef struct rtx_comm rtx_comm;
+int rtx_comm_unique_id(void* id128);
+int rtx_comm_create(const void* id128, int n_ranks, int rank, int device, rtx_comm** out);
+int rtx_comm_info(const rtx_comm* comm, int* n_ranks, int* rank);
+void rtx_comm_destroy(rtx_comm* comm);
+/* img_dev: an image of `height` rows of row_bytes bytes each on this rank's device -- the fp32 framebuffer
+ * (row_bytes = W*12, bottom_up = 0) or the BGR8 image of rtx_quantize_bgr8 (row_bytes = W*3, bottom_up = 1: image row y
+ * is stored at row H-1-y, util.cpp:50).  On return (asynchronously, on `stream`) rank `root`'s buffer holds every
+ * rank's owned rows; the other ranks' buffers are unchanged.  The scene's row ownership must be (band, n_ranks, rank). */
+int rtx_gather(rtx_scene* scene, rtx_comm* comm, void* img_dev, size_t row_bytes, int bottom_up, int root, void* stream);
+/* The transfer list rtx_gather executes (host-only, no GPU needed; used by the tests): band k = image rows
+ * [k*band_height, min((k+1)*band_height, height)), owned by rank k % n_parts, stored at byte `offset[k]`, `bytes[k]` long.
+ * Writes at most max_bands entries, returns the number of bands in *n_bands. */
+int rtx_gather_plan(uint32_t height, uint32_t band_height, uint32_t n_parts, size_t row_bytes, int bottom_up, uint32_t max_bands,
+                    uint32_t* owner, size_t* offset, size_t* bytes, uint32_t* n_bands);
+
 /* Probe rays (host buffers, synchronous): for each of n rays {orig xyz, dir xyz} runs Render::trace
  * (scene.cpp:724-756) and Render::castRay at depth 0 (scene.cpp:758-946).
  * hits: n x 8 floats = [hit 0/1, object index, triangle index (-1 unless mesh), tNear, u, v, 0, 0];

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 LIB_RTX = os.path.join(HERE, "librtx_hip.so")
 LIB_HOST = os.path.join(HERE, "librendering_host.so")
 
-__all__ = ["load", "Scene", "RtxError", "device_count", "math_probe", "exported_symbols"]
+__all__ = ["load", "Scene", "Comm", "RtxError", "device_count", "math_probe", "gather_plan", "exported_symbols"]
 
 
 class RtxError(RuntimeError):
@@ -38,6 +38,7 @@ RTX_SYMBOLS = [
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
     "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
     "rtx_bvh_build", "rtx_bvh_info", "rtx_bvh_read", "rtx_bvh_destroy",
+    "rtx_comm_unique_id", "rtx_comm_create", "rtx_comm_info", "rtx_comm_destroy", "rtx_gather", "rtx_gather_plan",
 ]
 
 
@@ -80,9 +81,17 @@ def load():
     rtx.rtx_bvh_read.argtypes = [vp, vp, vp, vp, vp, vp]
     rtx.rtx_bvh_destroy.argtypes = [vp]
     rtx.rtx_bvh_destroy.restype = None
+    rtx.rtx_comm_unique_id.argtypes = [vp]
+    rtx.rtx_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    rtx.rtx_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rtx.rtx_comm_destroy.argtypes = [vp]
+    rtx.rtx_comm_destroy.restype = None
+    rtx.rtx_gather.argtypes = [vp, vp, vp, C.c_size_t, i32, i32, vp]
+    rtx.rtx_gather_plan.argtypes = [u32, u32, u32, C.c_size_t, i32, u32, vp, vp, vp, C.POINTER(u32)]
     host.rah_set_ac_build.argtypes = [i32, i32]
     host.rah_set_ac_build.restype = None
     host.rah_bvh_build_info.argtypes = [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    host.rah_last_error.restype = C.c_char_p
     host.rah_scene_load.restype = vp
     host.rah_scene_load.argtypes = [C.c_char_p, C.c_char_p, i32, i32]
     host.rah_scene_free.argtypes = [vp]
@@ -104,6 +113,8 @@ def load():
     host.rah_tris.argtypes = [vp, i32, vp]
     host.rah_camera.argtypes = [vp, vp, vp, vp, vp]
     host.rah_scene_digest.argtypes = [vp, vp, i32]
+    host.rah_view_flags.argtypes = [vp]
+    host.rah_load_bmp.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), vp, i32]
     _rtx, _host = rtx, host
     return rtx, host
 
@@ -160,6 +171,46 @@ def bvh_build(tri_pos, root_lo, root_hi, ac_penalty=1, device=0):
         rtx.rtx_bvh_destroy(b)
 
 
+def gather_plan(height, band_height, n_parts, row_bytes, bottom_up=False):
+    """rtx_gather_plan: [(owner, byte offset, bytes), ...] -- the transfers rtx_gather executes (host only)."""
+    rtx, _ = load()
+    n = C.c_uint32(0)
+    cap = (height + band_height - 1) // band_height
+    owner = np.zeros(cap, np.uint32); off = np.zeros(cap, np.uint64); ln = np.zeros(cap, np.uint64)
+    _check(rtx.rtx_gather_plan(height, band_height, n_parts, row_bytes, int(bottom_up), cap, _np_ptr(owner), _np_ptr(off), _np_ptr(ln), C.byref(n)),
+           "rtx_gather_plan")
+    return [(int(owner[i]), int(off[i]), int(ln[i])) for i in range(n.value)]
+
+
+class Comm:
+    """RCCL communicator behind the C ABI (rtx_comm_*): one rank per GPU.  `exchange(id_bytes_or_None)` must hand rank 0's
+    128-byte id to every rank (e.g. a torch.distributed / MPI broadcast, a pipe): it receives the id on rank 0 and None
+    elsewhere, and returns the id on every rank."""
+
+    def __init__(self, n_ranks, rank, device, exchange):
+        self.rtx, _ = load()
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            _check(self.rtx.rtx_comm_unique_id(buf), "rtx_comm_unique_id")
+        raw = exchange(bytes(buf) if rank == 0 else None)
+        if len(raw) != 128:
+            raise RtxError("communicator id must be 128 bytes")
+        self.h = C.c_void_p()
+        _check(self.rtx.rtx_comm_create(raw, n_ranks, rank, device, C.byref(self.h)), "rtx_comm_create")
+        self.n_ranks, self.rank = n_ranks, rank
+
+    def gather(self, scene, img, bottom_up=False, root=0, stream=None):
+        """rtx_gather: every rank's owned rows of the device tensor img (H, ...) end up in rank `root`'s img."""
+        row_bytes = img[0].numel() * img.element_size()
+        _check(self.rtx.rtx_gather(scene.gpu(), self.h, C.c_void_p(img.data_ptr()), row_bytes, int(bottom_up), root,
+                                   Scene._stream_ptr(stream)), "rtx_gather")
+
+    def close(self):
+        if self.h:
+            self.rtx.rtx_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 def math_probe(op, x, y=None, device=0):
     """Evaluates the device math the parity contract depends on (see rtx_math_probe in include/rtx.h)."""
     rtx, _ = load()
@@ -184,7 +235,7 @@ class Scene:
         self.rtx, self.host = load()
         self.h = C.c_void_p(self.host.rah_scene_load(cwd.encode(), scene_path.encode(), width, height))
         if not self.h:
-            raise RtxError("could not load scene %s" % scene_path)
+            raise RtxError("could not load scene %s: %s" % (scene_path, self.host.rah_last_error().decode(errors="replace")))
         self.device = device
         self.host.rah_scene_set_device(self.h, device)
         self._dims()
@@ -216,6 +267,10 @@ class Scene:
         self.host.rah_camera(self.h, C.byref(scale), C.byref(aspect), _np_ptr(m), _np_ptr(pos))
         return np.float32(scale.value), np.float32(aspect.value), m, pos
 
+    def view_flags(self):
+        """rtx_view::flags this scene uploads (bit 0 back-face culling, bit 1 skybox)."""
+        return self.host.rah_view_flags(self.h)
+
     def digest(self):
         """Numeric fields of all objects and lights as uploaded (loader tests)."""
         out = np.zeros(4096, np.float32)
@@ -244,6 +299,8 @@ class Scene:
     def gpu(self):
         """rtx_scene* of the uploaded scene (flatten + upload on first use; re-applies the view after resize)."""
         self._gpu = C.c_void_p(self.host.rah_scene_gpu(self.h))
+        if not self._gpu:
+            raise RtxError("no GPU scene: %s" % self.host.rah_last_error().decode(errors="replace"))
         return self._gpu
 
     @staticmethod

@@ -90,8 +90,11 @@ struct rtx_scene {
 	std::vector<TileQueues> tileQueues;   // a few entries: a frame may be rendered in several row ranges
 	uint64_t tileUse = 0;
 	// HIP-event pairs around every launch of {pass 1, sobel, ssaa} since the last rtx_kernel_time_reset
+	// By default only the most recent pair is kept (rtx_last_kernel_ms); rtx_kernel_time_reset starts accumulating
+	// pairs for rtx_kernel_time_stats, up to kMaxTimedLaunches per kernel (later launches overwrite the last pair).
 	std::vector<hipEvent_t> evPool[3];
 	size_t evUsed[3] = { 0, 0, 0 };
+	bool evCollect = false;
 };
 
 namespace {
@@ -110,6 +113,9 @@ int setView(rtx_scene* s, const rtx_view* v)
 	if (d.maxDepth < 0) d.maxDepth = -1;
 	return RTX_OK;
 }
+
+constexpr size_t kMaxTimedLaunches = 4096;
+constexpr uint32_t kSsaaSpreadSlots = 1u << 20;
 
 int ensureWork(rtx_scene* s)
 {
@@ -150,7 +156,9 @@ int ensureWork(rtx_scene* s)
 		HIPCHK(hipMemset(s->tileCost, 0, tiles * sizeof(uint32_t)));
 		s->tileCap = tiles;
 	}
-	const size_t pixels = tiles * 64;     // every tile's pixels, padded to whole tiles
+	// every tile's pixels padded to whole waves, plus kSsaaSpreadSlots for the tiles that get 4-pixel waves (a slot budget
+	// enforced on the device by rtxSsaaCountKernel: a tile over the budget is packed normally)
+	const size_t pixels = tiles * 64 + kSsaaSpreadSlots;
 	if (pixels > s->ssaaPixCap) {
 		if (s->ssaaPixels) HIPCHK(hipFree(s->ssaaPixels));
 		s->ssaaPixels = nullptr; s->ssaaPixCap = 0;
@@ -167,8 +175,11 @@ int ensureWork(rtx_scene* s)
 }
 
 // Records an event on `st`; events come in (start, stop) pairs per launch.
+
 int stamp(rtx_scene* s, int which, hipStream_t st)
 {
+	if ((s->evUsed[which] & 1) == 0 && s->evUsed[which] >= 2 && (!s->evCollect || s->evUsed[which] >= 2 * kMaxTimedLaunches))
+		s->evUsed[which] -= 2;          // start of a launch: recycle the previous pair
 	if (s->evUsed[which] == s->evPool[which].size()) {
 		hipEvent_t e;
 		HIPCHK(hipEventCreate(&e));
@@ -487,6 +498,7 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream;
 	HIPCHK(hipMemsetAsync(s->work + 1, 0, sizeof(uint32_t), st));
+	HIPCHK(hipMemsetAsync(s->work + 8, 0, 4 * sizeof(uint32_t), st));
 	if ((rc = stamp(s, 2, st))) return rc;
 	Params p = s->params;
 	p.fb = fb_dev;
@@ -499,16 +511,19 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	p.ssaaPixels = s->ssaaPixels;
 	if (p.nTiles == 0 || p.view.width > 0xffffu || p.view.height > 0xffffu) return fail(RTX_ERR_ARG, "frame too large for the SSAA pixel list");
 	// flagged pixels -> one packed list; tiles on which pass 1 spent more than 0.25 ms go first (wall clock = 100 MHz)
-	const uint32_t heavyTicks = 25000u, scanN = 2 * p.nTiles + 1;
+	uint32_t heavyTicks = 25000u, spreadSlots = kSsaaSpreadSlots;
+	const uint32_t scanN = 2 * p.nTiles + 1;
+	if (const char* e = getenv("RTX_SSAA_HEAVY_TICKS")) heavyTicks = (uint32_t)strtoul(e, nullptr, 10);       // test knobs
+	if (const char* e = getenv("RTX_SSAA_SPREAD_SLOTS")) spreadSlots = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), kSsaaSpreadSlots);
 	// fewer flagged pixels than two full rounds of waves: tile-local waves (see rtxSsaaCountKernel)
 	uint32_t localBelow = (uint32_t)s->blocksSsaa * 4u * 16u * 2u;
 	if (const char* e = getenv("RTX_SSAA_LOCAL_BELOW")) localBelow = (uint32_t)strtoul(e, nullptr, 10);   // test knob: 0 = always packed
-	uint32_t* mode = s->work + 8;             // [0] local mode, [1] flagged pixels
+	uint32_t* mode = s->work + 8;             // [0] local mode, [1] flagged pixels, [2] extra slots handed to 4-pixel tiles
 	uint32_t launches = 0;
-	hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, 0u, 0u);
+	hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, 0u, 0u, 0u);
 	if ((rc = scanExclusive(s->items, scanN, s->items + scanN, st, launches))) return rc;
 	HIPCHK(hipMemcpyAsync(mode + 1, s->items + 2 * (size_t)p.nTiles, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-	hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, 1u, localBelow);
+	hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, 1u, localBelow, spreadSlots);
 	if ((rc = scanExclusive(s->items, scanN, s->items + scanN, st, launches))) return rc;
 	hipLaunchKernelGGL(rtxSsaaScatterKernel, dim3((p.nTiles + 255) / 256), dim3(256), 0, st, p, s->items, mode, s->ssaaPixels, heavyTicks);
 	HIPCHK(hipGetLastError());
@@ -623,6 +638,7 @@ int rtx_kernel_time_reset(rtx_scene* s)
 {
 	if (!s) return fail(RTX_ERR_ARG, "scene is NULL");
 	for (int i = 0; i < 3; i++) s->evUsed[i] = 0;
+	s->evCollect = true;
 	return RTX_OK;
 }
 
@@ -705,3 +721,6 @@ int rtx_math_probe(int device, int op, uint32_t n, const float* x, const float* 
 
 // device-side acceleration-structure build (uses fail / HIPCHK above)
 #include "rtx_bvh.hip"
+
+// multi-GPU: RCCL communicator + frame gather (uses fail / HIPCHK above)
+#include "rtx_comm.hip"

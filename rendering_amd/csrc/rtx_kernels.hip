@@ -1167,7 +1167,7 @@ __device__ __forceinline__ uint64_t ssaaFlagged(const Params& P, uint32_t tx, ui
 // Chosen on the device (decide != 0: from the total of the previous, unpadded count): with few flagged pixels the
 // launch is bounded by its slowest wave and coherent, tile-local waves are shorter; with many, full waves win.
 __global__ void __launch_bounds__(256) rtxSsaaCountKernel(const Params P, uint32_t* __restrict__ scan, uint32_t* __restrict__ mode,
-                                                          uint32_t heavyTicks, uint32_t decide, uint32_t localBelow)
+                                                          uint32_t heavyTicks, uint32_t decide, uint32_t localBelow, uint32_t spreadSlots)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t > 2 * P.nTiles) return;
@@ -1177,8 +1177,14 @@ __global__ void __launch_bounds__(256) rtxSsaaCountKernel(const Params P, uint32
 	const uint32_t ty = t / P.tilesXFull, tx = t - ty * P.tilesXFull;
 	uint32_t nf = (uint32_t)__popcll(ssaaFlagged(P, tx, ty));
 	// local mode: a wave holds 16 pixels of one tile -- or only 4 of a tile that was VERY slow in pass 1 (a silhouette),
-	// because the launch lasts as long as its slowest wave
-	if (local) nf = P.tileCost[t] > RTX_SSAA_VERY * heavyTicks ? ((nf + 3u) >> 2) * 16u : (nf + 15u) & ~15u;
+	// because the launch lasts as long as its slowest wave.  The 4-pixel layout needs up to 4x the slots; the list holds
+	// spreadSlots extra ones (mode[2] = handed out so far), a tile that does not get its share is packed normally.  The
+	// scatter kernel recognises the layout from the tile's slot count.
+	if (local) {
+		const uint32_t packed = (nf + 15u) & ~15u, spread = ((nf + 3u) >> 2) * 16u;
+		nf = packed;
+		if (P.tileCost[t] > RTX_SSAA_VERY * heavyTicks && spread > packed && atomicAdd(mode + 2, spread - packed) + (spread - packed) <= spreadSlots) nf = spread;
+	}
 	const bool heavy = P.tileCost[t] > heavyTicks;
 	scan[t] = heavy ? nf : 0u;
 	scan[P.nTiles + t] = heavy ? 0u : nf;
@@ -1191,8 +1197,10 @@ __global__ void __launch_bounds__(256) rtxSsaaScatterKernel(const Params P, cons
 	if (t >= P.nTiles) return;
 	const uint32_t ty = t / P.tilesXFull, tx = t - ty * P.tilesXFull;
 	uint64_t m = ssaaFlagged(P, tx, ty);
-	uint32_t slot = scan[P.tileCost[t] > heavyTicks ? t : P.nTiles + t];
-	const bool spread = mode[0] && P.tileCost[t] > RTX_SSAA_VERY * heavyTicks;      // 4 pixels per group of 16 slots
+	const uint32_t idx = P.tileCost[t] > heavyTicks ? t : P.nTiles + t;
+	uint32_t slot = scan[idx];
+	const uint32_t slots = scan[idx + 1] - slot, nf = (uint32_t)__popcll(m);      // (the other half's entry of a tile is 0 slots wide)
+	const bool spread = mode[0] && slots > ((nf + 15u) & ~15u);      // 4 pixels per group of 16 slots
 	uint32_t n = 0;
 	while (m) {
 		const uint32_t pos = (uint32_t)__builtin_ctzll(m);
@@ -1200,7 +1208,7 @@ __global__ void __launch_bounds__(256) rtxSsaaScatterKernel(const Params P, cons
 		pixels[slot + n++] = (tx * 8 + (pos & 7)) | (ty * 8 + (pos >> 3)) << 16;
 		if (spread && (n & 3u) == 0) for (int k = 0; k < 12; k++) pixels[slot + n++] = 0xffffffffu;
 	}
-	if (mode[0]) for (; n & 15u; n++) pixels[slot + n] = 0xffffffffu;
+	if (mode[0]) for (; n < slots; n++) pixels[slot + n] = 0xffffffffu;
 }
 
 // ------------------------------------------------------------------------------------------------

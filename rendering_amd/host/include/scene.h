@@ -10,8 +10,11 @@
 #include "objects.h"
 #include "options.h"
 
+#include <memory>
+
 struct rtx_scene;
 struct rtx_scene_desc;
+struct rtx_comm;
 
 typedef struct { size_t x0, x1, y0, y1; } tileInfo;
 
@@ -72,11 +75,30 @@ public:
 	int device = 0;
 	rtx_scene* gpu();                          // flattens + uploads on first use; LOG_ERROR()s without a GPU
 	void invalidateView();                     // call after changing options.width/height, camera, flags
+	// Multi-GPU (one process per GPU): with a communicator of the C ABI attached (rtx_comm_create), render() renders this
+	// rank's rows only and collects the image on rank 0 (rtx_gather), which writes the file.
+	void attachComm(rtx_comm* comm, int nRanks, int rank);
 	double lastPass1Ms = 0, lastSobelMs = 0, lastSsaaMs = 0;
+	// The switches the render reads are process-global in the reference (options::useBackfaceCulling, useSkybox,
+	// collectStatistics).  A host that keeps several scenes alive (the C API in capi.cpp) pins them per scene here:
+	// -1 = follow the global (the reference's behaviour), 0 / 1 = this scene's own value.
+	int useBackfaceCulling = -1, useSkybox = -1, collectStatistics = -1;
+	bool cullingOn() const { return useBackfaceCulling < 0 ? options::useBackfaceCulling : useBackfaceCulling != 0; }
+	bool skyboxOn() const { return useSkybox < 0 ? options::useSkybox : useSkybox != 0; }
+	bool statisticsOn() const { return collectStatistics < 0 ? options::collectStatistics : collectStatistics != 0; }
+	void pinFlags() { useBackfaceCulling = options::useBackfaceCulling; useSkybox = options::useSkybox; collectStatistics = options::collectStatistics; }
 
 private:
+	struct DeviceFrame;
+	DeviceFrame& deviceFrame();                // the frame's device buffers (fp32 framebuffer, Sobel mask, BGR8 image)
+	void pass1OnDevice();
+	void ssaaOnDevice();
+	void readTimes();
 	rtx_scene* gpu_ = nullptr;
 	bool viewDirty_ = true;
+	std::unique_ptr<DeviceFrame> frame_;
+	rtx_comm* comm_ = nullptr;
+	int nRanks_ = 1, rank_ = 0;
 };
 
 // Host-side flattening used by Scene::gpu(); exposed for tests and for maintainers wiring the reference's own

@@ -7,6 +7,14 @@
 #include "geometry.h"
 #include "options.h"
 
+#include <stdexcept>
+
+// The reference's error behaviour (util.h:13-19): print "Error: <file> <func> <line>" and std::exit(-1).  Inside the C API
+// used by the Python tests / bench (capi.cpp) the same condition is thrown as HostError instead and reported through
+// rah_last_error(), so that a recoverable error (no GPU, missing asset, bad size) does not end the host process.
+struct HostError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ThrowErrorsScope { ThrowErrorsScope(); ~ThrowErrorsScope(); bool prev; };
+void noteError(const std::string& what);   // context printed before LOG_ERROR() is also kept for HostError::what()
 #define LOG_ERROR() logError(__FILE__, __FUNCTION__, __LINE__)
 [[noreturn]] void logError(const char* file, const char* func, int line);
 

@@ -8,21 +8,43 @@
 #include "stats.h"
 #include "util.h"
 
+namespace {
+thread_local std::string gLastError;
+// Runs f with LOG_ERROR() throwing instead of exiting; a thrown error is kept for rah_last_error() and `bad` is returned.
+template <typename R, typename F> R guarded(R bad, F&& f)
+{
+	ThrowErrorsScope scope;
+	try { gLastError.clear(); return f(); }
+	catch (const std::exception& e) { gLastError = e.what(); return bad; }
+}
+}
+
 extern "C" {
 
-// Loads a .scene file (relative asset paths resolve against cwd when given); w/h > 0 override the file's
-// resolution.  Process-global options:: flags are reset to their defaults first.
+const char* rah_last_error(void) { return gLastError.c_str(); }
+
+// Loads a .scene file (relative asset paths resolve against cwd when given; the process's working directory is
+// restored afterwards); w/h > 0 override the file's resolution.  The process-global options:: switches are reset to
+// their defaults for the load and the ones the render reads are then pinned on the Scene (Scene::pinFlags), so that
+// loading another scene later does not change this one.  NULL on failure (rah_last_error).
 void* rah_scene_load(const char* cwd, const char* path, int width, int height)
 {
-	options::reset();
-	options::enableOutput = false;
-	options::imageOutput = false;
-	stats::reset();
-	if (cwd && cwd[0] && chdir(cwd) != 0) return nullptr;
-	Scene* s = new Scene(path);
-	if (width > 0) s->options.width = (size_t)width;
-	if (height > 0) s->options.height = (size_t)height;
-	return s;
+	return guarded<void*>(nullptr, [&]() -> void* {
+		options::reset();
+		options::enableOutput = false;
+		options::imageOutput = false;
+		stats::reset();
+		char back[4096];
+		const bool moved = cwd && cwd[0];
+		if (moved && (!getcwd(back, sizeof(back)) || chdir(cwd) != 0)) { gLastError = "cannot change to the scene's base directory"; return nullptr; }
+		struct Restore { const char* dir; ~Restore() { if (dir && chdir(dir) != 0) {} } } restore{ moved ? back : nullptr };
+		Scene* s = new Scene(path);
+		if (!s->sceneLoadSuccess) { delete s; gLastError = std::string("could not load scene ") + path; return nullptr; }
+		if (width > 0) s->options.width = (size_t)width;
+		if (height > 0) s->options.height = (size_t)height;
+		s->pinFlags();
+		return s;
+	});
 }
 void rah_scene_free(void* h) { delete (Scene*)h; }
 
@@ -40,9 +62,11 @@ void rah_scene_resize(void* h, int w, int ht)
 void rah_scene_set_device(void* h, int device) { ((Scene*)h)->device = device; }
 void rah_set_flag(void* h, const char* name, int v)
 {
-	if (!strcmp(name, "useBackfaceCulling")) options::useBackfaceCulling = v;
-	else if (!strcmp(name, "collectStatistics")) options::collectStatistics = v;
-	((Scene*)h)->invalidateView();
+	Scene* s = (Scene*)h;
+	if (!strcmp(name, "useBackfaceCulling")) s->useBackfaceCulling = v != 0;
+	else if (!strcmp(name, "collectStatistics")) s->collectStatistics = v != 0;
+	else if (!strcmp(name, "useSkybox")) s->useSkybox = v != 0;
+	s->invalidateView();
 }
 
 // Flattened description (host arrays stay alive until rah_flat_free).
@@ -112,21 +136,38 @@ int rah_tris(void* h, int obj, float* out)
 // camera constants exactly as uploaded (rtx_view::scale/aspect/cam_matrix/cam_pos)
 void rah_camera(void* h, float* scale, float* aspect, float* m16, float* pos3)
 {
-	FlatScene* f = flattenScene(*(Scene*)h);
-	const rtx_view& v = flatDesc(f)->view;
-	*scale = v.scale; *aspect = v.aspect;
-	memcpy(m16, v.cam_matrix, 64); memcpy(pos3, v.cam_pos, 12);
-	freeFlatScene(f);
+	guarded<int>(-1, [&] {
+		FlatScene* f = flattenScene(*(Scene*)h);
+		const rtx_view& v = flatDesc(f)->view;
+		*scale = v.scale; *aspect = v.aspect;
+		memcpy(m16, v.cam_matrix, 64); memcpy(pos3, v.cam_pos, 12);
+		freeFlatScene(f);
+		return 0;
+	});
+}
+
+// rtx_view::flags this scene uploads (RTX_FLAG_*), -1 on error
+int rah_view_flags(void* h)
+{
+	return guarded<int>(-1, [&] {
+		FlatScene* f = flattenScene(*(Scene*)h);
+		const int flags = (int)flatDesc(f)->view.flags;
+		freeFlatScene(f);
+		return flags;
+	});
 }
 
 // loadBMP (util.h) into a caller buffer of `cap` bytes; returns the number of bytes the image needs (3*w*h).
+// (-1: unreadable / unsupported file, rah_last_error; -2: the image needs more than INT_MAX bytes)
 int rah_load_bmp(const char* path, int* w, int* h, unsigned char* out, int cap)
 {
-	unsigned char* d = loadBMP(path, *w, *h);
-	const int need = 3 * *w * *h;
-	if (out && cap >= need) memcpy(out, d, (size_t)need);
-	delete[] d;
-	return need;
+	return guarded<int>(-1, [&] {
+		unsigned char* d = loadBMP(path, *w, *h);
+		const size_t need = (size_t)3 * (size_t)*w * (size_t)*h;
+		if (out && cap >= 0 && (size_t)cap >= need) memcpy(out, d, need);
+		delete[] d;
+		return need > 0x7fffffffu ? -2 : (int)need;
+	});
 }
 
 // Numeric digest of objects and lights (for loader tests): per object 16 floats
@@ -159,15 +200,18 @@ int rah_scene_digest(void* h, float* out, int maxFloats)
 	return n;
 }
 
-// The uploaded GPU scene (created on first use; exits through LOG_ERROR when no GPU is available).
-rtx_scene* rah_scene_gpu(void* h) { return ((Scene*)h)->gpu(); }
+// The uploaded GPU scene (created on first use); NULL when it cannot be created, e.g. without a GPU (rah_last_error).
+rtx_scene* rah_scene_gpu(void* h) { return guarded<rtx_scene*>(nullptr, [&] { return ((Scene*)h)->gpu(); }); }
 
 // Whole-frame convenience mirroring Scene::render() into a host buffer (H*W*3 floats, zero-initialised by caller).
-void rah_render_host(void* h, float* fb, int withSsaa)
+int rah_render_host(void* h, float* fb, int withSsaa)
 {
-	Scene* s = (Scene*)h;
-	s->launchWorkers((Vec3f*)fb);
-	if (withSsaa) s->launchSSAA((Vec3f*)fb);
+	return guarded<int>(-1, [&] {
+		Scene* s = (Scene*)h;
+		s->launchWorkers((Vec3f*)fb);
+		if (withSsaa) s->launchSSAA((Vec3f*)fb);
+		return 0;
+	});
 }
 
 int rah_save_bmp(void* h, const float* fb, const char* nameNoExt)

@@ -239,7 +239,6 @@ void parseLegacyObject(Scene& sc, const std::string& line)
 
 Scene::Scene(const std::string& sceneName) { sceneLoadSuccess = loadScene(sceneName); }
 
-Scene::~Scene() { if (gpu_) rtx_scene_destroy(gpu_); }
 
 bool Scene::loadScene(const std::string& scenePath)
 {
@@ -303,6 +302,11 @@ void Scene::loadSkybox()
 	for (int k = 0; k < 6; ++k) {
 		int w = 0, h = 0;
 		std::unique_ptr<unsigned char[]> px(loadBMP(options.skyboxNames[k], w, h));
+		if (k > 0 && (w != skyboxWidth || h != skyboxHeight)) {      // the lookup uses one size for all six faces (scene.cpp:383-385)
+			std::cout << "Skybox faces differ in size: " << options.skyboxNames[k] << '\n';
+			noteError("skybox faces differ in size");
+			LOG_ERROR();
+		}
 		skyboxWidth = w; skyboxHeight = h;
 		skyboxes[k].resize((size_t)w * h);
 		for (size_t i = 0; i < skyboxes[k].size(); ++i) {
@@ -353,7 +357,7 @@ void fillView(Scene& sc, rtx_view& v)
 	v.width = (uint32_t)sc.options.width; v.height = (uint32_t)sc.options.height;
 	v.bias = sc.options.bias; v.max_ray_depth = sc.options.maxRayDepth;
 	put3(v.background, sc.options.backgroundColor);
-	v.flags = (options::useBackfaceCulling ? RTX_FLAG_BACKFACE_CULL : 0u) | (options::useSkybox ? RTX_FLAG_SKYBOX : 0u);
+	v.flags = (sc.cullingOn() ? RTX_FLAG_BACKFACE_CULL : 0u) | (sc.skyboxOn() ? RTX_FLAG_SKYBOX : 0u);
 	put3(v.cam_pos, sc.camera.pos);
 	for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) v.cam_matrix[i * 4 + j] = sc.camera.rMatrix[i][j];
 	v.scale = tanf(sc.camera.fov * 0.5f / 180.0f * (float)(3.14159265358979323846));   // scene.cpp:447
@@ -438,7 +442,7 @@ FlatScene* flattenScene(Scene& sc)
 	fs->desc.n_objects = (uint32_t)fs->objects.size(); fs->desc.objects = fs->objects.data();
 	fs->desc.n_meshes = (uint32_t)fs->meshes.size(); fs->desc.meshes = fs->meshes.data();
 	fs->desc.n_lights = (uint32_t)fs->lights.size(); fs->desc.lights = fs->lights.data();
-	if (options::useSkybox && sc.skyboxWidth > 0) {
+	if (sc.skyboxOn() && sc.skyboxWidth > 0) {
 		fs->desc.sky_w = (uint32_t)sc.skyboxWidth; fs->desc.sky_h = (uint32_t)sc.skyboxHeight;
 		for (int k = 0; k < 6; ++k) fs->desc.sky[k] = &sc.skyboxes[k][0].x;   // Vec3f is 3 packed floats
 	}
@@ -456,6 +460,7 @@ void gpuCheck(int rc, const char* what)
 {
 	if (rc == RTX_OK) return;
 	std::cout << what << " failed: " << rtx_last_error() << '\n';
+	noteError(std::string(what) + " failed: " + rtx_last_error());
 	LOG_ERROR();
 }
 }
@@ -512,53 +517,102 @@ rtx_scene* Scene::gpu()
 }
 
 namespace {
-struct DeviceFrame {
-	float* fb = nullptr; uint8_t* mask = nullptr;
-	~DeviceFrame() { if (fb) (void)hipFree(fb); if (mask) (void)hipFree(mask); }
-};
 void hipCheck(hipError_t e, const char* what)
 {
 	if (e == hipSuccess) return;
 	std::cout << what << ": " << hipGetErrorString(e) << '\n';
+	noteError(std::string(what) + ": " + hipGetErrorString(e));
 	LOG_ERROR();
 }
 }
 
+// The frame lives in HBM across pass 1, the Sobel mask and the 4-ray pass (one allocation per Scene, re-used by every
+// render): the host sees it once, at the end.
+struct Scene::DeviceFrame {
+	float* fb = nullptr; uint8_t* mask = nullptr; uint8_t* bgr = nullptr;
+	size_t pixels = 0;
+	~DeviceFrame() { if (fb) (void)hipFree(fb); if (mask) (void)hipFree(mask); if (bgr) (void)hipFree(bgr); }
+};
+
+Scene::~Scene()
+{
+	frame_.reset();
+	if (gpu_) rtx_scene_destroy(gpu_);
+}
+
+Scene::DeviceFrame& Scene::deviceFrame()
+{
+	const size_t px = options.width * options.height;
+	hipCheck(hipSetDevice(device), "hipSetDevice");
+	if (!frame_ || frame_->pixels != px) {
+		frame_.reset(new DeviceFrame);
+		hipCheck(hipMalloc((void**)&frame_->fb, px * sizeof(Vec3f)), "hipMalloc");
+		hipCheck(hipMalloc((void**)&frame_->mask, px), "hipMalloc");
+		hipCheck(hipMalloc((void**)&frame_->bgr, px * 3), "hipMalloc");
+		frame_->pixels = px;
+	}
+	return *frame_;
+}
+
+void Scene::pass1OnDevice()
+{
+	rtx_scene* g = gpu();
+	DeviceFrame& d = deviceFrame();
+	gpuCheck(rtx_counters_enable(g, statisticsOn()), "rtx_counters_enable");
+	gpuCheck(rtx_render_pass1(g, 0, (uint32_t)options.height, d.fb, nullptr), "rtx_render_pass1");
+}
+
+void Scene::ssaaOnDevice()
+{
+	rtx_scene* g = gpu();
+	DeviceFrame& d = deviceFrame();
+	gpuCheck(rtx_counters_enable(g, statisticsOn()), "rtx_counters_enable");
+	gpuCheck(rtx_sobel(g, d.fb, 0, (uint32_t)options.height, d.mask, nullptr), "rtx_sobel");
+	gpuCheck(rtx_render_ssaa(g, d.mask, 0, (uint32_t)options.height, d.fb, nullptr), "rtx_render_ssaa");
+}
+
+void Scene::readTimes()
+{
+	float ms = 0;
+	if (rtx_last_kernel_ms(gpu_, 0, &ms) == RTX_OK) lastPass1Ms = ms;
+	if (rtx_last_kernel_ms(gpu_, 1, &ms) == RTX_OK) lastSobelMs = ms;
+	if (rtx_last_kernel_ms(gpu_, 2, &ms) == RTX_OK) lastSsaaMs = ms;
+}
+
+// The reference's entry points keep their meaning for a caller that owns a host framebuffer (scene.h:68-100): the
+// workers write their pixels into it and leave the others alone, so the buffer is uploaded, updated and copied back.
+// Scene::render() does not go through them: it keeps the frame on the device.
 void Scene::launchWorkers(Vec3f* frameBuffer)
 {
 	Timer t("Render scene");
-	rtx_scene* g = gpu();
+	DeviceFrame& d = deviceFrame();
 	const size_t bytes = options.width * options.height * sizeof(Vec3f);
-	DeviceFrame d;
-	hipCheck(hipSetDevice(device), "hipSetDevice");
-	hipCheck(hipMalloc((void**)&d.fb, bytes), "hipMalloc");
 	hipCheck(hipMemcpy(d.fb, frameBuffer, bytes, hipMemcpyHostToDevice), "hipMemcpy");
-	gpuCheck(rtx_counters_enable(g, options::collectStatistics), "rtx_counters_enable");
-	gpuCheck(rtx_render_pass1(g, 0, (uint32_t)options.height, d.fb, nullptr), "rtx_render_pass1");
+	pass1OnDevice();
 	hipCheck(hipMemcpy(frameBuffer, d.fb, bytes, hipMemcpyDeviceToHost), "hipMemcpy");
-	float ms = 0;
-	if (rtx_last_kernel_ms(g, 0, &ms) == RTX_OK) lastPass1Ms = ms;
+	readTimes();
 }
 
 void Scene::launchSSAA(Vec3f* frameBuffer)
 {
 	Timer t("MSAA");
-	rtx_scene* g = gpu();
+	DeviceFrame& d = deviceFrame();
 	const size_t bytes = options.width * options.height * sizeof(Vec3f);
-	DeviceFrame d;
-	hipCheck(hipSetDevice(device), "hipSetDevice");
-	hipCheck(hipMalloc((void**)&d.fb, bytes), "hipMalloc");
-	hipCheck(hipMalloc((void**)&d.mask, options.width * options.height), "hipMalloc");
 	hipCheck(hipMemcpy(d.fb, frameBuffer, bytes, hipMemcpyHostToDevice), "hipMemcpy");
-	gpuCheck(rtx_counters_enable(g, options::collectStatistics), "rtx_counters_enable");
-	gpuCheck(rtx_sobel(g, d.fb, 0, (uint32_t)options.height, d.mask, nullptr), "rtx_sobel");
-	gpuCheck(rtx_render_ssaa(g, d.mask, 0, (uint32_t)options.height, d.fb, nullptr), "rtx_render_ssaa");
+	ssaaOnDevice();
 	hipCheck(hipMemcpy(frameBuffer, d.fb, bytes, hipMemcpyDeviceToHost), "hipMemcpy");
-	float ms = 0;
-	if (rtx_last_kernel_ms(g, 1, &ms) == RTX_OK) lastSobelMs = ms;
-	if (rtx_last_kernel_ms(g, 2, &ms) == RTX_OK) lastSsaaMs = ms;
+	readTimes();
 }
 
+void Scene::attachComm(rtx_comm* comm, int nRanks, int rank)
+{
+	comm_ = comm; nRanks_ = nRanks < 1 ? 1 : nRanks; rank_ = rank;
+}
+
+// Scene::render (scene.cpp:595-606): pass 1, the adaptive 4-ray pass, saveImage.  The frame stays in HBM; what comes
+// back to the host is the BGR8 image saveImage writes (3 bytes per pixel instead of 4 x 12).  With a communicator
+// attached (one process per GPU) this rank renders its own 64-row bands, and the bands are collected on rank 0 with
+// rtx_gather (RCCL over xGMI) -- rank 0 writes the file.
 void Scene::render()
 {
 	if (!sceneLoadSuccess) return;
@@ -567,11 +621,34 @@ void Scene::render()
 		std::cout << "showAC / showNormals / useAC=0 are debug modes outside the accelerated hot path\n";
 		LOG_ERROR();
 	}
-	std::vector<Vec3f> frameBuffer(options.width * options.height);    // zero-initialised (scene.cpp:599)
-	launchWorkers(frameBuffer.data());
-	if (options::enableSSAA) launchSSAA(frameBuffer.data());
-	if (options::imageOutput) saveImage(frameBuffer.data(), options);
-	if (options::collectStatistics) {
+	rtx_scene* g = gpu();
+	DeviceFrame& d = deviceFrame();
+	const bool sharded = comm_ && nRanks_ > 1;
+	gpuCheck(rtx_set_row_ownership(g, sharded ? 64u : 0u, (uint32_t)nRanks_, (uint32_t)rank_, 1), "rtx_set_row_ownership");
+	hipCheck(hipMemset(d.fb, 0, options.width * options.height * sizeof(Vec3f)), "hipMemset");    // new Vec3f[H*W]() (scene.cpp:599)
+	{
+		Timer tp("Render scene");
+		pass1OnDevice();
+		hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+	}
+	if (options::enableSSAA) {
+		Timer ts("MSAA");
+		ssaaOnDevice();
+		hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+	}
+	readTimes();
+	if (options::imageOutput || sharded) {
+		if (options.width % 4 != 0) { std::cout << "saveImage is only defined for width % 4 == 0 (util.cpp:28-29)\n"; LOG_ERROR(); }
+		gpuCheck(rtx_quantize_bgr8(g, d.fb, d.bgr, nullptr), "rtx_quantize_bgr8");
+		if (sharded) gpuCheck(rtx_gather(g, comm_, d.bgr, options.width * 3, 1, 0, nullptr), "rtx_gather");
+		hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+		if (options::imageOutput && rank_ == 0) {
+			std::vector<unsigned char> bgr(options.width * options.height * 3);
+			hipCheck(hipMemcpy(bgr.data(), d.bgr, bgr.size(), hipMemcpyDeviceToHost), "hipMemcpy");
+			saveImageBGR(bgr.data(), options);
+		}
+	}
+	if (statisticsOn()) {
 		rtx_counters c{};
 		if (rtx_counters_read(gpu(), &c) == RTX_OK) {
 			stats::raysCasted = c.rays; stats::accelStructTests = c.box_tests; stats::rayTriTests = c.tri_tests;

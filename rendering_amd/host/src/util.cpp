@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <iomanip>
 #include <iostream>
 #include <sstream>
@@ -13,10 +14,19 @@
 #include "stats.h"
 #include "timer.h"
 
+namespace {
+thread_local bool gThrowErrors = false;
+thread_local std::string gErrorNote;
+}
+ThrowErrorsScope::ThrowErrorsScope() : prev(gThrowErrors) { gThrowErrors = true; gErrorNote.clear(); }
+ThrowErrorsScope::~ThrowErrorsScope() { gThrowErrors = prev; }
+void noteError(const std::string& what) { gErrorNote = what; }
+
 void logError(const char* file, const char* func, int line)
 {
 	// same message and exit status as the reference (util.h:13-19)
 	std::cout << "Error: " << file << ' ' << func << ' ' << line << std::endl;
+	if (gThrowErrors) throw HostError((gErrorNote.empty() ? std::string() : gErrorNote + " -- ") + "Error: " + file + " " + func + " " + std::to_string(line));
 	std::exit(-1);
 }
 
@@ -110,21 +120,29 @@ unsigned char* loadBMP(const char* filename, int& width, int& height)
 	uint32_t dataOffset; int32_t w, h; uint16_t bpp;
 	memcpy(&dataOffset, hdr + 10, 4); memcpy(&w, hdr + 18, 4); memcpy(&h, hdr + 22, 4); memcpy(&bpp, hdr + 28, 2);
 	const bool topDown = h < 0;
+	// the header is not trusted: dimensions are bounded (also rules out -INT_MIN), the pixel data must fit the file
+	constexpr int32_t kMaxDim = 32768;
+	if (w <= 0 || w > kMaxDim || h == 0 || h < -kMaxDim || h > kMaxDim || (bpp != 24 && bpp != 32)) {
+		fclose(f); std::cout << "Unsupported BMP (need 24/32 bpp, 1..32768 pixels a side): " << filename << '\n'; noteError(std::string("unsupported BMP ") + filename); LOG_ERROR();
+	}
 	if (topDown) h = -h;
-	if (w <= 0 || h <= 0 || (bpp != 24 && bpp != 32)) { fclose(f); std::cout << "Unsupported BMP (need 24/32 bpp): " << filename << '\n'; LOG_ERROR(); }
 	width = w; height = h;
 	if (dataOffset < 54) dataOffset = 54;
 	const size_t bytesPP = bpp / 8, rowBytes = ((size_t)w * bytesPP + 3) & ~(size_t)3;
+	long fileSize = -1;
+	if (fseek(f, 0, SEEK_END) == 0) fileSize = ftell(f);
+	if (fileSize < 0 || (size_t)fileSize < (size_t)dataOffset || fseek(f, (long)dataOffset, SEEK_SET) != 0) {
+		fclose(f); std::cout << "Truncated BMP: " << filename << '\n'; noteError(std::string("truncated BMP ") + filename); LOG_ERROR();
+	}
 	std::vector<unsigned char> row(rowBytes);
-	unsigned char* data = new unsigned char[(size_t)3 * w * h];
-	fseek(f, (long)dataOffset, SEEK_SET);
+	unsigned char* data = new unsigned char[(size_t)3 * (size_t)w * (size_t)h];
 	for (int y = 0; y < h; ++y) {
 		if (fread(row.data(), 1, rowBytes, f) != rowBytes) memset(row.data(), 0, rowBytes);   // truncated file: black
-		unsigned char* dst = data + (size_t)3 * w * (topDown ? (h - 1 - y) : y);             // keep file order = bottom-up
+		unsigned char* dst = data + (size_t)3 * (size_t)w * (size_t)(topDown ? (h - 1 - y) : y);             // keep file order = bottom-up
 		for (int x = 0; x < w; ++x) {
-			dst[x * 3 + 0] = row[x * bytesPP + 2];     // BGR -> RGB
-			dst[x * 3 + 1] = row[x * bytesPP + 1];
-			dst[x * 3 + 2] = row[x * bytesPP + 0];
+			dst[(size_t)x * 3 + 0] = row[(size_t)x * bytesPP + 2];     // BGR -> RGB
+			dst[(size_t)x * 3 + 1] = row[(size_t)x * bytesPP + 1];
+			dst[(size_t)x * 3 + 2] = row[(size_t)x * bytesPP + 0];
 		}
 	}
 	fclose(f);

@@ -6,8 +6,10 @@ Per frame and rank:
     pass 1 on the owned bands + a 1-row halo (recomputed, so the Sobel mask needs no exchange)
     Sobel mask + adaptive 4-ray pass on the owned rows
     quantise to BGR8 (what saveImage writes, util.cpp:46-58; 4x fewer bytes than the fp32 framebuffer)
-    ONE exchange: every owned band is sent to rank 0 as a point-to-point message, placed directly (gather_frame).
-The scene (<= ~60 MB) is replicated on every GPU.
+    ONE exchange: every owned band is sent to rank 0 as a point-to-point message, placed directly -- rtx_gather of the
+    C ABI (RCCL, include/rtx.h); make_comm() bootstraps its communicator over an existing torch.distributed group.
+The scene (<= ~60 MB) is replicated on every GPU.  gather_frame() is the same exchange over torch.distributed
+point-to-point operations; it exists for the CPU (gloo) tests and for boxes where the ranks have to share a device.
 """
 import numpy as np
 
@@ -61,3 +63,19 @@ def gather_frame(img, n_parts, part, band=BAND, dst=0, group=None, bottom_up=Fal
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return img
+
+
+def make_comm(n_parts, part, device, group=None):
+    """rendering_amd.Comm (rtx_comm_create) for the ranks of a torch.distributed group: rank 0's RCCL id is broadcast
+    as a byte tensor over that group (any backend)."""
+    import torch
+    import torch.distributed as dist
+    import rendering_amd as RA
+
+    def exchange(raw):
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor(list(raw), dtype=torch.uint8, device=dev) if raw is not None else torch.zeros(128, dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0, group=group)
+        return bytes(t.cpu().tolist())
+
+    return RA.Comm(n_parts, part, device, exchange)

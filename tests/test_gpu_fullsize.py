@@ -241,3 +241,41 @@ def test_cpp_cli_writes_reference_bmp(ra, tmp_path):
     assert "Render scene" in out.stdout and "MSAA" in out.stdout        # the reference's timer names
     bmp = open(work / "output" / "simple_shapes.bmp", "rb").read()
     assert hashlib.md5(bmp).hexdigest() == "d96bcb5498c89ae781d4f508d31f0b51"
+
+
+def test_comm_single_rank_and_gather_noop(ra, torch_cuda):
+    """rtx_comm_* / rtx_gather through RCCL with one rank (the box has one GPU; RCCL refuses two ranks on one device):
+    the library loads, the communicator initialises, a 1-rank gather leaves the image alone, teardown is clean."""
+    torch = torch_cuda
+    c = ra.Comm(1, 0, 0, lambda raw: raw)
+    g = ra.Scene("scenes/cfg1_simple_shapes.scene", 64, 64)
+    fb, _ = render(torch, g)
+    img = torch.zeros((64, 64, 3), dtype=torch.uint8, device="cuda")
+    g.quantize(fb, img)
+    before = img.clone()
+    c.gather(g, img, bottom_up=True)
+    torch.cuda.synchronize()
+    assert torch.equal(before, img)
+    c.close()
+
+
+def test_cpp_cli_multi_gpu(ra, tmp_path):
+    """`render_amd --gpus 2 <scene>`: two processes, one GPU each, bands collected on rank 0 by rtx_gather -- the BMP is
+    the single-GPU one.  On a box with one GPU the launcher must refuse (exit status 2) instead of hanging."""
+    import hashlib
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    work = tmp_path / "run"
+    (work / "output").mkdir(parents=True)
+    (work / "scenes").mkdir()
+    shutil.copy(os.path.join(root, "scenes", "cfg1_simple_shapes.scene"), work / "scenes")
+    out = subprocess.run([os.path.join(root, "rendering_amd", "render_amd"), "--gpus", "2", "scenes/cfg1_simple_shapes.scene"],
+                         cwd=work, capture_output=True, text=True, timeout=300)
+    if ra.device_count() < 2:
+        assert out.returncode == 2 and "one rank per GPU" in out.stderr
+        return
+    assert out.returncode == 0, out.stdout + out.stderr
+    bmp = open(work / "output" / "simple_shapes.bmp", "rb").read()
+    assert hashlib.md5(bmp).hexdigest() == "d96bcb5498c89ae781d4f508d31f0b51"

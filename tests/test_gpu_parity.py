@@ -120,6 +120,36 @@ def test_ssaa_list_modes_bit_exact(ra, oracle, monkeypatch, local_below):
         assert ndiff(ref, got) == 0
 
 
+@pytest.mark.parametrize("spread_slots", ["1048576", "4096", "0"])
+def test_ssaa_four_pixel_waves_and_slot_budget(ra, oracle, monkeypatch, spread_slots):
+    """Tile-local SSAA list with EVERY tile classified as very slow (knob: threshold of 1 tick), so that every tile asks
+    for the 4-pixels-per-wave layout (4x the slots): with a full, a partly and a fully exhausted slot budget the list
+    never overruns (tiles over the budget are packed normally) and the frame is the reference's."""
+    monkeypatch.setenv("RTX_SSAA_LOCAL_BELOW", "4000000000")
+    monkeypatch.setenv("RTX_SSAA_HEAVY_TICKS", "1")
+    monkeypatch.setenv("RTX_SSAA_SPREAD_SLOTS", spread_slots)
+    for name, w, h in (("cfg2_smooth_4k", 320, 240), ("cfg3_reflective_refractive", 240, 136)):
+        path = "scenes/%s.scene" % name
+        o = oracle.OracleScene(path, w, h)
+        g = ra.Scene(path, w, h)
+        ref = o.ssaa(o.pass1())
+        got = g.render_host(ssaa=True)
+        assert ndiff(ref, got) == 0
+
+
+def test_event_pool_does_not_grow(ra):
+    """Launch timing keeps one event pair per kernel unless rtx_kernel_time_reset asked for accumulation."""
+    g = ra.Scene("scenes/cfg1_simple_shapes.scene", 64, 64)
+    for _ in range(50):
+        g.render_host(ssaa=True)
+    assert g.kernel_time_stats(0)[0] == 1 and g.kernel_time_stats(2)[0] == 1
+    g.kernel_time_reset()
+    for _ in range(3):
+        g.render_host(ssaa=True)
+    n, ms = g.kernel_time_stats(0)
+    assert n == 3 and ms > 0
+
+
 def test_tile_cost_map(ra):
     """rtx_tile_cost_read: one entry per 8x8 tile of the frame; tiles on the mesh cost more than background tiles."""
     g = ra.Scene("scenes/cfg2_smooth_4k.scene", 160, 120)

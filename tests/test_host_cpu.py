@@ -134,3 +134,38 @@ def test_bmp_loader_hardening(ra, tmp_path):
     write(tmp_path / "off.bmp", img, extra=84); assert np.array_equal(load(tmp_path / "off.bmp"), ref)
     odd = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)            # 7*3 = 21 bytes per row -> 3 bytes of padding
     write(tmp_path / "odd.bmp", odd); assert np.array_equal(load(tmp_path / "odd.bmp"), odd[::-1])
+
+
+def test_errors_are_reported_not_fatal(ra, tmp_path):
+    """Recoverable host errors (missing scene, malformed BMP header, no GPU) come back as RtxError through the C API
+    instead of ending the process with the reference's LOG_ERROR() exit."""
+    import ctypes as C
+    import struct
+    import torch
+    with pytest.raises(ra.RtxError):
+        ra.Scene("scenes/does_not_exist.scene")
+    _, host = ra.load()
+    w, h = C.c_int(), C.c_int()
+    for hdr_w, hdr_h in ((1 << 30, 1 << 30), (16, -(1 << 31)), (0, 4), (70000, 4)):
+        p = tmp_path / "bad.bmp"
+        p.write_bytes(b"BM" + struct.pack("<IHHI", 54, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, hdr_w, hdr_h, 1, 24, 0, 0, 2835, 2835, 0, 0))
+        assert host.rah_load_bmp(str(p).encode(), C.byref(w), C.byref(h), None, 0) == -1
+        assert b"BMP" in host.rah_last_error()
+    if not torch.cuda.is_available():
+        s = ra.Scene("scenes/cfg1_simple_shapes.scene", 64, 64)
+        with pytest.raises(ra.RtxError):
+            s.gpu()
+
+
+def test_scene_flags_are_per_scene(ra):
+    """Loading a second scene does not change the switches an earlier one uploads (the reference keeps them in
+    process-global options::; the C API pins them per Scene)."""
+    a = ra.Scene("scenes/cfg3_reflective_refractive.scene", 64, 64)       # sets the skybox switch
+    assert a.view_flags() == 3
+    b = ra.Scene("scenes/cfg1_simple_shapes.scene", 64, 64)
+    assert b.view_flags() == 1
+    assert a.view_flags() == 3
+    b.set_flag("useBackfaceCulling", 0)
+    assert b.view_flags() == 0 and a.view_flags() == 3
+    import os
+    assert os.getcwd() == os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # the loader restored the cwd

@@ -67,3 +67,21 @@ def test_owned_rows_partition():
     for H, band, n in ((4096, 64, 8), (1080, 64, 4), (88, 16, 2), (10, 64, 3)):
         allrows = np.concatenate([parallel.owned_rows(H, band, n, r) for r in range(n)])
         assert sorted(allrows.tolist()) == list(range(H))
+
+
+def test_gather_plan_matches_band_ranges(ra):
+    """rtx_gather_plan (the transfer list of rtx_gather, C ABI) against the Python statement of the same banding."""
+    from rendering_amd import parallel
+    for H, band, parts, rb, bu in ((4096, 64, 8, 4096 * 3, True), (203, 64, 2, 316 * 12, False), (1080, 64, 3, 1920 * 3, True), (64, 64, 4, 12, False)):
+        plan = ra.gather_plan(H, band, parts, rb, bu)
+        want = []
+        for y0 in range(0, H, band):
+            y1 = min(y0 + band, H)
+            want.append(((y0 // band) % parts, (H - y1 if bu else y0) * rb, (y1 - y0) * rb))
+        assert plan == want
+        for part in range(parts):
+            mine = [(o, n) for r, o, n in plan if r == part]
+            assert mine == [((H - y1 if bu else y0) * rb, (y1 - y0) * rb) for y0, y1 in parallel.band_ranges(H, band, parts, part)]
+        # the slabs tile the image exactly once
+        cover = sorted((o, n) for _, o, n in plan)
+        assert cover[0][0] == 0 and all(cover[i][0] + cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1)) and cover[-1][0] + cover[-1][1] == H * rb
