@@ -72,7 +72,13 @@ def cpu_baseline(scene_path, width, height, gpu_scene, target_s=15.0):
     cores = os.cpu_count() or 1
     ref = reference_baseline(scene_path, width, height, gpu_scene, cores) if os.environ.get("BENCH_CPU_BASELINE", "reference") == "reference" else None
     if ref is not None:
+        # the oracle port on a shorter sample beside it, so that the line can be compared where oracle/_ref is absent
+        ref["port"] = cpu_baseline_port(scene_path, width, height, gpu_scene, target_s=8.0)
         return ref
+    return cpu_baseline_port(scene_path, width, height, gpu_scene, target_s)
+
+
+def cpu_baseline_port(scene_path, width, height, gpu_scene, target_s=15.0):
     from oracle import oracle as O
     o = O.OracleScene(scene_path, width, height)
     band = 32
@@ -111,26 +117,62 @@ def cpu_baseline(scene_path, width, height, gpu_scene, target_s=15.0):
             "sample": "pass 1 (Scene::launchWorkers) of the %dx%d frame, %s: %d rays in %.1f s" % (width, height, what, rays, ms * 1e-3)}
 
 
-def measured_traffic():
-    """HBM bytes per pass-1 launch from a separate rocprofv3 --pmc run of this same command (tools/pmc.sh,
-    FETCH_SIZE and WRITE_SIZE in separate passes, KB -> bytes); committed under profiles/.  None if absent."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pass1_traffic.json")))
-        return int(d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"])
-    except Exception:
-        return None
+VALU_PEAK_GINSTR = 1024 * 2.4 / 4      # 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles per SIMD, 2.4 GHz (profiles/r01_pmc_sq.txt: measured 4.16-4.4 cycles)
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pass1_pmc.json")
+ISA_JSON = os.path.join(ROOT, "profiles", "r02_pass1_isa.json")
 
 
-def valu_issue(avg_ms):
-    """Fraction of the VALU issue rate (the kernel's real bound) the pass-1 launch achieves: VALU
-    wave-instructions per launch (SQ_INSTS_VALU of a separate rocprofv3 --pmc run of this command, committed under
-    profiles/) over what 1024 SIMDs issue in the measured duration at one instruction per 4 cycles, 2.4 GHz."""
+def stamped(path):
+    """A profiles/ summary is quoted only if it was measured on the kernel sources this run uses (tools/srchash.py)."""
+    from tools.srchash import source_hash
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pass1_traffic.json")))
-        n = float(d["SQ_INSTS_VALU_per_launch"])
-        return {"instructions_per_launch": n, "peak_per_s": 1024 * 2.4e9 / 4, "frac": round(n / (avg_ms * 1e-3) / (1024 * 2.4e9 / 4), 4)}
+        d = json.load(open(path))
     except Exception:
-        return None
+        return None, "missing: regenerate with tools/pmc_pass1.sh / tools/isa_mix.py"
+    if d.get("source_hash") != source_hash():
+        return None, "stale: measured on sources %s, running %s -- regenerate with tools/pmc_pass1.sh / tools/isa_mix.py" % (d.get("source_hash"), source_hash())
+    return d, None
+
+
+def pmc_roofline(avg_ms, scene_bytes, fb_bytes):
+    """Hardware-counter side of the roofline of rtxPass1Kernel<false>: VALU wave-instructions and HBM-side bytes per
+    launch from profiles/r02_pass1_pmc.json (tools/pmc_pass1.sh: separate rocprofv3 --pmc passes of this command), over
+    the launch duration measured live in THIS run."""
+    d, why = stamped(PMC_JSON)
+    if d is None:
+        return {"counters": None, "note": why}
+    k = [v for n, v in d["kernels"].items() if "Pass1Kernel<false>" in n]
+    if not k:
+        return {"counters": None, "note": "no pass-1 kernel in " + os.path.basename(PMC_JSON)}
+    k = k[0]
+    valu = k["SQ_INSTS_VALU"]
+    # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced streaming reads (the leaf-reference
+    # stream: 16 B per lane) -- doubled; WRITE_SIZE as reported.  KB -> bytes.
+    fetch = 2.0 * k["FETCH_SIZE"] * 1024.0
+    write = k["WRITE_SIZE"] * 1024.0
+    sec = avg_ms * 1e-3
+    out = {"valu_instructions": valu, "valu_ginstr_s": valu / sec / 1e9,
+           "hbm": {"fetch_bytes": int(fetch), "write_bytes": int(write), "achieved_GBs": round((fetch + write) / sec / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
+                   "frac": round((fetch + write) / sec / 1e9 / HBM_PEAK_GBS, 4),
+                   "compulsory_bytes": int(scene_bytes + fb_bytes),
+                   "traffic_over_compulsory": round((fetch + write) / max(scene_bytes + fb_bytes, 1), 2),
+                   "l2_hit_rate": round(k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]), 3) if "TCC_HIT_sum" in k else None},
+           "sq": {c: k[c] for c in k if c.startswith("SQ_")}, "source_hash": d["source_hash"]}
+    isa, _ = stamped(ISA_JSON)
+    if isa is not None:
+        out["static_valu_mix"] = isa["valu_fraction_by_class"]
+        out["spills"] = {"vgpr": isa.get("vgpr_spill_count"), "sgpr": isa.get("sgpr_spill_count"), "scratch_bytes_per_lane": isa.get("private_segment_fixed_size")}
+    return out
+
+
+CONFIGS = {
+    "headline": ("scenes/cfg2_smooth_250k.scene", 4096, 4096),
+    "cfg1": ("scenes/cfg1_simple_shapes.scene", 512, 512),
+    "cfg2": ("scenes/cfg2_smooth_250k.scene", 1920, 1080),
+    "cfg3": ("scenes/cfg3_reflective_refractive.scene", 1920, 1080),
+    "cfg4": ("scenes/cfg4_textured_1024.scene", 4096, 4096),
+    "cfg5": ("scenes/cfg2_smooth_250k.scene", 8192, 8192),
+}
 
 
 def main():
@@ -138,13 +180,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="scenes/cfg2_smooth_250k.scene")
-    ap.add_argument("--width", type=int, default=4096)
-    ap.add_argument("--height", type=int, default=4096)
+    ap.add_argument("--config", default="headline", choices=sorted(CONFIGS),
+                    help="BASELINE.json workload: headline = the metric's own (250k scene at 4096^2, every N); cfg5 = the same scene at 8192^2; cfg1..cfg4 = the other configs")
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ssaa", action="store_true")
     ap.add_argument("--verify", action="store_true", help="N > 1: rank 0 also renders the whole frame alone and compares the gathered image with it")
     args = ap.parse_args()
+    cscene, cw, ch = CONFIGS[args.config]
+    args.scene = args.scene or cscene
+    args.width = args.width or cw
+    args.height = args.height or ch
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -180,6 +228,26 @@ def main():
     ssaa = not args.no_ssaa
 
     img = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") if world > 1 else None
+    # N > 1: the frame is collected by rtx_gather of the C ABI (RCCL communicator created here, its id broadcast over the
+    # torch.distributed group).  BENCH_GATHER=torch selects the same exchange written with torch.distributed
+    # point-to-point operations; it is also what runs if the RCCL communicator cannot be created (reported in the line).
+    comm, gather_via = None, None
+    if world > 1 and backend == "nccl":
+        gather_via = "torch.distributed P2P over RCCL"
+        if os.environ.get("BENCH_GATHER", "rtx") == "rtx":
+            try:
+                comm = parallel.make_comm(world, rank, local)
+                gather_via = "rtx_gather (C ABI, grouped ncclSend/ncclRecv over RCCL)"
+            except Exception as e:          # noqa: BLE001 -- reported, not hidden
+                gather_via = "torch.distributed P2P over RCCL (rtx_comm_create failed: %s)" % e
+                print("bench.py: " + gather_via, file=sys.stderr, flush=True)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 0 and comm is not None:      # some rank failed: every rank uses the torch path
+            comm.close(); comm = None
+            gather_via = "torch.distributed P2P over RCCL (rtx_comm_create failed on another rank)"
+    elif world > 1:
+        gather_via = "torch.distributed P2P over %s, staged through host memory (functional check)" % backend
 
     def step():
         parallel.shard_frame(scene, fb, mask, world, rank, ssaa=ssaa)
@@ -187,7 +255,9 @@ def main():
             # the frame has to end up in ONE place: quantise to the BGR8 image saveImage writes (4x fewer bytes than
             # the fp32 framebuffer) and send every owned band straight into rank 0's image
             scene.quantize(fb, img)
-            if backend == "nccl":
+            if comm is not None:
+                comm.gather(scene, img, bottom_up=True)
+            elif backend == "nccl":
                 parallel.gather_frame(img, world, rank, bottom_up=True)
             else:
                 host = img.cpu()
@@ -252,12 +322,36 @@ def main():
         sync()
     n1, ms1 = scene.kernel_time_stats(0)
     n2, ms2 = scene.kernel_time_stats(2)
-    # algorithmic bytes of ONE pass-1 launch: 32 B per box test + 40 B per triangle test counted
-    # under reference traversal semantics + 12 B per rendered pixel
+    avg_ms = ms1 / max(n1, 1)
+    # cold frame: a freshly created scene in the warm process -- its first pass 1 has no tile costs of a previous launch to
+    # order its queues by (the reference's use case is one frame per process)
+    cold_ms = None
+    if world == 1:
+        scene2 = RA.Scene(args.scene, W, H, device=local)
+        scene2.gpu()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        parallel.shard_frame(scene2, fb, mask, 1, 0, ssaa=ssaa)
+        torch.cuda.synchronize()
+        cold_ms = (time.perf_counter() - tc) * 1e3
+        scene2.close()
+    # The SURVEY 8d byte model (32 B per box test + 40 B per triangle test counted under REFERENCE traversal semantics
+    # + 12 B per rendered pixel) is kept as a description of the reference's work -- the kernel shares every fetch among
+    # 64 rays and rejects whole groups of triangles without touching them per ray, so it is not what bounds the kernel.
     rendered_px = (W - 1) * (H - 1) / world
     alg_bytes = 32.0 * float(c1[1]) + 40.0 * float(c1[2]) + 12.0 * rendered_px
-    avg_ms = ms1 / max(n1, 1)
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    walked = rays_per_frame - int(tot[3])
+    roof = {"bound": "valu_issue", "kernel": "rtxPass1Kernel<false>", "avg_launch_ms": round(avg_ms, 3), "launches_timed": n1,
+            "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINSTR, "achieved": None, "frac": None, "traffic": None,
+            "algorithmic_ref_semantics_bytes": int(alg_bytes), "box_tests": int(c1[1]), "tri_tests": int(c1[2])}
+    if world == 1:
+        pm = pmc_roofline(avg_ms, scene.scene_bytes(), 12.0 * rendered_px)
+        if pm.get("valu_instructions"):
+            roof["achieved"] = round(pm["valu_ginstr_s"], 1)
+            roof["frac"] = round(min(pm["valu_ginstr_s"] / VALU_PEAK_GINSTR, 1.0), 4)
+            roof["frac_unclamped"] = round(pm["valu_ginstr_s"] / VALU_PEAK_GINSTR, 4)
+            roof["traffic"] = pm["hbm"]["fetch_bytes"] + pm["hbm"]["write_bytes"]
+        roof["counters"] = pm
     out = {
         "metric": "Mrays/s + ms/frame at 4096^2, 250k-tri BVH scene",
         "value": round(rays_per_frame * args.steps / dt / 1e6, 3),
@@ -267,16 +361,16 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s @%dx%d, pass 1%s" % (os.path.basename(args.scene), W, H, " + Sobel-adaptive SSAA" if ssaa else ""),
-                   "rays_per_frame": rays_per_frame, "moot_shadow_rays": int(tot[3]), "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.BAND, world, ", BGR8 bands sent to rank 0 over RCCL" if world > 1 else ""),
+                   "name": args.config,
+                   "rays_per_frame": rays_per_frame, "moot_shadow_rays": int(tot[3]),
+                   "walked_rays_per_frame": walked, "walked_mrays_s": round(walked * args.steps / dt / 1e6, 3),
+                   "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.BAND, world, ", BGR8 bands collected on rank 0" if world > 1 else ""),
+                   "gather": gather_via,
                    "pass1_ms": round(avg_ms, 3), "ssaa_ms": round(ms2 / max(n2, 1), 3),
+                   "cold_frame_ms": None if cold_ms is None else round(cold_ms, 3),
                    "pass1_rays_rank0": int(c1[0]), "ssaa_rays_rank0": int(c2[0]), "ssaa_pixels_rank0": int(mask.sum()),
                    "ssaa_box_tests": int(c2[1]), "ssaa_tri_tests": int(c2[2])},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
-                     "kernel": "rtxPass1Kernel", "avg_launch_ms": round(avg_ms, 3),
-                     "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "box_tests": int(c1[1]), "tri_tests": int(c1[2]),
-                     "valu_issue": valu_issue(avg_ms) if world == 1 else None},
+        "roofline": roof,
     }
     if verified is not None:
         out["config"]["gathered_image_equals_single_gpu_image"] = verified

@@ -132,6 +132,8 @@ int rtx_device_count(int* count);
 /* Flatten-and-upload, once per scene (replaces nothing in the reference: its Scene is read in place). */
 int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out);
 void rtx_scene_destroy(rtx_scene* scene);
+/* Bytes of scene data rtx_scene_create placed in HBM (nodes, leaf references, shading arrays, texture maps, skybox). */
+int rtx_scene_bytes(rtx_scene* scene, size_t* bytes);
 /* Change resolution / camera / flags without re-uploading geometry. */
 int rtx_scene_set_view(rtx_scene* scene, const rtx_view* view);
 

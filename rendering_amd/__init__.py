@@ -33,7 +33,7 @@ _host = None
 
 # every entry point declared in include/rtx.h
 RTX_SYMBOLS = [
-    "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_set_view",
+    "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_set_view", "rtx_scene_bytes",
     "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_quantize_bgr8", "rtx_render_frame_host",
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
     "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
@@ -81,6 +81,7 @@ def load():
     rtx.rtx_bvh_read.argtypes = [vp, vp, vp, vp, vp, vp]
     rtx.rtx_bvh_destroy.argtypes = [vp]
     rtx.rtx_bvh_destroy.restype = None
+    rtx.rtx_scene_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     rtx.rtx_comm_unique_id.argtypes = [vp]
     rtx.rtx_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     rtx.rtx_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -361,6 +362,11 @@ class Scene:
         _check(self.rtx.rtx_counters_read(self.gpu(), C.byref(c)), "rtx_counters_read")
         self.moot_rays = int(c.moot_rays)      # shadow rays that cannot influence the pixel (only the instrumented variant traces them)
         return np.array([c.rays, c.box_tests, c.tri_tests], np.int64)
+
+    def scene_bytes(self):
+        n = C.c_size_t(0)
+        _check(self.rtx.rtx_scene_bytes(self.gpu(), C.byref(n)), "rtx_scene_bytes")
+        return n.value
 
     def last_kernel_ms(self, which=0):
         ms = C.c_float(0)

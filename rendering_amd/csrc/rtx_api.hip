@@ -38,12 +38,15 @@ struct DevBuf {
 	~DevBuf() { if (p) (void)hipFree(p); }
 };
 
+thread_local size_t gUploadedBytes = 0;     // bytes uploaded by the rtx_scene_create in progress
+
 template <typename T> int upload(std::vector<void*>& owned, const T* src, size_t count, const T** out)
 {
 	*out = nullptr;
 	if (!src || count == 0) return RTX_OK;
 	void* d = nullptr;
 	HIPCHK(hipMalloc(&d, count * sizeof(T)));
+	gUploadedBytes += count * sizeof(T);
 	owned.push_back(d);
 	HIPCHK(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));
 	*out = (const T*)d;
@@ -70,6 +73,7 @@ struct rtx_scene {
 	int device = 0;
 	int numCUs = 0;
 	std::vector<void*> owned;     // device allocations freed on destroy
+	size_t sceneBytes = 0;        // bytes of scene data resident in HBM (nodes, leaf references, shading arrays, maps, skybox)
 	Params params;                // template of the kernel argument block
 	bool stats = false;
 	// lazily sized work buffers
@@ -218,6 +222,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 	HIPCHK(hipGetDeviceProperties(&prop, device));
 
 	rtx_scene* s = new rtx_scene;
+	gUploadedBytes = 0;
 	s->device = device;
 	s->numCUs = prop.multiProcessorCount;
 	memset(&s->params, 0, sizeof(Params));
@@ -313,6 +318,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 	}
 	if ((rc = setView(s, &desc->view))) return bail(rc);
 	if ((rc = ensureWork(s))) return bail(rc);
+	s->sceneBytes = gUploadedBytes;
 	*out = s;
 	return RTX_OK;
 }
@@ -653,6 +659,13 @@ int rtx_kernel_time_stats(rtx_scene* s, int which, uint32_t* launches, double* t
 		HIPCHK(hipEventElapsedTime(&ms, s->evPool[which][i], s->evPool[which][i + 1]));
 		*total_ms += ms; (*launches)++;
 	}
+	return RTX_OK;
+}
+
+int rtx_scene_bytes(rtx_scene* s, size_t* bytes)
+{
+	if (!s || !bytes) return fail(RTX_ERR_ARG, "scene/bytes is NULL");
+	*bytes = s->sceneBytes;
 	return RTX_OK;
 }
 

@@ -1,0 +1,81 @@
+"""Instruction-class breakdown of the pass-1 kernel from the compiler's ISA (build/*.s, written by build.sh):
+whole kernel and per innermost loop.  python tools/isa_mix.py [round tag] -> profiles/<tag>_pass1_isa.json
+Classes: packed fp32 arithmetic (v_pk_*), plain arithmetic (mul/add/fma/max/min/...), compare + select, cross-lane
+(readlane / writelane / DPP / mbcnt), moves, VMEM, SMEM, SALU, other."""
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from srchash import source_hash, ROOT
+
+KERNEL = "_Z14rtxPass1KernelILb0EEvN4rtxd6ParamsE"
+
+
+def klass(op, line):
+    if op.startswith("v_pk_"):
+        return "valu_packed_arith"
+    if op.startswith(("v_cmp", "v_cndmask")):
+        return "valu_cmp_select"
+    if op.startswith(("v_readlane", "v_writelane", "v_readfirstlane", "v_mbcnt")) or "row_" in line or "quad_perm" in line:
+        return "valu_cross_lane"
+    if op.startswith(("v_mov", "v_accvgpr")):
+        return "valu_mov"
+    if op.startswith("v_"):
+        return "valu_plain_arith"
+    if op.startswith(("global_", "flat_", "buffer_", "scratch_")):
+        return "vmem"
+    if op.startswith("s_load") or op.startswith("s_buffer_load"):
+        return "smem"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith("s_waitcnt") or op.startswith("s_nop"):
+        return "wait_nop"
+    if op.startswith("s_"):
+        return "salu"
+    return "other"
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    path = os.path.join(ROOT, "build", "rtx_api-hip-amdgcn-amd-amdhsa-gfx950.s")
+    lines = open(path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
+    total = {}
+    loops = {}
+    cur = ("top", 0)
+    for ln in lines[start + 1:]:
+        t = ln.strip()
+        if t.startswith("s_endpgm"):
+            break
+        m = re.search(r"in Loop: Header=(\S+) Depth=(\d+)", ln) or re.search(r"^(\.LBB\S+):.*Loop Header: Depth=(\d+)", ln)
+        if m:
+            cur = (m.group(1).rstrip(":").lstrip("."), int(m.group(2)))
+        if not t or t.startswith((";", ".")) or t.endswith(":"):
+            continue
+        op = t.split()[0]
+        k = klass(op, t)
+        total[k] = total.get(k, 0) + 1
+        d = loops.setdefault("%s (depth %d)" % cur, {})
+        d[k] = d.get(k, 0) + 1
+    valu = sum(v for k, v in total.items() if k.startswith("valu_"))
+    res = {"source_hash": source_hash(), "kernel": "rtxPass1Kernel<false>", "what": "static instruction counts from " + os.path.basename(path),
+           "kernel_total": total, "valu_total": valu,
+           "valu_fraction_by_class": {k: round(v / valu, 4) for k, v in total.items() if k.startswith("valu_")},
+           "by_innermost_loop": {k: v for k, v in sorted(loops.items(), key=lambda kv: -sum(kv[1].values()))}}
+    txt = open(path).read()
+    i = txt.index(".name:           " + KERNEL)
+    blk = txt[max(0, i - 1500):i + 1500]
+    for key in ("sgpr_count", "vgpr_count", "sgpr_spill_count", "vgpr_spill_count", "private_segment_fixed_size"):
+        m = re.search(r"\.%s:\s+(\d+)" % key, blk)
+        if m:
+            res[key] = int(m.group(1))
+    json.dump(res, open(os.path.join(ROOT, "profiles", "%s_pass1_isa.json" % tag), "w"), indent=1)
+    print(json.dumps({k: res[k] for k in res if k != "by_innermost_loop"}, indent=1))
+    for k, v in list(res["by_innermost_loop"].items())[:8]:
+        print(k, v)
+
+
+if __name__ == "__main__":
+    main()
