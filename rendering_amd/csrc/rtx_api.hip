@@ -272,6 +272,27 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		if ((rc = upload(s->owned, m.normal_map, (size_t)m.normal_w * m.normal_h * 3, &dm.normal))) return bail(rc);
 		if ((rc = upload(s->owned, m.specular_map, (size_t)m.specular_w * m.specular_h, &dm.specular))) return bail(rc);
 		dm.nNodes = m.n_nodes; dm.nRefs = m.n_refs; dm.nTris = m.n_tris;
+		{
+			// mean edge length of the referenced triangles -> width above which a ray bundle is split (performance only)
+			double sum = 0; size_t cnt = 0;
+			const size_t stride = m.n_refs > 65536 ? m.n_refs / 65536 : 1;
+			for (size_t r = 0; r < m.n_refs; r += stride) {
+				const RefB& b = refB[r]; const RefC& c = refC[r];
+				const double l1 = std::sqrt((double)b.e1x * b.e1x + (double)b.e1y * b.e1y + (double)b.e1z * b.e1z);
+				const double l2 = std::sqrt((double)b.e2x * b.e2x + (double)c.e2y * c.e2y + (double)c.e2z * c.e2z);
+				if (std::isfinite(l1 + l2)) { sum += l1 + l2; cnt += 2; }
+			}
+			float factor = 3.0f;
+			if (const char* e = getenv("RTX_FAT_FACTOR")) factor = strtof(e, nullptr);       // tuning knob; 0 = never split
+			dm.fatRadius = cnt && factor > 0 ? (float)(sum / (double)cnt) * factor : INFINITY;
+			double rad = 0;
+			for (int c = 0; c < 3; c++) {
+				const double lo = m.n_nodes ? m.node_bounds[c] : 0.0, hi = m.n_nodes ? m.node_bounds[3 + c] : 0.0;
+				dm.centre[c] = (float)(0.5 * (lo + hi)); rad += 0.25 * (hi - lo) * (hi - lo);
+			}
+			dm.radius = (float)std::sqrt(rad);
+			if (!std::isfinite(dm.radius)) { dm.radius = 0; dm.fatRadius = INFINITY; }
+		}
 		dm.dW = m.diffuse_w; dm.dH = m.diffuse_h; dm.nW = m.normal_w; dm.nH = m.normal_h; dm.sW = m.specular_w; dm.sH = m.specular_h;
 	}
 	std::vector<Object> objs(desc->n_objects);

@@ -50,6 +50,9 @@ struct Mesh {
 	uint32_t nNodes, nRefs, nTris;
 	uint32_t dW, dH, nW, nH, sW, sH;
 	uint32_t pad;
+	// bundle splitting (rtx_kernels.hip, traceWave): a wave's rays are walked as ONE bundle unless the bundle is wider than
+	// fatRadius at this mesh (a few mean triangle edges); centre / radius = bounding sphere of the root box
+	float fatRadius, centre[3], radius;
 };
 
 struct Object {

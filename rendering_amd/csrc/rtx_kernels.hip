@@ -77,6 +77,8 @@ __device__ __forceinline__ uint32_t laneNow()
 // lane `lane` (wave-uniform) of v := val (wave-uniform); the lane select goes through m0 (constant-bus limit of gfx9)
 __device__ __forceinline__ uint32_t writeLane(uint32_t val, uint32_t lane, uint32_t v)
 {
+	val = __builtin_amdgcn_readfirstlane(val); lane = __builtin_amdgcn_readfirstlane(lane);      // (folded away when already scalar)
+	asm("" : "+s"(val));      // a register, never a literal (v_writelane_b32 takes no 32-bit literal on gfx9)
 	asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(lane) : "m0");
 	return v;
 }
@@ -507,6 +509,9 @@ __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, floa
 // order (phase 2: bundle filter with the lanes acting as triangles, exact test of the survivors with the lanes acting as
 // rays).  The two phases alternate every RTX_LEAF_BATCH leaves so that any-hit shadow rays still stop early.
 // A hit exists iff bt < FLT_MAX on return (the first accepted t is < FLT_MAX by objects.cpp:598,623).
+#ifndef RTX_EXP
+#define RTX_EXP 0     // timing experiments only (wrong pictures): 1 no exact tests, 2 node walk only, 3 no walk at all
+#endif
 #ifndef RTX_LEAF_BATCH
 #define RTX_LEAF_BATCH 8
 #endif
@@ -522,6 +527,9 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 	const uint32_t nN = uni(sload1(&M->nNodes));
 	bt = kFltMax; bu = 0; bv = 0; btri = 0;
 	if (nN == 0) return;
+#if RTX_EXP == 3
+	return;       // experiment: cost of everything but the walk
+#endif
 	// the largest limit of any ray of the wave: a triangle whose t is certainly not below it cannot be recorded by any
 	// lane (tightened whenever a lane finds a closer hit)
 	float tmaxB = unif(waveMax(consider ? tLimit : -__builtin_inff()));
@@ -559,6 +567,14 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				if (tymax < tmx) tmx = tymax;
 				const float tzmin = sz ? zhi : zlo, tzmax = sz ? zlo : zhi;
 				fail = fail || (tmin > tzmax) || (tzmin > tmx);
+#if RTX_EXP == 7
+				{ f2 oxx2 = oxx; asm volatile("" : "+v"(oxx2));      // experiment: box test twice
+				  const f2 cx = (f2{ F(nd[0]), F(nd[1]) } - oxx2) * ixx, cy = (f2{ F(nd[2]), F(nd[3]) } - oyy) * iyy, cz = (f2{ F(nd[4]), F(nd[5]) } - ozz) * izz;
+				  float a0 = sx ? cx.y : cx.x, a1 = sx ? cx.x : cx.y; const float b0 = sy ? cy.y : cy.x, b1 = sy ? cy.x : cy.y;
+				  bool f2_ = (a0 > b1) || (b0 > a1); if (b0 > a0) a0 = b0; if (b1 < a1) a1 = b1;
+				  const float c0 = sz ? cz.y : cz.x, c1 = sz ? cz.x : cz.y; f2_ = f2_ || (a0 > c1) || (c0 > a1);
+				  fail = fail && f2_; }
+#endif
 				const bool pass = act && !fail;
 				if (act && fail) resume = nxt;
 				if (STATS) cnt.box += __popcll(ballot(act));
@@ -589,6 +605,9 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 		// time, lane k classifies reference base + k against the bundle; the survivors are then tested, in the reference's
 		// order, by the lanes that passed the leaf's box.
 		const uint32_t lane = laneNow();
+#if RTX_EXP == 2
+		batch = 0;    // experiment: node walk only
+#endif
 		for (uint32_t e = 0; e < batch; e = uni(e + 1)) {
 			const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)eFirst, e), n = (uint32_t)__builtin_amdgcn_readlane((int)eCount, e);
 			const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)eMaskLo, e) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)eMaskHi, e) << 32;
@@ -603,11 +622,20 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				rb.e1x = vb.x; rb.e1y = vb.y; rb.e1z = vb.z; rb.e2x = vb.w; rc.e2y = vc.x; rc.e2z = vc.y;
 				FilterState fs;
 				const bool valid = base + lane < n;
-				const bool rej1 = bundleRejects1<CULL>(B, tmaxB, ra, rb, rc, fs);
+				bool rej1 = bundleRejects1<CULL>(B, tmaxB, ra, rb, rc, fs);
+#if RTX_EXP == 4
+				{ RefA ra2 = ra; asm volatile("" : "+v"(ra2.v0x)); FilterState f2; rej1 = rej1 && bundleRejects1<CULL>(B, tmaxB, ra2, rb, rc, f2); }     // experiment: stage 1 twice
+#endif
 				if (RTX_DBG) cnt.wChunks++;
 				if (ballot(valid && !rej1) == 0) { if (RTX_DBG) cnt.wChunkSkips++; continue; }
-				const bool rej2 = bundleRejects2<CULL>(B, rb, rc, fs);
+				bool rej2 = bundleRejects2<CULL>(B, rb, rc, fs);
+#if RTX_EXP == 5
+				{ RefB rb2 = rb; asm volatile("" : "+v"(rb2.e1x)); rej2 = rej2 && bundleRejects2<CULL>(B, rb2, rc, fs); }     // experiment: stage 2 twice
+#endif
 				uint64_t cand = ballot(valid && !rej1 && !rej2);
+#if RTX_EXP == 1
+				cand = 0;     // experiment: no exact tests
+#endif
 				if (RTX_DBG) { cnt.wTri += __popcll(cand); if (cand == 0) cnt.wS2++; }
 				while (cand != 0) {
 					const int c = __builtin_ctzll(cand);
@@ -620,6 +648,11 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 					const uint32_t tri = (uint32_t)__builtin_amdgcn_readlane((int)ra.tri, c);
 					const float before = bt;
 					if (pass) triTestOne<CULL, STATS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, tri, o, d, bt, bu, bv, btri);
+#if RTX_EXP == 6
+					{ float v0x2 = v0x; asm volatile("" : "+s"(v0x2)); float t2 = kFltMax, u2 = 0, w2 = 0; uint32_t k2 = 0;      // experiment: exact test twice
+					  if (pass) triTestOne<CULL, STATS>(v0x2, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, tri, o, d, t2, u2, w2, k2);
+					  asm volatile("" :: "v"(t2), "v"(u2), "v"(w2), "v"(k2)); }
+#endif
 					improved = improved || bt < before;
 				}
 			}
@@ -648,7 +681,6 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 	const float ix = 1 / d.x, iy = 1 / d.y, iz = 1 / d.z;
 	const bool sx = ix < 0, sy = iy < 0, sz = iz < 0;
 	bool live = active;
-	const Bundle B = makeBundle(active, o, d);
 	const uint32_t nObj = uni(P.nObjects);
 	for (uint32_t oi = 0; oi < nObj; oi = uni(oi + 1)) {
 		const Object* ob = uni(P.objects + oi);
@@ -659,10 +691,49 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 		if (ballot(consider) == 0) continue;
 		if (type == 3) {
 			const Mesh* M = uni(P.meshes + (int)sload1(&ob->mesh));
-			float bt, bu, bv; uint32_t btri;
-			if (cull) meshWalk<STATS, true>(M, B, consider, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
-			else meshWalk<STATS, false>(M, B, consider, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
-			if (bt < kFltMax && bt < h.t) { h.obj = (int)oi; h.t = bt; h.tri = btri; h.u = bu; h.v = bv; }   // scene.cpp:740-745
+			// The rays are walked as one bundle (meshWalk) -- unless the bundle is too wide at this mesh for the bundle
+			// filter to reject much (rays of a silhouette tile that hit different objects, a grazing strip of shadow-ray
+			// origins, coarse frames): then the lanes on one side of the middle of the widest axis go first, the others
+			// later, halving until the bundle is narrow.  Which lanes walk together changes the amount of work only.
+			const float fat = sloadf(&M->fatRadius), mrad = sloadf(&M->radius);
+			const float mcx = sloadf(&M->centre[0]), mcy = sloadf(&M->centre[1]), mcz = sloadf(&M->centre[2]);
+			// Rays that fail the root box (objects.cpp:590) take no further part: the bundles are formed by the others.
+			bool pending = consider;
+			if (uni(sload1(&M->nNodes)) != 0) {
+				const u32x8 rn = sload8(uni((const Node*)sloadp(&M->nodes)));
+				const float xlo = (F(rn[0]) - o.x) * ix, xhi = (F(rn[1]) - o.x) * ix, ylo = (F(rn[2]) - o.y) * iy, yhi = (F(rn[3]) - o.y) * iy;
+				const float zlo = (F(rn[4]) - o.z) * iz, zhi = (F(rn[5]) - o.z) * iz;
+				float tmin = sx ? xhi : xlo, tmx = sx ? xlo : xhi;
+				const float tymin = sy ? yhi : ylo, tymax = sy ? ylo : yhi;
+				bool fail = (tmin > tymax) || (tymin > tmx);
+				if (tymin > tmin) tmin = tymin;
+				if (tymax < tmx) tmx = tymax;
+				const float tzmin = sz ? zhi : zlo, tzmax = sz ? zlo : zhi;
+				fail = fail || (tmin > tzmax) || (tzmin > tmx);
+				if (STATS) cnt.box += __popcll(ballot(consider && fail));       // (their root-box test is still a test of the reference)
+				pending = consider && !fail;
+			}
+			while (ballot(pending) != 0) {
+				bool cl = pending;
+				Bundle B = makeBundle(cl, o, d);
+				for (int split = 0; split < 6; ++split) {
+					// width of the bundle where it can meet the mesh: origin box, and direction box times the distance to the far side
+					const float dist = fmaxf(fmaxf(fabsf(B.ocx - mcx), fabsf(B.ocy - mcy)), fabsf(B.ocz - mcz)) + mrad;
+					const float wo = B.roMax, wd = fmaxf(fmaxf(B.rdx, B.rdy), B.rdz) * dist;
+					if (!(wo > fat || wd > fat)) break;
+					bool lo;
+					if (wo >= wd) lo = B.rox >= B.roy && B.rox >= B.roz ? o.x < B.ocx : (B.roy >= B.roz ? o.y < B.ocy : o.z < B.ocz);
+					else lo = B.rdx >= B.rdy && B.rdx >= B.rdz ? d.x < B.dcx : (B.rdy >= B.rdz ? d.y < B.dcy : d.z < B.dcz);
+					if (ballot(cl && lo) == 0 || ballot(cl && !lo) == 0) break;
+					cl = cl && lo;
+					B = makeBundle(cl, o, d);
+				}
+				float bt, bu, bv; uint32_t btri;
+				if (cull) meshWalk<STATS, true>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				else meshWalk<STATS, false>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				if (cl && bt < kFltMax && bt < h.t) { h.obj = (int)oi; h.t = bt; h.tri = btri; h.u = bu; h.v = bv; }   // scene.cpp:740-745
+				pending = pending && !cl;
+			}
 		}
 		else {
 			const V3 c = mk(sloadf(&ob->pos[0]), sloadf(&ob->pos[1]), sloadf(&ob->pos[2]));
