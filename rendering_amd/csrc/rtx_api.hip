@@ -236,9 +236,13 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			return bail(fail(RTX_ERR_ARG, "mesh arrays missing"));
 		if (m.normal_map && !m.tri_tb) return bail(fail(RTX_ERR_ARG, "normal map without tangents"));
 		std::vector<Node> nodes(m.n_nodes);
+		bool boxesRegular = true;
 		for (uint32_t i = 0; i < m.n_nodes; i++) {
 			Node& nd = nodes[i];
-			for (int c = 0; c < 3; c++) { nd.b[2 * c] = m.node_bounds[(size_t)i * 6 + c]; nd.b[2 * c + 1] = m.node_bounds[(size_t)i * 6 + 3 + c]; }
+			for (int c = 0; c < 3; c++) {
+				nd.b[2 * c] = m.node_bounds[(size_t)i * 6 + c]; nd.b[2 * c + 1] = m.node_bounds[(size_t)i * 6 + 3 + c];
+				if (!(std::fabs(nd.b[2 * c]) < 1e30f && std::fabs(nd.b[2 * c + 1]) < 1e30f && nd.b[2 * c] <= nd.b[2 * c + 1])) boxesRegular = false;
+			}
 			if (m.leaf_count[i] < 0) {
 				if (m.node_skip[i] <= (int32_t)i + 1 || m.node_skip[i] > (int32_t)m.n_nodes) return bail(fail(RTX_ERR_ARG, "bad skip index"));
 				nd.link = m.node_skip[i]; nd.first = 0;
@@ -271,7 +275,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		if ((rc = upload(s->owned, m.diffuse_map, (size_t)m.diffuse_w * m.diffuse_h * 3, &dm.diffuse))) return bail(rc);
 		if ((rc = upload(s->owned, m.normal_map, (size_t)m.normal_w * m.normal_h * 3, &dm.normal))) return bail(rc);
 		if ((rc = upload(s->owned, m.specular_map, (size_t)m.specular_w * m.specular_h, &dm.specular))) return bail(rc);
-		dm.nNodes = m.n_nodes; dm.nRefs = m.n_refs; dm.nTris = m.n_tris;
+		dm.nNodes = m.n_nodes; dm.nRefs = m.n_refs; dm.nTris = m.n_tris; dm.boxesRegular = boxesRegular ? 1u : 0u;
 		{
 			// mean edge length of the referenced triangles -> width above which a ray bundle is split (performance only)
 			double sum = 0; size_t cnt = 0;

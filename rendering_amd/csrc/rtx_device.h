@@ -49,7 +49,7 @@ struct Mesh {
 	const float* specular; // w*h or null
 	uint32_t nNodes, nRefs, nTris;
 	uint32_t dW, dH, nW, nH, sW, sH;
-	uint32_t pad;
+	uint32_t boxesRegular;   // every node box is finite with lo <= hi on all axes (lets the walk use the min / max form of the box test)
 	// bundle splitting (rtx_kernels.hip, traceWave): a wave's rays are walked as ONE bundle unless the bundle is wider than
 	// fatRadius at this mesh (a few mean triangle edges); centre / radius = bounding sphere of the root box
 	float fatRadius, centre[3], radius;

@@ -515,7 +515,7 @@ __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, floa
 #ifndef RTX_LEAF_BATCH
 #define RTX_LEAF_BATCH 8
 #endif
-template <bool STATS, bool CULL>
+template <bool STATS, bool CULL, bool REGULAR>
 __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
                                          float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
                                          float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
@@ -560,13 +560,29 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				const f2 by = (f2{ F(nd[2]), F(nd[3]) } - oyy) * iyy;
 				const f2 bz = (f2{ F(nd[4]), F(nd[5]) } - ozz) * izz;
 				const float xlo = bx.x, xhi = bx.y, ylo = by.x, yhi = by.y, zlo = bz.x, zhi = bz.y;
-				float tmin = sx ? xhi : xlo, tmx = sx ? xlo : xhi;
-				const float tymin = sy ? yhi : ylo, tymax = sy ? ylo : yhi;
-				bool fail = (tmin > tymax) || (tymin > tmx);
-				if (tymin > tmin) tmin = tymin;
-				if (tymax < tmx) tmx = tymax;
-				const float tzmin = sz ? zhi : zlo, tzmax = sz ? zlo : zhi;
-				fail = fail || (tmin > tzmax) || (tzmin > tmx);
+				bool fail;
+				if (REGULAR) {
+					// no NaN can arise (finite boxes with lo <= hi, finite origin, finite 1/dir): the sign-selected entry / exit values
+					// are the smaller / larger product of each axis and the reference's sequential compares (objects.cpp:553-567) are
+					// exactly "largest entry > smallest exit" (the same-axis pairs it never compares cannot fail)
+					// (written as instructions: the compiler would first canonicalise all six operands for a possible signalling NaN)
+					float nx, ny, nz, fx, fy, fz, tn, tf;
+					asm("v_min_f32 %0, %1, %2" : "=v"(nx) : "v"(xlo), "v"(xhi)); asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(xlo), "v"(xhi));
+					asm("v_min_f32 %0, %1, %2" : "=v"(ny) : "v"(ylo), "v"(yhi)); asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(ylo), "v"(yhi));
+					asm("v_min_f32 %0, %1, %2" : "=v"(nz) : "v"(zlo), "v"(zhi)); asm("v_max_f32 %0, %1, %2" : "=v"(fz) : "v"(zlo), "v"(zhi));
+					asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn) : "v"(nx), "v"(ny), "v"(nz));
+					asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx), "v"(fy), "v"(fz));
+					fail = tn > tf;
+				}
+				else {
+					float tmin = sx ? xhi : xlo, tmx = sx ? xlo : xhi;
+					const float tymin = sy ? yhi : ylo, tymax = sy ? ylo : yhi;
+					fail = (tmin > tymax) || (tymin > tmx);
+					if (tymin > tmin) tmin = tymin;
+					if (tymax < tmx) tmx = tymax;
+					const float tzmin = sz ? zhi : zlo, tzmax = sz ? zlo : zhi;
+					fail = fail || (tmin > tzmax) || (tzmin > tmx);
+				}
 #if RTX_EXP == 7
 				{ f2 oxx2 = oxx; asm volatile("" : "+v"(oxx2));      // experiment: box test twice
 				  const f2 cx = (f2{ F(nd[0]), F(nd[1]) } - oxx2) * ixx, cy = (f2{ F(nd[2]), F(nd[3]) } - oyy) * iyy, cz = (f2{ F(nd[4]), F(nd[5]) } - ozz) * izz;
@@ -699,6 +715,11 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 			const float mcx = sloadf(&M->centre[0]), mcy = sloadf(&M->centre[1]), mcz = sloadf(&M->centre[2]);
 			// Rays that fail the root box (objects.cpp:590) take no further part: the bundles are formed by the others.
 			bool pending = consider;
+			// the min / max form of the box test (meshWalk<.., REGULAR>) is exact when no NaN can arise: regular boxes, finite
+			// origins and finite 1 / dir for every ray of the wave
+			const bool regular = uni(sload1(&M->boxesRegular)) != 0 &&
+			                     ballot(consider && !(fabsf(ix) < __builtin_inff() && fabsf(iy) < __builtin_inff() && fabsf(iz) < __builtin_inff() &&
+			                                          fabsf(o.x) < 0x1p100f && fabsf(o.y) < 0x1p100f && fabsf(o.z) < 0x1p100f)) == 0;
 			if (uni(sload1(&M->nNodes)) != 0) {
 				const u32x8 rn = sload8(uni((const Node*)sloadp(&M->nodes)));
 				const float xlo = (F(rn[0]) - o.x) * ix, xhi = (F(rn[1]) - o.x) * ix, ylo = (F(rn[2]) - o.y) * iy, yhi = (F(rn[3]) - o.y) * iy;
@@ -729,8 +750,9 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 					B = makeBundle(cl, o, d);
 				}
 				float bt, bu, bv; uint32_t btri;
-				if (cull) meshWalk<STATS, true>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
-				else meshWalk<STATS, false>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				if (cull && regular) meshWalk<STATS, true, true>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				else if (cull) meshWalk<STATS, true, false>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				else meshWalk<STATS, false, false>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				if (cl && bt < kFltMax && bt < h.t) { h.obj = (int)oi; h.t = bt; h.tri = btri; h.u = bu; h.v = bv; }   // scene.cpp:740-745
 				pending = pending && !cl;
 			}
