@@ -509,12 +509,12 @@ __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, floa
 // order (phase 2: bundle filter with the lanes acting as triangles, exact test of the survivors with the lanes acting as
 // rays).  The two phases alternate every RTX_LEAF_BATCH leaves so that any-hit shadow rays still stop early.
 // A hit exists iff bt < FLT_MAX on return (the first accepted t is < FLT_MAX by objects.cpp:598,623).
-#ifndef RTX_EXP
-#define RTX_EXP 0     // timing experiments only (wrong pictures): 1 no exact tests, 2 node walk only, 3 no walk at all
-#endif
 #ifndef RTX_LEAF_BATCH
 #define RTX_LEAF_BATCH 8
 #endif
+// one reached leaf: first reference, number of references, the lanes (rays) that passed its box, start in the batch's stream
+struct LeafEntry { uint32_t first, count, maskLo, maskHi, start, pad[3]; };
+__shared__ LeafEntry leafBatch[4][RTX_LEAF_BATCH];      // per wave of a 256-thread block; private to the wave (no barrier)
 template <bool STATS, bool CULL, bool REGULAR>
 __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
                                          float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
@@ -527,9 +527,6 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 	const uint32_t nN = uni(sload1(&M->nNodes));
 	bt = kFltMax; bu = 0; bv = 0; btri = 0;
 	if (nN == 0) return;
-#if RTX_EXP == 3
-	return;       // experiment: cost of everything but the walk
-#endif
 	// the largest limit of any ray of the wave: a triangle whose t is certainly not below it cannot be recorded by any
 	// lane (tightened whenever a lane finds a closer hit)
 	float tmaxB = unif(waveMax(consider ? tLimit : -__builtin_inff()));
@@ -537,10 +534,10 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 	uint32_t i = 0;
 	const uint32_t last = nN - 1;
 	u32x8 nd = sload8(nodes);
+	LeafEntry* entries = leafBatch[threadIdx.x >> 6];
 	for (;;) {
-		// ---- phase 1: nodes.  Entry k of the batch lives in lane k of four VGPRs (v_writelane / v_readlane).
-		uint32_t eFirst = 0, eCount = 0, eMaskLo = 0, eMaskHi = 0;
-		uint32_t batch = 0;
+		// ---- phase 1: nodes.  The reached leaves are noted in a small per-wave table in LDS.
+		uint32_t batch = 0, total = 0;      // total = references of the batch: its leaves form ONE stream, entry k starts at entries[k].start
 		{
 			const f2 oxx = { o.x, o.x }, oyy = { o.y, o.y }, ozz = { o.z, o.z }, ixx = { ix, ix }, iyy = { iy, iy }, izz = { iz, iz };
 			while (i < nN && batch < RTX_LEAF_BATCH) {
@@ -583,14 +580,6 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 					const float tzmin = sz ? zhi : zlo, tzmax = sz ? zlo : zhi;
 					fail = fail || (tmin > tzmax) || (tzmin > tmx);
 				}
-#if RTX_EXP == 7
-				{ f2 oxx2 = oxx; asm volatile("" : "+v"(oxx2));      // experiment: box test twice
-				  const f2 cx = (f2{ F(nd[0]), F(nd[1]) } - oxx2) * ixx, cy = (f2{ F(nd[2]), F(nd[3]) } - oyy) * iyy, cz = (f2{ F(nd[4]), F(nd[5]) } - ozz) * izz;
-				  float a0 = sx ? cx.y : cx.x, a1 = sx ? cx.x : cx.y; const float b0 = sy ? cy.y : cy.x, b1 = sy ? cy.x : cy.y;
-				  bool f2_ = (a0 > b1) || (b0 > a1); if (b0 > a0) a0 = b0; if (b1 < a1) a1 = b1;
-				  const float c0 = sz ? cz.y : cz.x, c1 = sz ? cz.x : cz.y; f2_ = f2_ || (a0 > c1) || (c0 > a1);
-				  fail = fail && f2_; }
-#endif
 				const bool pass = act && !fail;
 				if (act && fail) resume = nxt;
 				if (STATS) cnt.box += __popcll(ballot(act));
@@ -606,76 +595,73 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 					if (STATS) cnt.tri += (unsigned long long)__popcll(m) * n;
 					if (RTX_DBG) cnt.wLeaves++;
 					if (n != 0) {
-						eFirst = writeLane(nd[7], batch, eFirst);
-						eCount = writeLane(n, batch, eCount);
-						eMaskLo = writeLane((uint32_t)m, batch, eMaskLo);
-						eMaskHi = writeLane((uint32_t)(m >> 32), batch, eMaskHi);
+						if (laneNow() == 0) {
+							LeafEntry en;
+							en.first = nd[7]; en.count = n; en.maskLo = (uint32_t)m; en.maskHi = (uint32_t)(m >> 32); en.start = total; en.pad[0] = en.pad[1] = en.pad[2] = 0;
+							entries[batch] = en;
+						}
 						batch = uni(batch + 1);
+						total = uni(total + n);
 					}
 				}
 				nd = nxA;
 				i = next;
 			}
 		}
-		// ---- phase 2: the noted leaves, in order.  ALL 64 lanes take part (uniform control flow): 64 references at a
-		// time, lane k classifies reference base + k against the bundle; the survivors are then tested, in the reference's
-		// order, by the lanes that passed the leaf's box.
+		// ---- phase 2: the references of the noted leaves, as one stream in the reference's order, 64 at a time (a pass may
+		// hold the end of one leaf and several whole small ones).  ALL 64 lanes take part (uniform control flow): lane k
+		// classifies reference k of the pass against the bundle; the survivors are then tested exactly, in stream order,
+		// by the lanes that passed the box of the survivor's leaf.
 		const uint32_t lane = laneNow();
-#if RTX_EXP == 2
-		batch = 0;    // experiment: node walk only
-#endif
-		for (uint32_t e = 0; e < batch; e = uni(e + 1)) {
-			const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)eFirst, e), n = (uint32_t)__builtin_amdgcn_readlane((int)eCount, e);
-			const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)eMaskLo, e) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)eMaskHi, e) << 32;
-			const bool pass = (m >> lane) & 1ull;
-			bool improved = false;
-			for (uint32_t base = 0; base < n; base = uni(base + 64)) {
-				const uint32_t r = first + base + lane;
-				const f4v va = *(const RTX_AS1 f4v*)(refA + (r << 4)), vb = *(const RTX_AS1 f4v*)(refB + (r << 4));
-				const f2v vc = *(const RTX_AS1 f2v*)(refC + (r << 3));
-				RefA ra; RefB rb; RefC rc;
-				ra.v0x = va.x; ra.v0y = va.y; ra.v0z = va.z; ra.tri = __float_as_uint(va.w);
-				rb.e1x = vb.x; rb.e1y = vb.y; rb.e1z = vb.z; rb.e2x = vb.w; rc.e2y = vc.x; rc.e2z = vc.y;
-				FilterState fs;
-				const bool valid = base + lane < n;
-				bool rej1 = bundleRejects1<CULL>(B, tmaxB, ra, rb, rc, fs);
-#if RTX_EXP == 4
-				{ RefA ra2 = ra; asm volatile("" : "+v"(ra2.v0x)); FilterState f2; rej1 = rej1 && bundleRejects1<CULL>(B, tmaxB, ra2, rb, rc, f2); }     // experiment: stage 1 twice
-#endif
-				if (RTX_DBG) cnt.wChunks++;
-				if (ballot(valid && !rej1) == 0) { if (RTX_DBG) cnt.wChunkSkips++; continue; }
-				bool rej2 = bundleRejects2<CULL>(B, rb, rc, fs);
-#if RTX_EXP == 5
-				{ RefB rb2 = rb; asm volatile("" : "+v"(rb2.e1x)); rej2 = rej2 && bundleRejects2<CULL>(B, rb2, rc, fs); }     // experiment: stage 2 twice
-#endif
-				uint64_t cand = ballot(valid && !rej1 && !rej2);
-#if RTX_EXP == 1
-				cand = 0;     // experiment: no exact tests
-#endif
-				if (RTX_DBG) { cnt.wTri += __popcll(cand); if (cand == 0) cnt.wS2++; }
-				while (cand != 0) {
-					const int c = __builtin_ctzll(cand);
-					cand &= cand - 1;
-#define RTX_RL(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), c))
-					const float v0x = RTX_RL(ra.v0x), v0y = RTX_RL(ra.v0y), v0z = RTX_RL(ra.v0z);
-					const float e1x = RTX_RL(rb.e1x), e1y = RTX_RL(rb.e1y), e1z = RTX_RL(rb.e1z);
-					const float e2x = RTX_RL(rb.e2x), e2y = RTX_RL(rc.e2y), e2z = RTX_RL(rc.e2z);
-#undef RTX_RL
-					const uint32_t tri = (uint32_t)__builtin_amdgcn_readlane((int)ra.tri, c);
-					const float before = bt;
-					if (pass) triTestOne<CULL, STATS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, tri, o, d, bt, bu, bv, btri);
-#if RTX_EXP == 6
-					{ float v0x2 = v0x; asm volatile("" : "+s"(v0x2)); float t2 = kFltMax, u2 = 0, w2 = 0; uint32_t k2 = 0;      // experiment: exact test twice
-					  if (pass) triTestOne<CULL, STATS>(v0x2, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, tri, o, d, t2, u2, w2, k2);
-					  asm volatile("" :: "v"(t2), "v"(u2), "v"(w2), "v"(k2)); }
-#endif
-					improved = improved || bt < before;
-				}
+		uint32_t ecur = 0;                 // first entry that is not finished yet
+		for (uint32_t p0 = 0; p0 < total; p0 = uni(p0 + 64)) {
+			// which reference, of which entry, this lane holds: later entries overwrite earlier ones from their start on
+			uint32_t r = 0, myEnt = 0;
+			for (uint32_t e = ecur; e < batch; e = uni(e + 1)) {
+				const uint32_t st = uni(entries[e].start);
+				if (st >= p0 + 64) break;
+				const uint32_t n = uni(entries[e].count), first = uni(entries[e].first);
+				const int32_t rel = (int32_t)(st - p0);                   // (negative: the leaf began in an earlier pass)
+				const bool here = (int32_t)lane >= rel;
+				r = here ? first + (lane - (uint32_t)rel) : r;
+				myEnt = here ? e : myEnt;
+				if (st + n <= p0 + 64) ecur = uni(e + 1);              // finished within this pass
 			}
-			// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is true
-			// for this lane no later triangle or object can change the answer.
-			if (!STATS) { if (shadow && bt < tLimit) resume = kNever; }
+			const f4v va = *(const RTX_AS1 f4v*)(refA + (r << 4)), vb = *(const RTX_AS1 f4v*)(refB + (r << 4));
+			const f2v vc = *(const RTX_AS1 f2v*)(refC + (r << 3));
+			RefA ra; RefB rb; RefC rc;
+			ra.v0x = va.x; ra.v0y = va.y; ra.v0z = va.z; ra.tri = __float_as_uint(va.w);
+			rb.e1x = vb.x; rb.e1y = vb.y; rb.e1z = vb.z; rb.e2x = vb.w; rc.e2y = vc.x; rc.e2z = vc.y;
+			FilterState fs;
+			const bool valid = p0 + lane < total;
+			const bool rej1 = bundleRejects1<CULL>(B, tmaxB, ra, rb, rc, fs);
+			if (RTX_DBG) cnt.wChunks++;
+			if (ballot(valid && !rej1) == 0) { if (RTX_DBG) cnt.wChunkSkips++; continue; }
+			const bool rej2 = bundleRejects2<CULL>(B, rb, rc, fs);
+			uint64_t cand = ballot(valid && !rej1 && !rej2);
+			if (RTX_DBG) { cnt.wTri += __popcll(cand); if (cand == 0) cnt.wS2++; }
+			if (cand == 0) continue;
+			bool improved = false;
+			while (cand != 0) {
+				const int c = __builtin_ctzll(cand);
+				cand &= cand - 1;
+#define RTX_RL(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), c))
+				const float v0x = RTX_RL(ra.v0x), v0y = RTX_RL(ra.v0y), v0z = RTX_RL(ra.v0z);
+				const float e1x = RTX_RL(rb.e1x), e1y = RTX_RL(rb.e1y), e1z = RTX_RL(rb.e1z);
+				const float e2x = RTX_RL(rb.e2x), e2y = RTX_RL(rc.e2y), e2z = RTX_RL(rc.e2z);
+#undef RTX_RL
+				const uint32_t tri = (uint32_t)__builtin_amdgcn_readlane((int)ra.tri, c);
+				// the rays that reached the survivor's leaf
+				const uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)myEnt, c);
+				const bool pass = (((lane & 32u) ? entries[ent].maskHi : entries[ent].maskLo) >> (lane & 31u)) & 1u;
+				const float before = bt;
+				if (pass) triTestOne<CULL, STATS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, tri, o, d, bt, bu, bv, btri);
+				improved = improved || bt < before;
+			}
 			if (ballot(improved) != 0) {
+				// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is true
+				// for this lane no later triangle or object can change the answer.
+				if (!STATS) { if (shadow && bt < tLimit) resume = kNever; }
 				// no lane can record a t that is not below its own current limit any more
 				const bool open = resume != kNever;
 				tmaxB = unif(waveMax(open ? fminf(bt, tLimit) : -__builtin_inff()));
