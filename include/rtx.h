@@ -236,6 +236,11 @@ int rtx_cast_rays(rtx_scene* scene, uint32_t n, const float* rays_host, float* h
  * 2 sqrtf(x), 3 (float)(1/sqrt((double)x)), 4 x/y. */
 int rtx_math_probe(int device, int op, uint32_t n, const float* x, const float* y, float* out);
 
+/* The shading path's vector helpers on the device, n inputs at a time (host buffers, n x 3 floats; unit tests against the
+ * reference's vectors).  op: 0 Render::reflect(a, b) (scene.cpp:672-675), 1 Render::refract(a, b, ior) (677-696),
+ * 2 Render::fresnel(a, b, ior) in out[3 i] (698-722), 3 Vec3::normalize(a) (geometry.h:104-112; b may be NULL). */
+int rtx_vec_probe(int device, int op, uint32_t n, const float* a, const float* b, float ior, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,7 +38,7 @@ RTX_SYMBOLS = [
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
     "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
     "rtx_bvh_build", "rtx_bvh_info", "rtx_bvh_read", "rtx_bvh_destroy",
-    "rtx_comm_unique_id", "rtx_comm_create", "rtx_comm_info", "rtx_comm_destroy", "rtx_gather", "rtx_gather_plan",
+    "rtx_vec_probe", "rtx_comm_unique_id", "rtx_comm_create", "rtx_comm_info", "rtx_comm_destroy", "rtx_gather", "rtx_gather_plan",
 ]
 
 
@@ -82,6 +82,7 @@ def load():
     rtx.rtx_bvh_destroy.argtypes = [vp]
     rtx.rtx_bvh_destroy.restype = None
     rtx.rtx_scene_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
+    rtx.rtx_vec_probe.argtypes = [i32, i32, u32, vp, vp, C.c_float, vp]
     rtx.rtx_comm_unique_id.argtypes = [vp]
     rtx.rtx_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     rtx.rtx_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -222,6 +223,19 @@ def math_probe(op, x, y=None, device=0):
         y = np.ascontiguousarray(np.broadcast_to(np.asarray(y, np.float32), x.shape))
         yp = _np_ptr(y)
     _check(rtx.rtx_math_probe(device, op, x.size, _np_ptr(x), yp, _np_ptr(out)), "rtx_math_probe")
+    return out
+
+
+def vec_probe(op, a, b=None, ior=1.0, device=0):
+    """rtx_vec_probe: reflect / refract / fresnel / normalize on the device (n x 3 arrays)."""
+    rtx, _ = load()
+    a = np.ascontiguousarray(a, np.float32).reshape(-1, 3)
+    out = np.zeros_like(a)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, np.float32).reshape(-1, 3)
+        bp = _np_ptr(b)
+    _check(rtx.rtx_vec_probe(device, op, a.shape[0], _np_ptr(a), bp, ior, _np_ptr(out)), "rtx_vec_probe")
     return out
 
 

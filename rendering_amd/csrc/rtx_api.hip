@@ -755,6 +755,23 @@ int rtx_math_probe(int device, int op, uint32_t n, const float* x, const float* 
 	return RTX_OK;
 }
 
+int rtx_vec_probe(int device, int op, uint32_t n, const float* a, const float* b, float ior, float* out)
+{
+	if (!a || !out || op < 0 || op > 3 || (op < 3 && !b)) return fail(RTX_ERR_ARG, "bad argument");
+	int cnt = 0;
+	if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fail(RTX_ERR_NO_DEVICE, "no HIP device visible");
+	HIPCHK(hipSetDevice(device));
+	DevBuf da, db, dout;
+	const size_t bytes = (size_t)n * 3 * sizeof(float);
+	HIPCHK(hipMalloc(&da.p, bytes)); HIPCHK(hipMalloc(&dout.p, bytes));
+	HIPCHK(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+	if (b) { HIPCHK(hipMalloc(&db.p, bytes)); HIPCHK(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice)); }
+	hipLaunchKernelGGL(rtxVecProbeKernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, op, n, (const float*)da.p, (const float*)db.p, ior, (float*)dout.p);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+	return RTX_OK;
+}
+
 } // extern "C"
 
 // device-side acceleration-structure build (uses fail / HIPCHK above)

@@ -55,15 +55,18 @@ struct Mesh {
 	float fatRadius, centre[3], radius;
 };
 
+// 128 bytes; everything Render::trace needs (the first ten dwords) arrives with ONE s_load_dwordx16.
 struct Object {
 	int32_t type, material;
 	float pos[3];
-	float color[3];
-	float ior, ambient, diffuse, specular, nSpecular;
 	float r2;
 	float normal[3];
 	int32_t mesh;
+	float color[3];
+	float ior, ambient, diffuse, specular, nSpecular;
+	uint32_t pad[14];
 };
+static_assert(sizeof(Object) == 128, "object record = two 64-byte lines");
 
 struct Light {
 	int32_t type;

@@ -509,6 +509,12 @@ __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, floa
 // order (phase 2: bundle filter with the lanes acting as triangles, exact test of the survivors with the lanes acting as
 // rays).  The two phases alternate every RTX_LEAF_BATCH leaves so that any-hit shadow rays still stop early.
 // A hit exists iff bt < FLT_MAX on return (the first accepted t is < FLT_MAX by objects.cpp:598,623).
+#ifndef RTX_PRIO
+#define RTX_PRIO 1            // raised wave priority for work items known to be slow
+#endif
+#ifndef RTX_PRIO_TICKS
+#define RTX_PRIO_TICKS 50000u // pass 1: tiles that took more than 0.5 ms (100 MHz ticks) in the previous launch
+#endif
 #ifndef RTX_LEAF_BATCH
 #define RTX_LEAF_BATCH 8
 #endif
@@ -686,13 +692,14 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 	const uint32_t nObj = uni(P.nObjects);
 	for (uint32_t oi = 0; oi < nObj; oi = uni(oi + 1)) {
 		const Object* ob = uni(P.objects + oi);
-		const int type = (int)sload1(&ob->type);
-		const int mat = (int)sload1(&ob->material);
+		const u32x16 rec = sload16(ob);         // type, material, pos[3], r2, normal[3], mesh, ...
+		const int type = (int)rec[0];
+		const int mat = (int)rec[1];
 		// transparent objects do not cast shadows (scene.cpp:733)
 		const bool consider = live && !(shadow && mat == 2);
 		if (ballot(consider) == 0) continue;
 		if (type == 3) {
-			const Mesh* M = uni(P.meshes + (int)sload1(&ob->mesh));
+			const Mesh* M = uni(P.meshes + (int)rec[9]);
 			// The rays are walked as one bundle (meshWalk) -- unless the bundle is too wide at this mesh for the bundle
 			// filter to reject much (rays of a silhouette tile that hit different objects, a grazing strip of shadow-ray
 			// origins, coarse frames): then the lanes on one side of the middle of the widest axis go first, the others
@@ -744,10 +751,10 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 			}
 		}
 		else {
-			const V3 c = mk(sloadf(&ob->pos[0]), sloadf(&ob->pos[1]), sloadf(&ob->pos[2]));
+			const V3 c = mk(F(rec[2]), F(rec[3]), F(rec[4]));
 			float t0 = kFltMax; bool hit;
 			if (type == 1) {                       // Sphere::intersectObject, objects.cpp:774-786
-				const float r2 = sloadf(&ob->r2);
+				const float r2 = F(rec[5]);
 				const V3 L = c - o;
 				const float tca = dot(L, d);
 				const float d2 = dot(L, L) - tca * tca;
@@ -759,7 +766,7 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 				if (t0 < 0) hit = false;
 			}
 			else {                                 // Plane::intersectObject, objects.cpp:807-814
-				const V3 n = mk(sloadf(&ob->normal[0]), sloadf(&ob->normal[1]), sloadf(&ob->normal[2]));
+				const V3 n = mk(F(rec[6]), F(rec[7]), F(rec[8]));
 				const float denom = dot(d, n);
 				hit = !(fabsf(denom) < RTX_EPS8);
 				t0 = dot(c - o, n) / denom;
@@ -1117,6 +1124,11 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 			if (ballot(valid) == 0) continue;
 			V3 o, d;
 			primaryRay(P, (float)x + 0.5f, (float)y + 0.5f, o, d);
+#if RTX_PRIO
+			// a tile that was slow in the previous launch of this view (a pole, a silhouette) runs at raised priority: the
+			// launch ends when its slowest wave does, and such a wave otherwise gets one issue slot in RTX_WAVES
+			if (sload1(P.tileCost + ty * P.tilesXFull + tx) > RTX_PRIO_TICKS) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
 			const unsigned long long t0 = wall_clock64();
 			const V3 c = castRayWave<STATS>(P, valid, o, d, gl, cnt);
 			const unsigned long long dt = wall_clock64() - t0;
@@ -1172,6 +1184,10 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
 		const uint32_t total = sload1(P.ssaaScan + 2 * (size_t)P.nTiles);
 		const uint32_t first = work * 16;
 		if (first >= total) break;
+#if RTX_PRIO
+		// the items of the tiles that were slow in pass 1 come first in the list: they run at raised priority
+		if (first < sload1(P.ssaaScan + P.nTiles)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
 		const uint32_t g = first + (lane >> 2), sub = lane & 3;
 		const uint32_t pxy = P.ssaaPixels[g < total ? g : first];
 		const bool valid = g < total && pxy != 0xffffffffu;
@@ -1372,6 +1388,20 @@ __global__ void rtxMathProbeKernel(int op, uint32_t n, const float* x, const flo
 	else if (op == 3) r = invLenD(x[i]);
 	else if (op == 4) r = x[i] / y[i];
 	out[i] = r;
+}
+
+// Device-side vector helpers of the shading path against the reference's unit vectors (rtx_vec_probe)
+__global__ void rtxVecProbeKernel(int op, uint32_t n, const float* a, const float* b, float ior, float* out)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const V3 d = load3(a + (size_t)i * 3), nn = b ? load3(b + (size_t)i * 3) : mk(0, 0, 0);
+	V3 r = mk(0, 0, 0);
+	if (op == 0) r = reflectDir(d, nn);
+	else if (op == 1) r = refractDir(d, nn, ior);
+	else if (op == 2) r.x = fresnelKr(d, nn, ior);
+	else if (op == 3) r = normalized(d);
+	out[(size_t)i * 3] = r.x; out[(size_t)i * 3 + 1] = r.y; out[(size_t)i * 3 + 2] = r.z;
 }
 
 // explicit instantiations used by rtx_api.hip

@@ -119,22 +119,28 @@ struct Builder {
 
 } // namespace
 
-static bool wantDeviceBuild()
+// Where the structure is built.  options::acBuildOnDevice: 0 host, 1 device, -1 (default) = the faster one: the device
+// build (rtx_bvh_build) wins from some tens of thousands of triangles on (250k: scene load 113 ms vs 133 ms with the host
+// builder, profiles/r02_bvh_build_time.txt), below that its fixed cost of ~600 small launches makes it the slower one.
+// Environment RENDERING_AMD_AC_BUILD=host|device overrides the default.  Both give the same structure bit for bit.
+static bool wantDeviceBuild(size_t nTris)
 {
-	if (options::acBuildOnDevice < 0) {
+	int mode = options::acBuildOnDevice;
+	if (mode < 0) {
 		const char* e = std::getenv("RENDERING_AMD_AC_BUILD");
-		int n = 0;
-		if (e && !strcmp(e, "host")) options::acBuildOnDevice = 0;
-		else if (e && !strcmp(e, "device")) options::acBuildOnDevice = 1;
-		else options::acBuildOnDevice = (rtx_device_count(&n) == RTX_OK && n > 0) ? 1 : 0;
+		if (e && !strcmp(e, "host")) mode = 0;
+		else if (e && !strcmp(e, "device")) mode = 1;
 	}
-	return options::acBuildOnDevice == 1;
+	if (mode >= 0) return mode == 1;
+	static int devices = -1;
+	if (devices < 0) { int n = 0; devices = (rtx_device_count(&n) == RTX_OK && n > 0) ? n : 0; }
+	return devices > 0 && nTris >= 50000;
 }
 
 bool AccelerationStructure::setup(const std::vector<Triangle>& tris, const Options& options)
 {
 	nodes.clear(); refs.clear(); maxDepth = 0; buildMs = 0; builtOnDevice = false;
-	const bool onDevice = wantDeviceBuild();
+	const bool onDevice = wantDeviceBuild(tris.size());
 	Timer timer(onDevice ? "AC build (device)" : "AC build (host)");
 	if (!onDevice) {
 		Builder b(tris, options.acPenalty, *this);

@@ -39,10 +39,15 @@ def test_device_build_equals_host_build(ra, name):
         _same(h, d)
 
 
-def test_default_loader_builds_on_the_device(ra):
-    """With a GPU visible the loader's default is the device builder (no silent host path)."""
+def test_default_loader_picks_the_faster_builder(ra):
+    """The loader's default: the device builder from 50 000 triangles on (where it is the faster one), the host builder
+    for small meshes -- the same structure either way (the digest test pins the 250k one to the reference)."""
+    from rendering_amd import assets
+    assets.ensure(["bumpy_250k.obj"])
     ra.set_ac_build("auto")
     g = ra.Scene("scenes/cfg2_smooth_4k.scene", 64, 64)
+    assert not any(g.bvh(oi)["built_on_device"] for oi in _mesh_objects(g))
+    g = ra.Scene("scenes/cfg2_smooth_250k.scene", 64, 64)
     assert all(g.bvh(oi)["built_on_device"] for oi in _mesh_objects(g))
 
 

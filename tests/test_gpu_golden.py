@@ -32,7 +32,11 @@ def test_hip_path_matches_reference_golden(ra, name):
             n, md5 = item.split("=")
             assert assets.md5(n) == md5, "generated asset %s differs from the one the golden was made with" % n
     w, h = int(g["width"]), int(g["height"])
-    s = ra.Scene("scenes/%s.scene" % name, w, h)
+    ra.set_ac_build("device")          # (the default picks the host builder for meshes this small)
+    try:
+        s = ra.Scene("scenes/%s.scene" % name, w, h)
+    finally:
+        ra.set_ac_build("auto")
     scale, aspect, m, pos = s.camera()
     assert bits(scale) == bits(g["cam_scale"]) and bits(aspect) == bits(g["cam_aspect"])
     assert np.array_equal(bits(m), bits(g["cam_matrix"])) and np.array_equal(bits(pos), bits(g["cam_pos"]))
@@ -83,3 +87,16 @@ def test_headline_250k_mesh_matches_reference_digest(ra):
     s.counters_enable(False)
     assert [int(x) for x in st] == d["pass1_128x128_stats"]
     assert sha(fb) == d["pass1_128x128_sha1"]
+
+
+def test_device_vector_helpers_match_reference_units(ra):
+    """reflect / refract / fresnel / normalize evaluated ON THE DEVICE against the vectors recorded from the reference
+    (tests/golden/units.npz: scene.cpp:672-722, geometry.h:104-112) -- the pieces of the shading path that the frame tests
+    only see through colours."""
+    g = np.load(os.path.join(GOLD, "units.npz"))
+    d, n = g["d"], g["n"]
+    assert np.array_equal(bits(ra.vec_probe(0, d, n)), bits(g["reflect"]))
+    for ior in ("1.4", "1", "0.7", "2.5"):
+        assert np.array_equal(bits(ra.vec_probe(1, d, n, float(ior))), bits(g["refract_" + ior])), "refract " + ior
+        assert np.array_equal(bits(ra.vec_probe(2, d, n, float(ior))[:, 0]), bits(g["fresnel_" + ior])), "fresnel " + ior
+    assert np.array_equal(bits(ra.vec_probe(3, g["normalize_in"])), bits(g["normalize_out"]))
