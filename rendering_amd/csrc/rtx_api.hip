@@ -478,6 +478,9 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	const uint32_t tilesY = (lastRow + 7) / 8 - p.tileRow0;
 	p.nTiles = p.tilesX * tilesY;
 	p.tilesY = tilesY;
+#if RTX_DBG
+	if (const char* e = getenv("RTX_DBG_TILE")) { unsigned tx = 0, ty = 0; if (sscanf(e, "%u,%u", &tx, &ty) == 2) p.pad3 = ((ty << 16) | tx) + 1; }
+#endif
 	p.workCounter = s->work + 128;            // eight per-XCD queue heads, 64 bytes apart
 	if (p.view.width > 0x7fff8u || p.view.height > 0x7fff8u) return fail(RTX_ERR_ARG, "frame too large");
 	rtx_scene::TileQueues* tq = nullptr;

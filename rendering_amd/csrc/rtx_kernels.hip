@@ -27,7 +27,7 @@
 using namespace rtxd;
 
 #ifndef RTX_SSAA_VERY
-#define RTX_SSAA_VERY 8u   // x 0.25 ms of pass-1 time: tiles above get 4-pixel SSAA waves
+#define RTX_SSAA_VERY 4u   // x 0.25 ms of pass-1 time: tiles above get 4-pixel SSAA waves
 #endif
 #ifndef RTX_DBG
 #define RTX_DBG 0     // 1: wave-level stage counters + per-wave pass-1 timeline, 2: + sampled certificate outcomes / leaf-size histograms (slow) (RTX_DEBUG_ITEMS=1 prints them)
@@ -515,6 +515,9 @@ __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, floa
 #ifndef RTX_PRIO_TICKS
 #define RTX_PRIO_TICKS 50000u // pass 1: tiles that took more than 0.5 ms (100 MHz ticks) in the previous launch
 #endif
+#ifndef RTX_MAX_SPLITS
+#define RTX_MAX_SPLITS 4          // halvings of a wide bundle
+#endif
 #ifndef RTX_LEAF_BATCH
 #define RTX_LEAF_BATCH 8
 #endif
@@ -730,7 +733,7 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 			while (ballot(pending) != 0) {
 				bool cl = pending;
 				Bundle B = makeBundle(cl, o, d);
-				for (int split = 0; split < 6; ++split) {
+				for (int split = 0; split < RTX_MAX_SPLITS; ++split) {
 					// width of the bundle where it can meet the mesh: origin box, and direction box times the distance to the far side
 					const float dist = fmaxf(fmaxf(fabsf(B.ocx - mcx), fabsf(B.ocy - mcy)), fabsf(B.ocz - mcz)) + mrad;
 					const float wo = B.roMax, wd = fmaxf(fmaxf(B.rdx, B.rdy), B.rdz) * dist;
@@ -1117,6 +1120,9 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 			const uint32_t j = nextWork(P.workCounter + q * 16);
 			if (j >= qSize) break;
 			const uint32_t tile = sload1(P.tileList + qBase + j);
+#if RTX_DBG
+			if (P.pad3 != 0 && tile != P.pad3 - 1) continue;      // RTX_DBG_TILE=tx,ty: only this tile (counters of one work item)
+#endif
 			const uint32_t tx = tile & 0xffffu, ty = tile >> 16;
 			const uint32_t x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
 			// x1/y1 are clamped to W-1/H-1: the last column and row are never rendered (scene.cpp:369-372)
