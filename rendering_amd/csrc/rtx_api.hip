@@ -132,9 +132,11 @@ int ensureWork(rtx_scene* s)
 		int b = 0;
 		HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxPass1Kernel<false>, 256, 0));
 		if (b < 1) b = 1;
+		if (const char* e = getenv("RTX_PASS1_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < b) b = v; }      // experiment knob
 		s->blocksPass1 = b * s->numCUs;
 		HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxSsaaKernel<false>, 256, 0));
 		if (b < 1) b = 1;
+		if (const char* e = getenv("RTX_SSAA_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < b) b = v; }
 		s->blocksSsaa = b * s->numCUs;
 	}
 	const int blocks = s->blocksPass1 > s->blocksSsaa ? s->blocksPass1 : s->blocksSsaa;

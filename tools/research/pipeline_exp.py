@@ -2,7 +2,10 @@
 band k (the SSAA launches are latency-bound: few, slow waves).  python tools/research/pipeline_exp.py [K ...]
 RESULT (round 1): frames are bit-identical to the plain frame, but nothing overlaps -- the persistent pass-1 waves hold
 every wave slot until their queue is empty, so the other stream's kernels start when pass 1 ends (rocprofv3 kernel
-trace); K = 2 / 4 / 8 bands: 19.5 / 21.4 / 24.5 ms against 17.1 ms.  Overlap needs ONE persistent kernel."""
+trace); K = 2 / 4 / 8 bands: 19.5 / 21.4 / 24.5 ms against 17.1 ms.  Overlap needs ONE persistent kernel.
+RESULT (round 2, kernels twice as fast): K = 2 / 4 / 8: 9.6 / 10.3 / 11.4 ms against 7.9 ms.  Leaving wave slots free for the
+other stream (RTX_PASS1_BLOCKS_PER_CU=5 RTX_SSAA_BLOCKS_PER_CU=1, knobs read at scene creation) makes the two streams
+overlap but costs more than it hides: plain 10.1 ms, K = 4 10.2 ms; 5 + 2: 9.4 / 9.7; 4 + 2: 10.3 / 9.8."""
 import os, sys, time
 import numpy as np
 import torch
