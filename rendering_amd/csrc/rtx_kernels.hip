@@ -515,6 +515,9 @@ __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, floa
 #ifndef RTX_PRIO_TICKS
 #define RTX_PRIO_TICKS 50000u // pass 1: tiles that took more than 0.5 ms (100 MHz ticks) in the previous launch
 #endif
+#ifndef RTX_NODE_PACKED
+#define RTX_NODE_PACKED 0         // packed fp32 box test (6 instructions, 12 VGPRs of duplicated operands) or plain (12 instructions)
+#endif
 #ifndef RTX_MAX_SPLITS
 #define RTX_MAX_SPLITS 4          // halvings of a wide bundle
 #endif
@@ -548,7 +551,9 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 		// ---- phase 1: nodes.  The reached leaves are noted in a small per-wave table in LDS.
 		uint32_t batch = 0, total = 0;      // total = references of the batch: its leaves form ONE stream, entry k starts at entries[k].start
 		{
+#if RTX_NODE_PACKED
 			const f2 oxx = { o.x, o.x }, oyy = { o.y, o.y }, ozz = { o.z, o.z }, ixx = { ix, ix }, iyy = { iy, iy }, izz = { iz, iz };
+#endif
 			while (i < nN && batch < RTX_LEAF_BATCH) {
 				const int32_t link = (int32_t)nd[6];
 				const uint32_t next = uni(i + 1);
@@ -562,10 +567,15 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				const bool act = i >= resume;
 				// slab test, objects.cpp:546-567: (bounds[sign] - orig) * invdir per axis, sequential compares.
 				// ((lo_i, hi_i) - orig_i) * invdir_i as one packed subtract + one packed multiply per axis
+#if RTX_NODE_PACKED
 				const f2 bx = (f2{ F(nd[0]), F(nd[1]) } - oxx) * ixx;
 				const f2 by = (f2{ F(nd[2]), F(nd[3]) } - oyy) * iyy;
 				const f2 bz = (f2{ F(nd[4]), F(nd[5]) } - ozz) * izz;
 				const float xlo = bx.x, xhi = bx.y, ylo = by.x, yhi = by.y, zlo = bz.x, zhi = bz.y;
+#else
+				const float xlo = (F(nd[0]) - o.x) * ix, xhi = (F(nd[1]) - o.x) * ix, ylo = (F(nd[2]) - o.y) * iy, yhi = (F(nd[3]) - o.y) * iy;
+				const float zlo = (F(nd[4]) - o.z) * iz, zhi = (F(nd[5]) - o.z) * iz;
+#endif
 				bool fail;
 				if (REGULAR) {
 					// no NaN can arise (finite boxes with lo <= hi, finite origin, finite 1/dir): the sign-selected entry / exit values
