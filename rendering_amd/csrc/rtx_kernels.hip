@@ -411,7 +411,7 @@ __device__ __forceinline__ Bundle makeBundle(bool active, const V3& o, const V3&
 // Magnitudes outside the assumed range (or NaN) make the compares false: nothing is rejected.
 // Evaluated in two stages so that a wave whose 64 references all fail the cheap first stage (orientation and t range:
 // the back of the mesh, everything behind a shadow ray's origin) skips the second (u, v).
-struct FilterState { float ax, ay, az, s1, s2, kda, detHi1, sg; bool ok; };
+struct FilterState { float kda, detHi1, sg; bool ok; };      // (kept small: it is live across the ballot between the stages)
 
 template <bool CULL>
 __device__ __forceinline__ bool bundleRejects1(const Bundle& B, float tmaxB, const RefA& ra, const RefB& rb, const RefC& rc, FilterState& f)
@@ -444,26 +444,27 @@ __device__ __forceinline__ bool bundleRejects1(const Bundle& B, float tmaxB, con
 	const float Et = __builtin_fmaf(kFilterK * ainf, s12, kFilterEta);
 	const float detHi1 = detHi * (1.0f + 0x1p-18f);
 	const bool rej = (CULL && detHi < 0) || ntc + ntr < -Et || ntc - ntr - Et >= tmaxB * detHi1;
-	f.ax = ax; f.ay = ay; f.az = az; f.s1 = s1; f.s2 = s2; f.kda = B.kd * ainf; f.detHi1 = detHi1; f.sg = sg;
+	f.kda = B.kd * ainf; f.detHi1 = detHi1; f.sg = sg;
 	f.ok = usable && tame && B.sane;
 	return rej && f.ok;
 }
 
 template <bool CULL>
-__device__ __forceinline__ bool bundleRejects2(const Bundle& B, const RefB& rb, const RefC& rc, const FilterState& f)
+__device__ __forceinline__ bool bundleRejects2(const Bundle& B, const RefA& ra, const RefB& rb, const RefC& rc, const FilterState& f)
 {
 	const float e1x = rb.e1x, e1y = rb.e1y, e1z = rb.e1z, e2x = rb.e2x, e2y = rc.e2y, e2z = rc.e2z;
-	const float ax = f.ax, ay = f.ay, az = f.az;
+	const float ax = B.ocx - ra.v0x, ay = B.ocy - ra.v0y, az = B.ocz - ra.v0z;      // (recomputed: cheaper than three live registers)
+	const float s1 = fabsf(e1x) + fabsf(e1y) + fabsf(e1z), s2 = fabsf(e2x) + fabsf(e2y) + fabsf(e2z);
 	// u: Nu = d . (e2 x a)
 	const float wux = __builtin_fmaf(e2y, az, -(e2z * ay)), wuy = __builtin_fmaf(e2z, ax, -(e2x * az)), wuz = __builtin_fmaf(e2x, ay, -(e2y * ax));
 	float nuc = __builtin_fmaf(B.dcz, wuz, __builtin_fmaf(B.dcy, wuy, B.dcx * wux));
-	const float nur = __builtin_fmaf(B.kdRoSum, f.s2, __builtin_fmaf(B.rdz, fabsf(wuz), __builtin_fmaf(B.rdy, fabsf(wuy), B.rdx * fabsf(wux)))) * (1.0f + 0x1p-20f);
-	const float Eu = __builtin_fmaf(f.kda, f.s2, kFilterEta);
+	const float nur = __builtin_fmaf(B.kdRoSum, s2, __builtin_fmaf(B.rdz, fabsf(wuz), __builtin_fmaf(B.rdy, fabsf(wuy), B.rdx * fabsf(wux)))) * (1.0f + 0x1p-20f);
+	const float Eu = __builtin_fmaf(f.kda, s2, kFilterEta);
 	// v: Nv = d . (a x e1)
 	const float wvx = __builtin_fmaf(ay, e1z, -(az * e1y)), wvy = __builtin_fmaf(az, e1x, -(ax * e1z)), wvz = __builtin_fmaf(ax, e1y, -(ay * e1x));
 	float nvc = __builtin_fmaf(B.dcz, wvz, __builtin_fmaf(B.dcy, wvy, B.dcx * wvx));
-	const float nvr = __builtin_fmaf(B.kdRoSum, f.s1, __builtin_fmaf(B.rdz, fabsf(wvz), __builtin_fmaf(B.rdy, fabsf(wvy), B.rdx * fabsf(wvx)))) * (1.0f + 0x1p-20f);
-	const float Ev = __builtin_fmaf(f.kda, f.s1, kFilterEta);
+	const float nvr = __builtin_fmaf(B.kdRoSum, s1, __builtin_fmaf(B.rdz, fabsf(wvz), __builtin_fmaf(B.rdy, fabsf(wvy), B.rdx * fabsf(wvx)))) * (1.0f + 0x1p-20f);
+	const float Ev = __builtin_fmaf(f.kda, s1, kFilterEta);
 	if (!CULL) { nuc *= f.sg; nvc *= f.sg; }
 	const float nuLo = nuc - nur - Eu;
 	const bool rej = nuc + nur < -Eu || nuLo > f.detHi1 || nvc + nvr < -Ev || nuLo + (nvc - nvr - Ev) > f.detHi1;
@@ -656,7 +657,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 			const bool rej1 = bundleRejects1<CULL>(B, tmaxB, ra, rb, rc, fs);
 			if (RTX_DBG) cnt.wChunks++;
 			if (ballot(valid && !rej1) == 0) { if (RTX_DBG) cnt.wChunkSkips++; continue; }
-			const bool rej2 = bundleRejects2<CULL>(B, rb, rc, fs);
+			const bool rej2 = bundleRejects2<CULL>(B, ra, rb, rc, fs);
 			uint64_t cand = ballot(valid && !rej1 && !rej2);
 			if (RTX_DBG) { cnt.wTri += __popcll(cand); if (cand == 0) cnt.wS2++; }
 			if (cand == 0) continue;
@@ -810,7 +811,7 @@ struct Lane {
 	float specCoef, nSpec, dsum, ssum;
 	uint32_t li, si;
 	// pending trace request
-	V3 qo, qd; float qtmax; bool qshadow;
+	float qtmax;                  // (origin / direction of the pending request are derived from the state: see castRayWave)
 	bool qmoot;                   // the pending shadow ray cannot influence the pixel (see advance)
 };
 
@@ -872,7 +873,7 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 	for (;;) {
 		if (s.state == ST_NEWRAY) {
 			if (s.sp > maxDepth) { s.col = skyColor(P, s.rd); s.state = ST_RETURN; continue; }   // scene.cpp:760
-			s.qo = s.ro; s.qd = s.rd; s.qtmax = kFltMax; s.qshadow = false;
+			s.qtmax = kFltMax;
 			s.state = ST_WAIT_PRIMARY;
 			return;
 		}
@@ -919,7 +920,7 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 			// the max is +0 (surface turned away from the light, or NaN) the product is the same +0 for either answer: the
 			// ray cannot influence the pixel ("moot"), and the product kernels do not walk it (castRayWave).
 			s.qmoot = s.mat == 0 && fmaxRef(0.f, dot(s.N, -s.L)) == 0.f;
-			s.qo = s.P + s.N * bias; s.qd = -s.L; s.qtmax = dist; s.qshadow = true;               // scene.cpp:787
+			s.qtmax = dist;               // the ray itself: Ray{P + N*bias, -L, ShadowRay} (scene.cpp:787), built in castRayWave
 			s.state = ST_WAIT_SHADOW;
 			return;
 		}
@@ -1048,7 +1049,7 @@ __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 
 	s.obj = 0; s.mat = 0; s.li = 0; s.si = 0;
 	s.P = s.N = s.objColor = s.diff = s.spec = s.L = s.I = mk(0, 0, 0);
 	s.specCoef = s.nSpec = s.dsum = s.ssum = 0;
-	s.qo = o; s.qd = d; s.qtmax = kFltMax; s.qshadow = false; s.qmoot = false;
+	s.qtmax = kFltMax; s.qmoot = false;
 	advance(P, s, gl);
 	while (ballot(s.state != ST_DONE) != 0) {
 		Hit h;
@@ -1056,7 +1057,10 @@ __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 
 		// them; here the lane just sits the trace out and consumes "not occluded", which gives the same +0 product
 		const bool moot = s.state == ST_WAIT_SHADOW && s.qmoot;
 		if (STATS) cnt.moot += __popcll(ballot(moot));
-		traceWave<STATS>(P, s.state != ST_DONE && (STATS || !moot), s.qshadow, s.qo, s.qd, s.qtmax, h, cnt);
+		// the pending request of every lane: a shadow ray from the point being shaded, or the lane's current ray
+		const bool qshadow = s.state == ST_WAIT_SHADOW;
+		const V3 qo = qshadow ? s.P + s.N * P.view.bias : s.ro, qd = qshadow ? -s.L : s.rd;
+		traceWave<STATS>(P, s.state != ST_DONE && (STATS || !moot), qshadow, qo, qd, s.qtmax, h, cnt);
 		if (s.state != ST_DONE) {
 			consume(P, s, h);
 			advance(P, s, gl);
