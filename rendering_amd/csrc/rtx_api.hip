@@ -254,6 +254,51 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			if (begin + count > m.n_refs) return bail(fail(RTX_ERR_ARG, "leaf range out of bounds"));
 			nd.link = ~m.leaf_count[i]; nd.first = (int32_t)begin;
 		}
+		// the tree with every other level skipped (rtxd::WideNode), when every box lies inside its parent's
+		std::vector<WideNode> wide;
+		if (boxesRegular && m.n_nodes > 0) {
+			bool nested = true;
+			uint32_t depthMax = 0;
+			auto isLeaf = [&](uint32_t i) { return m.leaf_count[i] >= 0; };
+			auto rightOf = [&](uint32_t i) { return isLeaf(i + 1) ? i + 2 : (uint32_t)m.node_skip[i + 1]; };     // children of inner node i: i + 1 and this
+			auto inside = [&](uint32_t c, uint32_t p) {
+				for (int k = 0; k < 3; k++)
+					if (!(nodes[c].b[2 * k] >= nodes[p].b[2 * k] && nodes[c].b[2 * k + 1] <= nodes[p].b[2 * k + 1])) return false;
+				return true;
+			};
+			// iterative pre-order construction: (binary node, index of its wide node, depth)
+			struct Item { uint32_t node, wideIndex, depth; };
+			std::vector<Item> todo;
+			wide.emplace_back(); memset(&wide[0], 0, sizeof(WideNode));
+			if (isLeaf(0)) { wide[0].slot[0] = nodes[0]; }
+			else todo.push_back({ 0u, 0u, 1u });
+			while (!todo.empty() && nested) {
+				const Item it = todo.back(); todo.pop_back();
+				depthMax = std::max(depthMax, it.depth);
+				uint32_t slots[4]; int ns = 0;
+				const uint32_t kids[2] = { it.node + 1, rightOf(it.node) };
+				for (uint32_t c : kids) {
+					if (c >= m.n_nodes || !inside(c, it.node)) { nested = false; break; }
+					if (isLeaf(c)) slots[ns++] = c;
+					else {
+						const uint32_t g[2] = { c + 1, rightOf(c) };
+						for (uint32_t gc : g) { if (gc >= m.n_nodes || !inside(gc, c)) { nested = false; break; } slots[ns++] = gc; }
+					}
+				}
+				if (!nested) break;
+				// children wide nodes are created in REVERSE so that the vector stays in pre-order when popped; indices are fixed here
+				uint32_t childWide[4] = { 0, 0, 0, 0 };
+				for (int k = 0; k < ns; k++)
+					if (!isLeaf(slots[k])) { childWide[k] = (uint32_t)wide.size(); wide.emplace_back(); memset(&wide.back(), 0, sizeof(WideNode)); }
+				for (int k = ns - 1; k >= 0; k--) {
+					Node sl = nodes[slots[k]];
+					if (!isLeaf(slots[k])) { sl.link = (int32_t)childWide[k] + 1; sl.first = 0; todo.push_back({ slots[k], childWide[k], it.depth + 1 }); }
+					wide[it.wideIndex].slot[k] = sl;
+				}
+			}
+			// the walk's stack holds at most 3 entries per wide level + 4
+			if (!nested || 3 * depthMax + 4 > 60) wide.clear();
+		}
 		// leaf references in the reference's order, three parallel arrays padded by one wave
 		std::vector<RefA> refA((size_t)m.n_refs + 64);
 		std::vector<RefB> refB((size_t)m.n_refs + 64);
@@ -268,6 +313,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		memset(&dm, 0, sizeof(dm));
 		int rc;
 		if ((rc = upload(s->owned, nodes.data(), nodes.size(), &dm.nodes))) return bail(rc);
+		if ((rc = upload(s->owned, wide.data(), wide.size(), &dm.wide))) return bail(rc);
+		dm.nWide = (uint32_t)wide.size();
 		if ((rc = upload(s->owned, refA.data(), refA.size(), &dm.refA))) return bail(rc);
 		if ((rc = upload(s->owned, refB.data(), refB.size(), &dm.refB))) return bail(rc);
 		if ((rc = upload(s->owned, refC.data(), refC.size(), &dm.refC))) return bail(rc);

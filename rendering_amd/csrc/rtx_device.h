@@ -18,6 +18,15 @@ struct Node {
 };
 static_assert(sizeof(Node) == 32, "node must be one s_load_dwordx8");
 
+// Four slots = the grandchildren of a binary node (a child that is a leaf takes one slot itself), left to right, in the
+// layout of four Node records.  link > 0: inner node, link - 1 = index of its own WideNode; link < 0: leaf with ~link
+// references from `first`; link == 0: empty slot.  One WideNode = two s_load_dwordx16: one dependent fetch per TWO levels
+// of the reference's tree.  Skipping the boxes of the levels in between is exact: every box lies inside its parent's, and
+// for nested boxes the slab products are monotone in the bounds, so a ray that passes a box passes every box around it --
+// a ray reaches a leaf (objects.cpp:587-631) iff it passes the leaf's OWN box (no NaN: see meshWalk).
+struct WideNode { Node slot[4]; };
+static_assert(sizeof(WideNode) == 128, "wide node = two s_load_dwordx16");
+
 // Leaf references, duplicated per leaf in the reference's DFS-left-first order (objects.cpp:622-629): reference r of the
 // mesh (r = Node::first + position in the leaf) is one entry of three parallel arrays, so that LANE i of a wave reads
 // reference base + i with three fully coalesced vector loads (16 + 16 + 8 bytes per lane):
@@ -50,6 +59,10 @@ struct Mesh {
 	uint32_t nNodes, nRefs, nTris;
 	uint32_t dW, dH, nW, nH, sW, sH;
 	uint32_t boxesRegular;   // every node box is finite with lo <= hi on all axes (lets the walk use the min / max form of the box test)
+	// The same tree with every other level skipped (`wide`, see WideNode): usable when no NaN can arise and every box
+	// lies inside its parent's (nWide = 0 otherwise).
+	const struct WideNode* wide;
+	uint32_t nWide, padw;
 	// bundle splitting (rtx_kernels.hip, traceWave): a wave's rays are walked as ONE bundle unless the bundle is wider than
 	// fatRadius at this mesh (a few mean triangle edges); centre / radius = bounding sphere of the root box
 	float fatRadius, centre[3], radius;

@@ -519,6 +519,9 @@ __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, floa
 #ifndef RTX_NODE_PACKED
 #define RTX_NODE_PACKED 0         // packed fp32 box test (6 instructions, 12 VGPRs of duplicated operands) or plain (12 instructions)
 #endif
+#ifndef RTX_WIDE
+#define RTX_WIDE 1                // walk the tree two levels at a time where that is exact (rtxd::WideNode)
+#endif
 #ifndef RTX_MAX_SPLITS
 #define RTX_MAX_SPLITS 4          // halvings of a wide bundle
 #endif
@@ -528,7 +531,24 @@ __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, floa
 // one reached leaf: first reference, number of references, the lanes (rays) that passed its box, start in the batch's stream
 struct LeafEntry { uint32_t first, count, maskLo, maskHi, start, pad[3]; };
 __shared__ LeafEntry leafBatch[4][RTX_LEAF_BATCH];      // per wave of a 256-thread block; private to the wave (no barrier)
-template <bool STATS, bool CULL, bool REGULAR>
+// WIDE walk: pending subtrees / leaves of the wave, top of the stack = next in the reference's order.  link > 0: wide node
+// link - 1; link < 0: leaf with ~link references from `first`; mask = the rays that passed the item's own box.
+struct WideItem { int32_t link; uint32_t first, maskLo, maskHi; };
+__shared__ WideItem wideStack[4][64];
+// the reference's box test in its min / max form (exact when no NaN can arise, see meshWalk) against a box in SGPRs
+__device__ __forceinline__ bool boxFailsRegular(float blox, float bhix, float bloy, float bhiy, float bloz, float bhiz, const V3& o, float ix, float iy, float iz)
+{
+	const float xlo = (blox - o.x) * ix, xhi = (bhix - o.x) * ix, ylo = (bloy - o.y) * iy, yhi = (bhiy - o.y) * iy;
+	const float zlo = (bloz - o.z) * iz, zhi = (bhiz - o.z) * iz;
+	float nx, ny, nz, fx, fy, fz, tn, tf;
+	asm("v_min_f32 %0, %1, %2" : "=v"(nx) : "v"(xlo), "v"(xhi)); asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(xlo), "v"(xhi));
+	asm("v_min_f32 %0, %1, %2" : "=v"(ny) : "v"(ylo), "v"(yhi)); asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(ylo), "v"(yhi));
+	asm("v_min_f32 %0, %1, %2" : "=v"(nz) : "v"(zlo), "v"(zhi)); asm("v_max_f32 %0, %1, %2" : "=v"(fz) : "v"(zlo), "v"(zhi));
+	asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn) : "v"(nx), "v"(ny), "v"(nz));
+	asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx), "v"(fy), "v"(fz));
+	return tn > tf;
+}
+template <bool STATS, bool CULL, bool REGULAR, bool WIDE = false>
 __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
                                          float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
                                          float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
@@ -548,10 +568,64 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 	const uint32_t last = nN - 1;
 	u32x8 nd = sload8(nodes);
 	LeafEntry* entries = leafBatch[threadIdx.x >> 6];
+	// WIDE: the tree with every other level skipped (rtxd::WideNode), walked with a wave-level stack in LDS; one dependent
+	// fetch per two levels.  The items carry the rays that passed their own box, so nothing per lane has to remember where
+	// it is in the tree; `resume` only marks the rays that are done.
+	WideItem* stack = wideStack[threadIdx.x >> 6];
+	const WideNode* wideNodes = WIDE ? uni((const WideNode*)sloadp(&M->wide)) : nullptr;
+	uint32_t sp = 0;
+	if (WIDE) {
+		// (the rays in `consider` have passed the root box: traceWave)
+		const uint64_t m0 = ballot(consider);
+		if (laneNow() == 0) { WideItem it; it.link = 1; it.first = 0; it.maskLo = (uint32_t)m0; it.maskHi = (uint32_t)(m0 >> 32); stack[0] = it; }
+		sp = 1;
+	}
 	for (;;) {
 		// ---- phase 1: nodes.  The reached leaves are noted in a small per-wave table in LDS.
 		uint32_t batch = 0, total = 0;      // total = references of the batch: its leaves form ONE stream, entry k starts at entries[k].start
-		{
+		if (WIDE) {
+			const uint32_t lane = laneNow();
+			while (sp != 0 && batch < RTX_LEAF_BATCH) {
+				sp = uni(sp - 1);
+				const WideItem it = stack[sp];
+				const int32_t link = (int32_t)uni((uint32_t)it.link);
+				const uint32_t mlo = uni(it.maskLo), mhi = uni(it.maskHi);
+				const bool in = ((((lane & 32u) ? mhi : mlo) >> (lane & 31u)) & 1u) != 0 && resume != kNever;
+				if (link < 0) {
+					// a leaf, in the reference's order: note it with the rays that reached it and are still open
+					const uint64_t m = ballot(in);
+					const uint32_t n = (uint32_t)~link;
+					if (RTX_DBG) cnt.wLeaves++;
+					if (m != 0 && n != 0) {
+						if (lane == 0) {
+							LeafEntry en;
+							en.first = it.first; en.count = n; en.maskLo = (uint32_t)m; en.maskHi = (uint32_t)(m >> 32); en.start = total; en.pad[0] = en.pad[1] = en.pad[2] = 0;
+							entries[batch] = en;
+						}
+						batch = uni(batch + 1);
+						total = uni(total + n);
+					}
+					continue;
+				}
+				if (ballot(in) == 0) continue;
+				if (RTX_DBG) cnt.wNodes++;
+				const WideNode* w = wideNodes + (uint32_t)(link - 1);
+				const u32x16 wa = sload16(w), wb = sload16((const char*)w + 64);
+				// slots 3..0, so that slot 0 ends up on top of the stack
+#define RTX_SLOT(rec, base, k)                                                                                                     \
+				if ((int32_t)rec[base + 6] != 0) {                                                                                   \
+					const bool fail = boxFailsRegular(F(rec[base]), F(rec[base + 1]), F(rec[base + 2]), F(rec[base + 3]), F(rec[base + 4]), F(rec[base + 5]), o, ix, iy, iz); \
+					const uint64_t mk_ = ballot(in && !fail);                                                                       \
+					if (mk_ != 0) {                                                                                                 \
+						if (lane == 0) { WideItem ni; ni.link = (int32_t)rec[base + 6]; ni.first = rec[base + 7]; ni.maskLo = (uint32_t)mk_; ni.maskHi = (uint32_t)(mk_ >> 32); stack[sp] = ni; } \
+						sp = uni(sp + 1);                                                                                           \
+					}                                                                                                               \
+				}
+				RTX_SLOT(wb, 8, 3) RTX_SLOT(wb, 0, 2) RTX_SLOT(wa, 8, 1) RTX_SLOT(wa, 0, 0)
+#undef RTX_SLOT
+			}
+		}
+		else {
 #if RTX_NODE_PACKED
 			const f2 oxx = { o.x, o.x }, oyy = { o.y, o.y }, ozz = { o.z, o.z }, ixx = { ix, ix }, iyy = { iy, iy }, izz = { iz, iz };
 #endif
@@ -688,7 +762,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				if (!STATS && ballot(open) == 0) return;
 			}
 		}
-		if (i >= nN) break;
+		if (WIDE ? sp == 0 : i >= nN) break;
 	}
 }
 
@@ -727,6 +801,7 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 			const bool regular = uni(sload1(&M->boxesRegular)) != 0 &&
 			                     ballot(consider && !(fabsf(ix) < __builtin_inff() && fabsf(iy) < __builtin_inff() && fabsf(iz) < __builtin_inff() &&
 			                                          fabsf(o.x) < 0x1p100f && fabsf(o.y) < 0x1p100f && fabsf(o.z) < 0x1p100f)) == 0;
+			const bool wideOk = RTX_WIDE && uni(sload1(&M->nWide)) != 0;
 			if (uni(sload1(&M->nNodes)) != 0) {
 				const u32x8 rn = sload8(uni((const Node*)sloadp(&M->nodes)));
 				const float xlo = (F(rn[0]) - o.x) * ix, xhi = (F(rn[1]) - o.x) * ix, ylo = (F(rn[2]) - o.y) * iy, yhi = (F(rn[3]) - o.y) * iy;
@@ -757,7 +832,8 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 					B = makeBundle(cl, o, d);
 				}
 				float bt, bu, bv; uint32_t btri;
-				if (cull && regular) meshWalk<STATS, true, true>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				if (!STATS && cull && regular && wideOk) meshWalk<STATS, true, true, true>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				else if (cull && regular) meshWalk<STATS, true, true>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				else if (cull) meshWalk<STATS, true, false>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				else meshWalk<STATS, false, false>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				if (cl && bt < kFltMax && bt < h.t) { h.obj = (int)oi; h.t = bt; h.tri = btri; h.u = bu; h.v = bv; }   // scene.cpp:740-745
