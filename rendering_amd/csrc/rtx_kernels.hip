@@ -369,12 +369,32 @@ __device__ __forceinline__ void centreRadius(float lo, float hi, float& c, float
 	r = unif((0.5f * (hi - lo)) * (1.0f + 0x1p-19f) + 0x1p-21f * fmaxf(fabsf(lo), fabsf(hi)));
 }
 
+// max and min of one value over the wave, as two interleaved chains of v_max_f32 / v_min_f32 with a DPP source (one
+// instruction per step and chain; s_nop 0 + the other chain's instruction = the two wait states a DPP read of a
+// just-written VGPR needs).  Through __builtin_amdgcn_update_dpp every step is v_mov + v_mov_dpp + canonicalising v_max + v_max.
+__device__ __forceinline__ void waveMaxMin(float& hi, float& lo)
+{
+#define RTX_STEP(ctrl) "v_max_f32_dpp %0, %0, %0 " ctrl "\n\tv_min_f32_dpp %1, %1, %1 " ctrl "\n\ts_nop 0\n\t"
+	asm volatile("s_nop 1\n\t"
+		RTX_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") RTX_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+		RTX_STEP("row_half_mirror row_mask:0xf bank_mask:0xf") RTX_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+		RTX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") RTX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+		"s_nop 0" : "+v"(hi), "+v"(lo));
+#undef RTX_STEP
+	hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi), 63));
+	lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo), 63));
+}
+
 __device__ __forceinline__ Bundle makeBundle(bool active, const V3& o, const V3& d)
 {
 	const float ninf = -__builtin_inff();
 	Bundle B;
 	float lo, hi;
+#if RTX_BUNDLE_ASM
+#define RTX_RANGE(x, c, r) hi = active ? (x) : ninf; lo = active ? (x) : -ninf; waveMaxMin(hi, lo); centreRadius(lo, hi, c, r)
+#else
 #define RTX_RANGE(x, c, r) hi = waveMax(active ? (x) : ninf); lo = -waveMax(active ? -(x) : ninf); centreRadius(lo, hi, c, r)
+#endif
 	RTX_RANGE(o.x, B.ocx, B.rox); RTX_RANGE(o.y, B.ocy, B.roy); RTX_RANGE(o.z, B.ocz, B.roz);
 	RTX_RANGE(d.x, B.dcx, B.rdx); RTX_RANGE(d.y, B.dcy, B.rdy); RTX_RANGE(d.z, B.dcz, B.rdz);
 #undef RTX_RANGE
@@ -518,6 +538,9 @@ __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, floa
 #endif
 #ifndef RTX_NODE_PACKED
 #define RTX_NODE_PACKED 0         // packed fp32 box test (6 instructions, 12 VGPRs of duplicated operands) or plain (12 instructions)
+#endif
+#ifndef RTX_BUNDLE_ASM
+#define RTX_BUNDLE_ASM 1
 #endif
 #ifndef RTX_WIDE
 #define RTX_WIDE 1                // walk the tree two levels at a time where that is exact (rtxd::WideNode)
