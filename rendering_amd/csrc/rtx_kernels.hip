@@ -337,15 +337,13 @@ template <typename T> __device__ __forceinline__ T after(T x, uint32_t v)
 // steps inside each row of 16, two row broadcasts, the result is read from lane 63.
 __device__ __forceinline__ float waveMax(float v)
 {
-	const int neg = (int)0xff800000u;
-#define RTX_DPP_MAX(ctrl, rowmask) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(neg, __float_as_int(v), ctrl, rowmask, 0xf, false)))
-	RTX_DPP_MAX(0xB1, 0xf);    // quad_perm [1,0,3,2]
-	RTX_DPP_MAX(0x4E, 0xf);    // quad_perm [2,3,0,1]
-	RTX_DPP_MAX(0x141, 0xf);   // row_half_mirror
-	RTX_DPP_MAX(0x140, 0xf);   // row_mirror
-	RTX_DPP_MAX(0x142, 0xa);   // row_bcast15 -> rows 1, 3
-	RTX_DPP_MAX(0x143, 0xc);   // row_bcast31 -> rows 2, 3
-#undef RTX_DPP_MAX
+	// (one v_max_f32 with a DPP source per step; s_nop 1 = the two wait states before a DPP read of a just-written VGPR)
+#define RTX_STEP(ctrl) "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl "\n\t"
+	asm volatile(RTX_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") RTX_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+	             RTX_STEP("row_half_mirror row_mask:0xf bank_mask:0xf") RTX_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+	             RTX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") RTX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+	             "s_nop 0" : "+v"(v));
+#undef RTX_STEP
 	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
