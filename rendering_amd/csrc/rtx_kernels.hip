@@ -729,9 +729,10 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 		// by the lanes that passed the box of the survivor's leaf.
 		const uint32_t lane = laneNow();
 		uint32_t ecur = 0;                 // first entry that is not finished yet
-		for (uint32_t p0 = 0; p0 < total; p0 = uni(p0 + 64)) {
-			// which reference, of which entry, this lane holds: later entries overwrite earlier ones from their start on
-			uint32_t r = 0, myEnt = 0;
+		// which reference, of which entry, a lane holds in the pass that starts at p0: later entries overwrite earlier ones
+		// from their start on
+		auto assign = [&](uint32_t p0, uint32_t& r, uint32_t& myEnt) {
+			r = 0; myEnt = 0;
 			for (uint32_t e = ecur; e < batch; e = uni(e + 1)) {
 				const uint32_t st = uni(entries[e].start);
 				if (st >= p0 + 64) break;
@@ -742,8 +743,9 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				myEnt = here ? e : myEnt;
 				if (st + n <= p0 + 64) ecur = uni(e + 1);              // finished within this pass
 			}
-			const f4v va = *(const RTX_AS1 f4v*)(refA + (r << 4)), vb = *(const RTX_AS1 f4v*)(refB + (r << 4));
-			const f2v vc = *(const RTX_AS1 f2v*)(refC + (r << 3));
+		};
+		// classification of one pass + exact tests of its survivors; true when every ray of the wave is done
+		auto process = [&](uint32_t p0, const f4v& va, const f4v& vb, const f2v& vc, uint32_t myEnt) -> bool {
 			RefA ra; RefB rb; RefC rc;
 			ra.v0x = va.x; ra.v0y = va.y; ra.v0z = va.z; ra.tri = __float_as_uint(va.w);
 			rb.e1x = vb.x; rb.e1y = vb.y; rb.e1z = vb.z; rb.e2x = vb.w; rc.e2y = vc.x; rc.e2z = vc.y;
@@ -751,11 +753,11 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 			const bool valid = p0 + lane < total;
 			const bool rej1 = bundleRejects1<CULL>(B, tmaxB, ra, rb, rc, fs);
 			if (RTX_DBG) cnt.wChunks++;
-			if (ballot(valid && !rej1) == 0) { if (RTX_DBG) cnt.wChunkSkips++; continue; }
+			if (ballot(valid && !rej1) == 0) { if (RTX_DBG) cnt.wChunkSkips++; return false; }
 			const bool rej2 = bundleRejects2<CULL>(B, ra, rb, rc, fs);
 			uint64_t cand = ballot(valid && !rej1 && !rej2);
 			if (RTX_DBG) { cnt.wTri += __popcll(cand); if (cand == 0) cnt.wS2++; }
-			if (cand == 0) continue;
+			if (cand == 0) return false;
 			bool improved = false;
 			while (cand != 0) {
 				const int c = __builtin_ctzll(cand);
@@ -780,8 +782,22 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				// no lane can record a t that is not below its own current limit any more
 				const bool open = resume != kNever;
 				tmaxB = unif(waveMax(open ? fminf(bt, tLimit) : -__builtin_inff()));
-				if (!STATS && ballot(open) == 0) return;
+				if (!STATS && ballot(open) == 0) return true;
 			}
+			return false;
+		};
+		// two passes are requested together: one memory round trip per 128 references
+		for (uint32_t p0 = 0; p0 < total; p0 = uni(p0 + 128)) {
+			uint32_t rA, entA, rB = 0, entB = 0;
+			assign(p0, rA, entA);
+			const f4v vaA = *(const RTX_AS1 f4v*)(refA + (rA << 4)), vbA = *(const RTX_AS1 f4v*)(refB + (rA << 4));
+			const f2v vcA = *(const RTX_AS1 f2v*)(refC + (rA << 3));
+			const bool two = p0 + 64 < total;
+			if (two) assign(p0 + 64, rB, entB);
+			const f4v vaB = *(const RTX_AS1 f4v*)(refA + (rB << 4)), vbB = *(const RTX_AS1 f4v*)(refB + (rB << 4));
+			const f2v vcB = *(const RTX_AS1 f2v*)(refC + (rB << 3));
+			if (process(p0, vaA, vbA, vcA, entA)) return;
+			if (two && process(p0 + 64, vaB, vbB, vcB, entB)) return;
 		}
 		if (WIDE ? sp == 0 : i >= nN) break;
 	}
