@@ -26,6 +26,9 @@
 
 using namespace rtxd;
 
+#ifndef RTX_WAVES_SSAA
+#define RTX_WAVES_SSAA 5   // the SSAA launch lasts as long as its slowest wave: fewer, less spilled waves
+#endif
 #ifndef RTX_SSAA_VERY
 #define RTX_SSAA_VERY 4u   // x 0.25 ms of pass-1 time: tiles above get 4-pixel SSAA waves
 #endif
@@ -1303,7 +1306,7 @@ __device__ __forceinline__ uint32_t nthSetBit(uint64_t m, uint32_t n)   // posit
 }
 
 template <bool STATS>
-__global__ void __launch_bounds__(256, RTX_WAVES) rtxSsaaKernel(const Params P)
+__global__ void __launch_bounds__(256, RTX_WAVES_SSAA) rtxSsaaKernel(const Params P)
 {
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
