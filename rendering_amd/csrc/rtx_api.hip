@@ -76,6 +76,7 @@ struct rtx_scene {
 	size_t sceneBytes = 0;        // bytes of scene data resident in HBM (nodes, leaf references, shading arrays, maps, skybox)
 	Params params;                // template of the kernel argument block
 	bool stats = false;
+	bool analytic = true;         // no object is a triangle mesh: the ray kernels without the walk are launched
 	// lazily sized work buffers
 	float* frames = nullptr; size_t framesBytes = 0, framesArea = 0;
 	uint32_t* tileCost = nullptr; uint32_t* items = nullptr; size_t tileCap = 0;   // per-tile pass-1 cost, SSAA scan array (2 tiles + 1, then scan scratch)
@@ -356,6 +357,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		if (o.type < RTX_OBJ_SPHERE || o.type > RTX_OBJ_MESH) return bail(fail(RTX_ERR_ARG, "bad object type"));
 		if (o.material < 0 || o.material > 3) return bail(fail(RTX_ERR_ARG, "bad material"));
 		if (o.type == RTX_OBJ_MESH && (o.mesh < 0 || (uint32_t)o.mesh >= desc->n_meshes)) return bail(fail(RTX_ERR_ARG, "bad mesh index"));
+		if (o.type == RTX_OBJ_MESH) s->analytic = false;
 		d.type = o.type; d.material = o.material;
 		memcpy(d.pos, o.pos, 12); memcpy(d.color, o.color, 12); memcpy(d.normal, o.normal, 12);
 		d.ior = o.ior; d.ambient = o.ambient; d.diffuse = o.diffuse; d.specular = o.specular; d.nSpecular = o.n_specular;
@@ -547,6 +549,7 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	if (blocks > wavesNeeded) blocks = wavesNeeded ? wavesNeeded : 1;
 	if ((rc = stamp(s, 0, st))) return rc;
 	if (s->stats) hipLaunchKernelGGL(rtxPass1Kernel<true>, dim3(blocks), dim3(256), 0, st, p);
+	else if (s->analytic) hipLaunchKernelGGL((rtxPass1Kernel<false, false>), dim3(blocks), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxPass1Kernel<false>, dim3(blocks), dim3(256), 0, st, p);
 	HIPCHK(hipGetLastError());
 	if ((rc = stamp(s, 0, st))) return rc;
@@ -611,6 +614,7 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	hipLaunchKernelGGL(rtxSsaaScatterKernel, dim3((p.nTiles + 255) / 256), dim3(256), 0, st, p, s->items, mode, s->ssaaPixels, heavyTicks);
 	HIPCHK(hipGetLastError());
 	if (s->stats) hipLaunchKernelGGL(rtxSsaaKernel<true>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
+	else if (s->analytic) hipLaunchKernelGGL((rtxSsaaKernel<false, false>), dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxSsaaKernel<false>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	HIPCHK(hipGetLastError());
 	if ((rc = stamp(s, 2, st))) return rc;
@@ -690,6 +694,18 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 			for (int b = 0; b < 10; b++) fprintf(stderr, " %d", hist[b]);
 			fprintf(stderr, "\n");
 		}
+	}
+#endif
+#if RTX_DBG
+	if (getenv("RTX_DEBUG_ITEMS")) {
+		unsigned long long h[64];
+		HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(gDbgHist), sizeof(h)));
+		{ unsigned long long z[8] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gDbgHist), z, sizeof(z), 8 * sizeof(unsigned long long))); }
+		static const char* names[10] = { "depth limit sky", "next light", "lights done: mirror", "lights done: transparent", "return: mirror", "return: transparent 1", "return: transparent 2", "consume: miss", "consume: shade", "consume: shadow" };
+		for (int k = 0; k < 10; k++) if (h[17 + 2 * k]) fprintf(stderr, "[rtx]   %-26s %8llu wave-level executions, %7.0f cycles each\n", names[k], h[17 + 2 * k], (double)h[16 + 2 * k] / (double)h[17 + 2 * k]);
+		{ unsigned long long z[32] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gDbgHist), z, sizeof(z), 16 * sizeof(unsigned long long))); }
+		if (h[15]) fprintf(stderr, "[rtx] work items %llu: slowest = %llu trace rounds, %llu cycles in Render::trace + %llu in the castRay state machine; "
+		                   "all items: %llu rounds, %.0f + %.0f cycles per round\n", h[15], h[9], h[10], h[11], h[12], (double)h[13] / (double)h[12], (double)h[14] / (double)h[12]);
 	}
 #endif
 #if RTX_DBG >= 2

@@ -35,6 +35,9 @@ using namespace rtxd;
 #ifndef RTX_DBG
 #define RTX_DBG 0     // 1: wave-level stage counters + per-wave pass-1 timeline, 2: + sampled certificate outcomes / leaf-size histograms (slow) (RTX_DEBUG_ITEMS=1 prints them)
 #endif
+#ifndef RTX_WAVES_ANALYTIC
+#define RTX_WAVES_ANALYTIC 4   // scenes without meshes: the whole castRay state in registers (128 VGPRs)
+#endif
 #ifndef RTX_WAVES
 #define RTX_WAVES 6   // target waves per SIMD of the two ray kernels (register budget = 512 / RTX_WAVES VGPRs)
 #endif
@@ -319,6 +322,13 @@ struct Hit { int obj; float t; uint32_t tri; float u, v; };
 #if RTX_DBG
 __device__ unsigned long long gDbgWave[3 * 16384];   // per wave of the last pass 1: first pop, last tile end, busy ticks
 __device__ unsigned long long gDbgHist[64];   // [0,8) certificate outcomes (one sampled lane per evaluation), [16,64) by log2(leaf size)
+#endif
+#if RTX_DBG >= 3      // per-block timers of the castRay state machine (their atomics disturb a full launch: use on small frames)
+#define RTX_T0 const unsigned long long dbgB0 = __builtin_readcyclecounter();
+#define RTX_ACC(k) { const unsigned long long dbgE = __builtin_readcyclecounter() - dbgB0; if (__lane_id() == (uint32_t)__ffsll((long long)ballot(true)) - 1u) { atomicAdd(&gDbgHist[16 + 2 * (k)], dbgE); atomicAdd(&gDbgHist[17 + 2 * (k)], 1ull); } }
+#else
+#define RTX_T0
+#define RTX_ACC(k)
 #endif
 struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips, wChunks, wChunkSkips, triLanes, moot; };
 
@@ -806,7 +816,9 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 	}
 }
 
-template <bool STATS>
+// MESH = false: the variant for scenes without triangle meshes (spheres and planes only).  Without the walk the castRay
+// state machine fits the register file, and a small frame lasts as long as its slowest wave's chain of dependent rays.
+template <bool STATS, bool MESH = true>
 __device__ __forceinline__ void traceWave(const Params& P, bool active, bool shadow, V3 o, V3 d, float tmax,
                                           Hit& h, Counts& cnt)
 {
@@ -826,7 +838,7 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 		// transparent objects do not cast shadows (scene.cpp:733)
 		const bool consider = live && !(shadow && mat == 2);
 		if (ballot(consider) == 0) continue;
-		if (type == 3) {
+		if (MESH && type == 3) {
 			const Mesh* M = uni(P.meshes + (int)rec[9]);
 			// The rays are walked as one bundle (meshWalk) -- unless the bundle is too wide at this mesh for the bundle
 			// filter to reject much (rays of a silhouette tile that hit different objects, a grazing strip of shadow-ray
@@ -988,12 +1000,14 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 	const float bias = P.view.bias;
 	for (;;) {
 		if (s.state == ST_NEWRAY) {
-			if (s.sp > maxDepth) { s.col = skyColor(P, s.rd); s.state = ST_RETURN; continue; }   // scene.cpp:760
+			RTX_T0
+			if (s.sp > maxDepth) { s.col = skyColor(P, s.rd); s.state = ST_RETURN; RTX_ACC(0) continue; }   // scene.cpp:760
 			s.qtmax = kFltMax;
 			s.state = ST_WAIT_PRIMARY;
 			return;
 		}
 		if (s.state == ST_NEXT_LIGHT) {
+			RTX_T0
 			if (s.li >= P.nLights) { s.state = ST_LIGHTS_DONE; continue; }
 			const Light* l = P.lights + s.li;
 			const int lt = l->type;
@@ -1038,9 +1052,11 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 			s.qmoot = s.mat == 0 && fmaxRef(0.f, dot(s.N, -s.L)) == 0.f;
 			s.qtmax = dist;               // the ray itself: Ray{P + N*bias, -L, ShadowRay} (scene.cpp:787), built in castRayWave
 			s.state = ST_WAIT_SHADOW;
+			RTX_ACC(1)
 			return;
 		}
 		if (s.state == ST_LIGHTS_DONE) {
+			RTX_T0
 			const Object* ob = P.objects + s.obj;
 			if (s.mat == 0) { s.col = s.objColor * s.diff; s.state = ST_RETURN; continue; }       // scene.cpp:808
 			if (s.mat == 3) {                                                                   // scene.cpp:852
@@ -1052,7 +1068,7 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 				frameAt(P, gl, s.sp, 2) = s.spec.x; frameAt(P, gl, s.sp, 3) = s.spec.y; frameAt(P, gl, s.sp, 4) = s.spec.z;
 				const V3 nd = s.rd - s.N * (2 * dot(s.rd, s.N));
 				s.ro = s.P + s.N * bias; s.rd = nd;
-				s.sp++; s.state = ST_NEWRAY; continue;
+				s.sp++; s.state = ST_NEWRAY; RTX_ACC(2) continue;
 			}
 			// Transparent, scene.cpp:893-907
 			const float ior = ob->ior;
@@ -1076,14 +1092,15 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 				frameAt(P, gl, s.sp, 5) = 0.f; frameAt(P, gl, s.sp, 6) = 0.f; frameAt(P, gl, s.sp, 7) = 0.f;
 				s.ro = fo; s.rd = fd;
 			}
-			s.sp++; s.state = ST_NEWRAY; continue;
+			s.sp++; s.state = ST_NEWRAY; RTX_ACC(3) continue;
 		}
 		if (s.state == ST_RETURN) {
+			RTX_T0
 			if (s.sp == 0) { s.state = ST_DONE; return; }
 			s.sp--;
 			const int kind = __float_as_int(frameAt(P, gl, s.sp, 0));
 			const V3 spec = mk(frameAt(P, gl, s.sp, 2), frameAt(P, gl, s.sp, 3), frameAt(P, gl, s.sp, 4));
-			if (kind == FR_REFL) { s.col = s.col * 0.8f + spec; continue; }                      // scene.cpp:858, 890
+			if (kind == FR_REFL) { s.col = s.col * 0.8f + spec; RTX_ACC(4) continue; }                      // scene.cpp:858, 890
 			const float kr = frameAt(P, gl, s.sp, 1);
 			if (kind == FR_TRANS1) {                                                             // scene.cpp:896-902
 				const V3 acc = mk(0, 0, 0) + s.col * (1 - kr);
@@ -1091,11 +1108,12 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 				frameAt(P, gl, s.sp, 5) = acc.x; frameAt(P, gl, s.sp, 6) = acc.y; frameAt(P, gl, s.sp, 7) = acc.z;
 				s.ro = mk(frameAt(P, gl, s.sp, 8), frameAt(P, gl, s.sp, 9), frameAt(P, gl, s.sp, 10));
 				s.rd = mk(frameAt(P, gl, s.sp, 11), frameAt(P, gl, s.sp, 12), frameAt(P, gl, s.sp, 13));
-				s.sp++; s.state = ST_NEWRAY; continue;
+				s.sp++; s.state = ST_NEWRAY; RTX_ACC(5) continue;
 			}
 			V3 acc = mk(frameAt(P, gl, s.sp, 5), frameAt(P, gl, s.sp, 6), frameAt(P, gl, s.sp, 7));
 			acc = acc + s.col * kr;                                                              // scene.cpp:908
 			s.col = acc + spec * kr;                                                             // scene.cpp:940
+			RTX_ACC(6)
 			continue;
 		}
 		return;   // ST_DONE / waiting states
@@ -1106,12 +1124,15 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 __device__ __forceinline__ void consume(const Params& P, Lane& s, const Hit& h)
 {
 	if (s.state == ST_WAIT_PRIMARY) {
-		if (h.obj < 0) { s.col = skyColor(P, s.rd); s.state = ST_RETURN; return; }             // scene.cpp:945
+		RTX_T0
+		if (h.obj < 0) { s.col = skyColor(P, s.rd); s.state = ST_RETURN; RTX_ACC(7) return; }             // scene.cpp:945
 		shadePrimary(P, s, h);
 		s.state = ST_NEXT_LIGHT;
+		RTX_ACC(8)
 		return;
 	}
 	if (s.state == ST_WAIT_SHADOW) {
+		RTX_T0
 		const float vis = (h.obj < 0) ? 1.0f : 0.0f;       // bool vis = !trace(...)
 		const bool area = P.lights[s.li].type == 3;
 		const V3 nL = -s.L;
@@ -1135,6 +1156,7 @@ __device__ __forceinline__ void consume(const Params& P, Lane& s, const Hit& h)
 		}
 		if (area) s.si++; else s.li++;
 		s.state = ST_NEXT_LIGHT;
+		RTX_ACC(9)
 	}
 }
 
@@ -1156,7 +1178,7 @@ __device__ __forceinline__ void primaryRay(const Params& P, float x, float y, V3
 	d = r;
 }
 
-template <bool STATS>
+template <bool STATS, bool MESH = true>
 __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 d, uint32_t gl, Counts& cnt)
 {
 	Lane s;
@@ -1167,8 +1189,14 @@ __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 
 	s.specCoef = s.nSpec = s.dsum = s.ssum = 0;
 	s.qtmax = kFltMax; s.qmoot = false;
 	advance(P, s, gl);
+#if RTX_DBG
+	unsigned long long dbgRounds = 0, dbgTrace = 0, dbgState = 0;
+#endif
 	while (ballot(s.state != ST_DONE) != 0) {
 		Hit h;
+#if RTX_DBG
+		const unsigned long long dbgT0 = __builtin_readcyclecounter();
+#endif
 		// moot shadow rays (see advance): only the instrumented variant walks them -- the reference's statistics count
 		// them; here the lane just sits the trace out and consumes "not occluded", which gives the same +0 product
 		const bool moot = s.state == ST_WAIT_SHADOW && s.qmoot;
@@ -1176,12 +1204,26 @@ __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 
 		// the pending request of every lane: a shadow ray from the point being shaded, or the lane's current ray
 		const bool qshadow = s.state == ST_WAIT_SHADOW;
 		const V3 qo = qshadow ? s.P + s.N * P.view.bias : s.ro, qd = qshadow ? -s.L : s.rd;
-		traceWave<STATS>(P, s.state != ST_DONE && (STATS || !moot), qshadow, qo, qd, s.qtmax, h, cnt);
+		traceWave<STATS, MESH>(P, s.state != ST_DONE && (STATS || !moot), qshadow, qo, qd, s.qtmax, h, cnt);
+#if RTX_DBG
+		const unsigned long long dbgT1 = __builtin_readcyclecounter();
+#endif
 		if (s.state != ST_DONE) {
 			consume(P, s, h);
 			advance(P, s, gl);
 		}
+#if RTX_DBG
+		dbgRounds++; dbgTrace += dbgT1 - dbgT0; dbgState += __builtin_readcyclecounter() - dbgT1;
+#endif
 	}
+#if RTX_DBG
+	// trace rounds of one work item, and where its cycles went (s_memtime): slowest item and sums
+	if (__lane_id() == 0) {
+		const unsigned long long before = atomicMax(&gDbgHist[8], dbgTrace + dbgState);
+		if (dbgTrace + dbgState > before) { gDbgHist[9] = dbgRounds; gDbgHist[10] = dbgTrace; gDbgHist[11] = dbgState; }
+		atomicAdd(&gDbgHist[12], dbgRounds); atomicAdd(&gDbgHist[13], dbgTrace); atomicAdd(&gDbgHist[14], dbgState); atomicAdd(&gDbgHist[15], 1ull);
+	}
+#endif
 	return s.col;
 }
 
@@ -1225,8 +1267,8 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 // ------------------------------------------------------------------------------------------------
 // Pass 1: Scene::renderWorker over 8x8 pixel tiles (scene.cpp:444-468)
 // ------------------------------------------------------------------------------------------------
-template <bool STATS>
-__global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
+template <bool STATS, bool MESH = true>
+__global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rtxPass1Kernel(const Params P)
 {
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
@@ -1266,7 +1308,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES) rtxPass1Kernel(const Params P)
 			if (sload1(P.tileCost + ty * P.tilesXFull + tx) > RTX_PRIO_TICKS) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 #endif
 			const unsigned long long t0 = wall_clock64();
-			const V3 c = castRayWave<STATS>(P, valid, o, d, gl, cnt);
+			const V3 c = castRayWave<STATS, MESH>(P, valid, o, d, gl, cnt);
 			const unsigned long long dt = wall_clock64() - t0;
 #if RTX_DBG
 			dbgEnd = t0 + dt; dbgBusy += dt;
@@ -1305,8 +1347,8 @@ __device__ __forceinline__ uint32_t nthSetBit(uint64_t m, uint32_t n)   // posit
 	return pos;
 }
 
-template <bool STATS>
-__global__ void __launch_bounds__(256, RTX_WAVES_SSAA) rtxSsaaKernel(const Params P)
+template <bool STATS, bool MESH = true>
+__global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTIC) rtxSsaaKernel(const Params P)
 {
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
@@ -1333,7 +1375,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES_SSAA) rtxSsaaKernel(const Param
 		V3 o, d;
 		primaryRay(P, fx, fy, o, d);
 		const unsigned long long t0 = STATS ? wall_clock64() : 0;
-		const V3 c = castRayWave<STATS>(P, valid, o, d, gl, cnt);
+		const V3 c = castRayWave<STATS, MESH>(P, valid, o, d, gl, cnt);
 		if (STATS && lane == 0) { atomicMax(P.counters + 3, wall_clock64() - t0); atomicAdd(P.counters + 4, wall_clock64() - t0); }
 		// color = 0; color += c0; += c1; += c2; += c3; fb = color / 4
 		const int base = (int)(lane & ~3u);
@@ -1545,3 +1587,5 @@ template __global__ void rtxPass1Kernel<false>(const Params);
 template __global__ void rtxPass1Kernel<true>(const Params);
 template __global__ void rtxSsaaKernel<false>(const Params);
 template __global__ void rtxSsaaKernel<true>(const Params);
+template __global__ void rtxPass1Kernel<false, false>(const Params);
+template __global__ void rtxSsaaKernel<false, false>(const Params);
