@@ -134,16 +134,16 @@ def stamped(path):
     return d, None
 
 
-def pmc_roofline(avg_ms, scene_bytes, fb_bytes):
+def pmc_roofline(avg_ms, scene_bytes, fb_bytes, kernel="rtxPass1Kernel<false>"):
     """Hardware-counter side of the roofline of rtxPass1Kernel<false>: VALU wave-instructions and HBM-side bytes per
     launch from profiles/r02_pass1_pmc.json (tools/pmc_pass1.sh: separate rocprofv3 --pmc passes of this command), over
     the launch duration measured live in THIS run."""
     d, why = stamped(PMC_JSON)
     if d is None:
         return {"counters": None, "note": why}
-    k = [v for n, v in d["kernels"].items() if "Pass1Kernel<false>" in n]
+    k = [v for n, v in d["kernels"].items() if kernel.replace("rtx", "") in n]
     if not k:
-        return {"counters": None, "note": "no pass-1 kernel in " + os.path.basename(PMC_JSON)}
+        return {"counters": None, "note": "no %s in %s" % (kernel, os.path.basename(PMC_JSON))}
     k = k[0]
     valu = k["SQ_INSTS_VALU"]
     # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced streaming reads (the leaf-reference
@@ -296,6 +296,11 @@ def main():
         dist.all_reduce(tot)
     rays_per_frame = int(tot[0])
 
+    # rtx_render_frame measures, on the first warm frames of a view, whether one launch or three are faster for it, from
+    # events it reads back without waiting; a few synchronised frames let it settle before the untimed warmup
+    for _ in range(6):
+        step()
+        sync()
     for _ in range(args.warmup):
         step()
     sync()
@@ -322,7 +327,12 @@ def main():
         sync()
     n1, ms1 = scene.kernel_time_stats(0)
     n2, ms2 = scene.kernel_time_stats(2)
-    avg_ms = ms1 / max(n1, 1)
+    n4, ms4 = scene.kernel_time_stats(4)
+    frame_mode, split_ms, fused_ms = scene.frame_mode() if ssaa else (0, -1.0, -1.0)
+    # the dominant kernel: pass 1, or the single kernel of the frame where that is what ran
+    one_launch = ssaa and n4 > n1
+    dom_kernel = "rtxFrameKernel<true>" if one_launch else "rtxPass1Kernel<false>"
+    avg_ms = ms4 / max(n4, 1) if one_launch else ms1 / max(n1, 1)
     # cold frame: a freshly created scene in the warm process -- its first pass 1 has no tile costs of a previous launch to
     # order its queues by (the reference's use case is one frame per process)
     cold_ms = None
@@ -341,11 +351,11 @@ def main():
     rendered_px = (W - 1) * (H - 1) / world
     alg_bytes = 32.0 * float(c1[1]) + 40.0 * float(c1[2]) + 12.0 * rendered_px
     walked = rays_per_frame - int(tot[3])
-    roof = {"bound": "valu_issue", "kernel": "rtxPass1Kernel<false>", "avg_launch_ms": round(avg_ms, 3), "launches_timed": n1,
+    roof = {"bound": "valu_issue", "kernel": dom_kernel, "avg_launch_ms": round(avg_ms, 3), "launches_timed": n4 if one_launch else n1,
             "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINSTR, "achieved": None, "frac": None, "traffic": None,
             "algorithmic_ref_semantics_bytes": int(alg_bytes), "box_tests": int(c1[1]), "tri_tests": int(c1[2])}
     if world == 1:
-        pm = pmc_roofline(avg_ms, scene.scene_bytes(), 12.0 * rendered_px)
+        pm = pmc_roofline(avg_ms, scene.scene_bytes(), 12.0 * rendered_px, dom_kernel)
         if pm.get("valu_instructions"):
             roof["achieved"] = round(pm["valu_ginstr_s"], 1)
             roof["frac"] = round(min(pm["valu_ginstr_s"] / VALU_PEAK_GINSTR, 1.0), 4)
@@ -366,7 +376,10 @@ def main():
                    "walked_rays_per_frame": walked, "walked_mrays_s": round(walked * args.steps / dt / 1e6, 3),
                    "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.BAND, world, ", BGR8 bands collected on rank 0" if world > 1 else ""),
                    "gather": gather_via,
-                   "pass1_ms": round(avg_ms, 3), "ssaa_ms": round(ms2 / max(n2, 1), 3),
+                   "frame": ("one launch (rtxFrameKernel)" if one_launch else "three launches (pass 1, Sobel, SSAA)") if ssaa else "pass 1 only",
+                   "measured_three_launches_ms": None if split_ms < 0 else round(split_ms, 3), "measured_one_launch_ms": None if fused_ms < 0 else round(fused_ms, 3),
+                   "pass1_ms": round(ms1 / n1, 3) if n1 else None, "ssaa_ms": round(ms2 / n2, 3) if n2 else None,
+                   "frame_kernel_ms": round(ms4 / n4, 3) if n4 else None,
                    "cold_frame_ms": None if cold_ms is None else round(cold_ms, 3),
                    "pass1_rays_rank0": int(c1[0]), "ssaa_rays_rank0": int(c2[0]), "ssaa_pixels_rank0": int(mask.sum()),
                    "ssaa_box_tests": int(c2[1]), "ssaa_tri_tests": int(c2[2])},

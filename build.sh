@@ -8,7 +8,7 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize 
   -save-temps=obj -Rpass-analysis=kernel-resource-usage $RTX_DEFS \
   -o build/librtx_hip.so rendering_amd/csrc/rtx_api.hip 2> build/hipcc.log || { cat build/hipcc.log; exit 1; }
 cp build/librtx_hip.so rendering_amd/librtx_hip.so
-grep -E 'Function Name|VGPRs:|TotalSGPRs|ScratchSize|Occupancy' build/hipcc.log | sed -e 's/.*usage-analysis..//' -e 's/remark: [^ ]* *//' -e 's/ \[-Rpass.*//' | paste - - - - - | grep -E 'Pass1|Ssaa' || true
+grep -E 'Function Name|VGPRs:|TotalSGPRs|ScratchSize|Occupancy' build/hipcc.log | sed -e 's/.*usage-analysis..//' -e 's/remark: [^ ]* *//' -e 's/ \[-Rpass.*//' | paste - - - - - | grep -E 'Pass1|Ssaa|Frame' || true
 # host side: C++17 Scene/Options/Object API + loaders + BVH builder + flattener, linked against the C ABI
 HOST=rendering_amd/host
 HIPINC=/opt/rocm/include

@@ -142,6 +142,23 @@ int rtx_scene_set_view(rtx_scene* scene, const rtx_view* view);
  * are never written, as in the reference (scene.cpp:369-372).  Asynchronous on `stream`. */
 int rtx_render_pass1(rtx_scene* scene, uint32_t row_begin, uint32_t row_end, float* fb_dev, void* stream);
 
+/* The whole frame in one launch: the same pixels and the same mask as
+ *   rtx_render_pass1(rows) ; rtx_sobel(rows) ; rtx_render_ssaa(rows)
+ * (scene.cpp:444-568: renderWorker, the Sobel pass and SSAAworker of Scene::render), with the three stages
+ * overlapped on the device through per-tile dependencies instead of separated by launch boundaries.
+ * mask_dev rows [row_begin, row_end) are written completely (0 for rows owned by another part).
+ * Asynchronous on `stream`; rtx_frame_status synchronises and reports a frame kernel that gave up
+ * (status != 0 -- a bug guard, see rtx_kernels.hip).
+ * Whether the single launch or the three launches are faster depends on the view (slowest tile against total work);
+ * rtx_render_frame measures both on the first warm frames of a view and keeps the faster (environment
+ * RTX_FRAME_MODE=fused|split forces one).  rtx_frame_mode: what the last call used (0 three launches, 1 one launch)
+ * and the measured durations of the current view (ms, -1 = not measured yet).
+ * which = 3 in rtx_last_kernel_ms / rtx_kernel_time_stats: the frame, either way; 4: the single launch's kernel alone. */
+int rtx_render_frame(rtx_scene* scene, uint32_t row_begin, uint32_t row_end, float* fb_dev, uint8_t* mask_dev, void* stream);
+int rtx_frame_status(rtx_scene* scene, uint32_t* status);
+int rtx_frame_mode(rtx_scene* scene, int* mode, float* split_ms, float* fused_ms);
+int rtx_set_frame_mode(rtx_scene* scene, int mode); /* -1 measure and choose (default), 0 always three launches, 1 always one */
+
 /* Sobel edge mask of Scene::launchSSAA (scene.cpp:547-568) for rows [row_begin,row_end); reads the
  * 3x3 neighbourhood from fb_dev; border entries (row 0, H-1, column 0, W-1) are written as 0. */
 int rtx_sobel(rtx_scene* scene, const float* fb_dev, uint32_t row_begin, uint32_t row_end,
@@ -166,7 +183,7 @@ int rtx_counters_reset(rtx_scene* scene);
 int rtx_counters_read(rtx_scene* scene, rtx_counters* out); /* synchronises the device */
 
 /* Kernel timing from HIP events recorded on the launch stream around every launch.
- * which: 0 = pass 1, 1 = sobel, 2 = ssaa (mask compaction + 4-ray kernel).
+ * which: 0 = pass 1, 1 = sobel, 2 = ssaa (mask compaction + 4-ray kernel), 3 / 4: see rtx_render_frame.
  * rtx_last_kernel_ms: the most recent launch (synchronises on its stop event).
  * rtx_kernel_time_stats: number of launches and their summed duration since rtx_kernel_time_reset
  * (synchronises on the recorded events; call it after the timed region). */

@@ -34,7 +34,7 @@ _host = None
 # every entry point declared in include/rtx.h
 RTX_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_set_view", "rtx_scene_bytes",
-    "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_quantize_bgr8", "rtx_render_frame_host",
+    "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_render_frame", "rtx_frame_status", "rtx_frame_mode", "rtx_set_frame_mode", "rtx_quantize_bgr8", "rtx_render_frame_host",
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
     "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
     "rtx_bvh_build", "rtx_bvh_info", "rtx_bvh_read", "rtx_bvh_destroy",
@@ -64,6 +64,10 @@ def load():
     rtx.rtx_render_pass1.argtypes = [vp, u32, u32, vp, vp]
     rtx.rtx_sobel.argtypes = [vp, vp, u32, u32, vp, vp]
     rtx.rtx_render_ssaa.argtypes = [vp, vp, u32, u32, vp, vp]
+    rtx.rtx_render_frame.argtypes = [vp, u32, u32, vp, vp, vp]
+    rtx.rtx_frame_status.argtypes = [vp, C.POINTER(C.c_uint32)]
+    rtx.rtx_set_frame_mode.argtypes = [vp, C.c_int]
+    rtx.rtx_frame_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     rtx.rtx_quantize_bgr8.argtypes = [vp, vp, vp, vp]
     rtx.rtx_render_frame_host.argtypes = [vp, i32, vp]
     rtx.rtx_counters_enable.argtypes = [vp, i32]
@@ -346,6 +350,28 @@ class Scene:
         _check(self.rtx.rtx_render_ssaa(self.gpu(), C.c_void_p(mask.data_ptr()), r0, r1, C.c_void_p(fb.data_ptr()),
                                         self._stream_ptr(stream)), "rtx_render_ssaa")
 
+    def render_frame(self, fb, mask, rows=None, stream=None):
+        """Pass 1 + Sobel + SSAA of rows [r0,r1) in one launch (rtx_render_frame): same fb and mask as the three calls."""
+        r0, r1 = rows if rows is not None else (0, self.height)
+        _check(self.rtx.rtx_render_frame(self.gpu(), r0, r1, C.c_void_p(fb.data_ptr()), C.c_void_p(mask.data_ptr()),
+                                         self._stream_ptr(stream)), "rtx_render_frame")
+
+    def frame_status(self):
+        """Synchronises; raises if the frame kernel of rtx_render_frame gave up (a bug guard), else returns 0."""
+        st = C.c_uint32(0)
+        _check(self.rtx.rtx_frame_status(self.gpu(), C.byref(st)), "rtx_frame_status")
+        return st.value
+
+    def set_frame_mode(self, mode):
+        """render_frame: -1 measure and choose (default), 0 always three launches, 1 always one launch."""
+        _check(self.rtx.rtx_set_frame_mode(self.gpu(), int(mode)), "rtx_set_frame_mode")
+
+    def frame_mode(self):
+        """(mode of the last render_frame: 0 three launches / 1 one launch, measured split ms, measured fused ms; -1 = not yet)."""
+        m, a, b = C.c_int(-1), C.c_float(-1), C.c_float(-1)
+        _check(self.rtx.rtx_frame_mode(self.gpu(), C.byref(m), C.byref(a), C.byref(b)), "rtx_frame_mode")
+        return m.value, a.value, b.value
+
     def quantize(self, fb, out, stream=None):
         _check(self.rtx.rtx_quantize_bgr8(self.gpu(), C.c_void_p(fb.data_ptr()), C.c_void_p(out.data_ptr()),
                                           self._stream_ptr(stream)), "rtx_quantize_bgr8")
@@ -391,7 +417,7 @@ class Scene:
         _check(self.rtx.rtx_kernel_time_reset(self.gpu()), "rtx_kernel_time_reset")
 
     def kernel_time_stats(self, which=0):
-        """(launches, total_ms) of kernel `which` (0 pass 1, 1 sobel, 2 ssaa) since kernel_time_reset()."""
+        """(launches, total_ms) of kernel `which` (0 pass 1, 1 sobel, 2 ssaa, 3 whole frame) since kernel_time_reset()."""
         n, ms = C.c_uint32(0), C.c_double(0)
         _check(self.rtx.rtx_kernel_time_stats(self.gpu(), which, C.byref(n), C.byref(ms)), "rtx_kernel_time_stats")
         return n.value, ms.value

@@ -83,22 +83,38 @@ struct rtx_scene {
 	uint32_t* ssaaPixels = nullptr; size_t ssaaPixCap = 0;                         // SSAA flagged-pixel list (<= W * H entries)
 	uint32_t* work = nullptr;     // 256 words: [1] SSAA queue head, [3] probe queue head, [8] SSAA list mode, [9] flagged pixels, [128 + 16 q] pass-1 queue head of XCD q
 	unsigned long long* counters = nullptr;
-	int blocksPass1 = 0, blocksSsaa = 0;
+	int blocksPass1 = 0, blocksSsaa = 0, blocksFrame = 0;
+	// rtx_render_frame: dependency counters (ready, sobel), flags, SSAA item queue, control words
+	uint32_t* tileDeps = nullptr; unsigned long long* tileFlags = nullptr; uint8_t* tileClass = nullptr; size_t depCap = 0;
+	unsigned long long* ssaaQueue = nullptr; size_t queueCap = 0;
+	unsigned long long* frameCtl = nullptr;
+	uint32_t epoch = 0;
 	// pass-1 tile queues (buildTileList): rebuilt when the view, the row range or the row ownership changes
 	std::vector<float> meshBounds;        // 6 floats per mesh: the root box
 	struct TileQueues {
 		std::vector<uint32_t> key;        // what the list was built for (view, row range, row ownership)
 		uint32_t* list = nullptr; size_t cap = 0;   // [0, cap): queues in geometric order, [cap, 2 cap): ordered by cost
+		uint8_t* need = nullptr; size_t needCap = 0; uint32_t listed = 0;
+		uint32_t* countExpect = nullptr; uint32_t countGroups = 0;          // listed tiles by index % 64 (the frame kernel's completion counters)   // rtx_render_frame: listed tiles in each tile's 3x3 neighbourhood
 		bool costValid = false;           // tileCost holds the costs of a launch with this key
 		uint64_t lastUse = 0;
+		// rtx_render_frame: measured duration of the frame in either mode (0: three launches, 1: one launch), -1 = not yet
+		float frameMs[2] = { -1.f, -1.f };
+		uint32_t frameSamples[2] = { 0, 0 };
+		uint32_t framesSeen = 0, generation = 0;
 	};
+	// rtx_render_frame: event pairs around the last few frames, read back (without waiting) by later calls
+	struct FrameProbe { hipEvent_t a = nullptr, b = nullptr; int mode = -1; size_t queue = 0; uint32_t generation = 0; bool pending = false; };
+	FrameProbe probes[8];
+	unsigned probeNext = 0;
+	int lastFrameMode = -1, frameModeForced = -1;
 	std::vector<TileQueues> tileQueues;   // a few entries: a frame may be rendered in several row ranges
 	uint64_t tileUse = 0;
 	// HIP-event pairs around every launch of {pass 1, sobel, ssaa} since the last rtx_kernel_time_reset
 	// By default only the most recent pair is kept (rtx_last_kernel_ms); rtx_kernel_time_reset starts accumulating
 	// pairs for rtx_kernel_time_stats, up to kMaxTimedLaunches per kernel (later launches overwrite the last pair).
-	std::vector<hipEvent_t> evPool[3];
-	size_t evUsed[3] = { 0, 0, 0 };
+	std::vector<hipEvent_t> evPool[5];      // pass 1, sobel, ssaa, whole frame (rtx_render_frame), its single kernel
+	size_t evUsed[5] = { 0, 0, 0, 0, 0 };
 	bool evCollect = false;
 };
 
@@ -121,6 +137,7 @@ int setView(rtx_scene* s, const rtx_view* v)
 
 constexpr size_t kMaxTimedLaunches = 4096;
 constexpr uint32_t kSsaaSpreadSlots = 1u << 20;
+constexpr size_t kFrameCtlBytes = 256 * 64;      // the frame kernel's control block (FC_* in rtx_kernels.hip), every word on its own line
 
 int ensureWork(rtx_scene* s)
 {
@@ -139,8 +156,13 @@ int ensureWork(rtx_scene* s)
 		if (b < 1) b = 1;
 		if (const char* e = getenv("RTX_SSAA_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < b) b = v; }
 		s->blocksSsaa = b * s->numCUs;
+		if (s->analytic) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxFrameKernel<false>, 256, 0));
+		else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxFrameKernel<true>, 256, 0));
+		if (b < 1) b = 1;
+		if (const char* e = getenv("RTX_FRAME_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < b) b = v; }
+		s->blocksFrame = b * s->numCUs;
 	}
-	const int blocks = s->blocksPass1 > s->blocksSsaa ? s->blocksPass1 : s->blocksSsaa;
+	const int blocks = std::max(s->blocksFrame, s->blocksPass1 > s->blocksSsaa ? s->blocksPass1 : s->blocksSsaa);
 	const uint32_t totalLanes = (uint32_t)blocks * 256u;
 	const int slots = s->params.view.maxDepth + 2;
 	// two areas: pass-1 launches use the first, SSAA launches the second (the two may run concurrently on two streams)
@@ -407,11 +429,17 @@ void rtx_scene_destroy(rtx_scene* s)
 	for (void* p : s->owned) (void)hipFree(p);
 	if (s->frames) (void)hipFree(s->frames);
 	if (s->tileCost) { (void)hipFree(s->tileCost); (void)hipFree(s->items); }
-	for (auto& q : s->tileQueues) if (q.list) (void)hipFree(q.list);
+	for (auto& q : s->tileQueues) { if (q.list) (void)hipFree(q.list); if (q.need) (void)hipFree(q.need); if (q.countExpect) (void)hipFree(q.countExpect); }
+	if (s->tileDeps) (void)hipFree(s->tileDeps);
+	if (s->tileFlags) (void)hipFree(s->tileFlags);
+	if (s->tileClass) (void)hipFree(s->tileClass);
+	for (auto& pr : s->probes) { if (pr.a) (void)hipEventDestroy(pr.a); if (pr.b) (void)hipEventDestroy(pr.b); }
+	if (s->ssaaQueue) (void)hipFree(s->ssaaQueue);
+	if (s->frameCtl) (void)hipFree(s->frameCtl);
 	if (s->ssaaPixels) (void)hipFree(s->ssaaPixels);
 	if (s->work) {
 		(void)hipFree(s->work); (void)hipFree(s->counters);
-		for (int i = 0; i < 3; i++) for (hipEvent_t e : s->evPool[i]) (void)hipEventDestroy(e);
+		for (int i = 0; i < 5; i++) for (hipEvent_t e : s->evPool[i]) (void)hipEventDestroy(e);
 	}
 	delete s;
 }
@@ -468,6 +496,7 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 	rtx_scene::TileQueues* e = &s->tileQueues[0];
 	for (auto& q : s->tileQueues) { if (!q.list) { e = &q; break; } if (q.lastUse < e->lastUse) e = &q; }
 	e->costValid = false; e->key.clear();
+	e->frameMs[0] = e->frameMs[1] = -1.f; e->frameSamples[0] = e->frameSamples[1] = 0; e->framesSeen = 0; e->generation++;
 	const uint32_t H = p.view.height;
 	auto rowOwnedH = [&](uint32_t y) { return p.bandH == 0 || (y / p.bandH) % p.nParts == p.part; };
 	auto rowRenderedH = [&](uint32_t y) {
@@ -498,10 +527,40 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 	if (list.size() > e->cap) {
 		if (e->list) HIPCHK(hipFree(e->list));
 		e->list = nullptr; e->cap = 0;
-		HIPCHK(hipMalloc((void**)&e->list, 2 * list.size() * sizeof(uint32_t)));
+		HIPCHK(hipMalloc((void**)&e->list, 17 * list.size() * sizeof(uint32_t)));      // + the ordered copy, where every tile may be listed in sixteen parts
 		e->cap = list.size();
 	}
 	HIPCHK(hipMemcpy(e->list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	{
+		// rtx_render_frame: how many listed tiles each tile has in its 3x3 neighbourhood (itself included; 0 = not listed)
+		const uint32_t txFull = p.tilesXFull, tyFull = (H + 7) / 8;
+		std::vector<uint8_t> listedAt((size_t)txFull * tyFull, 0), need((size_t)txFull * tyFull, 0);
+		for (size_t i = 16; i < list.size(); i++) listedAt[(size_t)(list[i] >> 16) * txFull + (list[i] & 0xffffu)] = 1;
+		for (size_t i = 16; i < list.size(); i++) {
+			const uint32_t tx = list[i] & 0xffffu, ty = list[i] >> 16;
+			uint8_t n = 0;
+			for (int dy = -1; dy <= 1; dy++)
+				for (int dx = -1; dx <= 1; dx++) {
+					const int64_t nx = (int64_t)tx + dx, ny = (int64_t)ty + dy;
+					if (nx >= 0 && ny >= 0 && nx < txFull && ny < tyFull) n += listedAt[(size_t)ny * txFull + nx];
+				}
+			need[(size_t)ty * txFull + tx] = n;
+		}
+		if (need.size() > e->needCap) {
+			if (e->need) HIPCHK(hipFree(e->need));
+			e->need = nullptr; e->needCap = 0;
+			HIPCHK(hipMalloc((void**)&e->need, need.size()));
+			e->needCap = need.size();
+		}
+		HIPCHK(hipMemcpy(e->need, need.data(), need.size(), hipMemcpyHostToDevice));
+		e->listed = (uint32_t)(list.size() - 16);
+		uint32_t expect[64] = { 0 };
+		for (size_t i = 16; i < list.size(); i++) expect[((size_t)(list[i] >> 16) * txFull + (list[i] & 0xffffu)) & 63u]++;
+		e->countGroups = 0;
+		for (int k = 0; k < 64; k++) e->countGroups += expect[k] != 0;
+		if (!e->countExpect) HIPCHK(hipMalloc((void**)&e->countExpect, sizeof(expect)));
+		HIPCHK(hipMemcpy(e->countExpect, expect, sizeof(expect), hipMemcpyHostToDevice));
+	}
 	e->key = key;
 	e->lastUse = ++s->tileUse;
 	*out = e;
@@ -556,6 +615,203 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	return RTX_OK;
 }
 
+// The frame in one launch (rtxFrameKernel).
+static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, uint8_t* mask_dev, void* stream)
+{
+	const uint32_t W = s->params.view.width, H = s->params.view.height;
+	if (rowEnd > H) rowEnd = H;
+	if (rowBegin >= rowEnd) return RTX_OK;
+	int rc = ensureWork(s);
+	if (rc) return rc;
+	hipStream_t st = (hipStream_t)stream;
+	Params p = s->params;
+	p.fb = fb_dev;
+	p.maskOut = mask_dev;
+	p.rowBegin = rowBegin; p.rowEnd = rowEnd;
+	p.tilesX = (W - 1 + 7) / 8;
+	p.tileRow0 = rowBegin / 8;
+	if (p.view.width > 0xffffu || p.view.height > 0xffffu) return fail(RTX_ERR_ARG, "frame too large");
+	// the mask of the rows is defined everywhere: 0 where no tile computes it (rows of other parts, the last row / column)
+	HIPCHK(hipMemsetAsync(mask_dev + (size_t)rowBegin * W, 0, (size_t)(rowEnd - rowBegin) * W, st));
+	const uint32_t lastRow = (rowEnd < H - 1 ? rowEnd : H - 1);   // exclusive; row H-1 is never rendered
+	if (lastRow <= rowBegin) return RTX_OK;
+	const uint32_t tilesY = (lastRow + 7) / 8 - p.tileRow0;
+	p.nTiles = p.tilesX * tilesY;
+	p.tilesY = tilesY;
+	p.tilesYFull = (H + 7) / 8;
+	p.workCounter = s->work + 128;            // eight per-XCD queue heads, 64 bytes apart
+	rtx_scene::TileQueues* tq = nullptr;
+	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY, &tq))) return rc;
+	const size_t tiles = (size_t)p.tilesXFull * p.tilesYFull;
+	if (tiles > s->depCap) {
+		HIPCHK(hipDeviceSynchronize());
+		if (s->tileDeps) { HIPCHK(hipFree(s->tileDeps)); HIPCHK(hipFree(s->tileFlags)); HIPCHK(hipFree(s->tileClass)); }
+		s->tileDeps = nullptr; s->tileFlags = nullptr; s->tileClass = nullptr; s->depCap = 0;
+		HIPCHK(hipMalloc((void**)&s->tileClass, tiles));
+		HIPCHK(hipMalloc((void**)&s->tileDeps, 4 * tiles * sizeof(uint32_t)));      // pass-1 count, Sobel count, quarter costs, quarter count
+		HIPCHK(hipMalloc((void**)&s->tileFlags, tiles * sizeof(unsigned long long)));
+		s->depCap = tiles;
+	}
+	// 64 queues; in all up to 4 items per tile (16 flagged pixels each) plus the budget of extra items for tiles that get
+	// 4-pixel items.  The items are dealt round the queues, so each holds about 1/64 of them: twice that, and some.
+	const size_t perQueue = 2 * ((4 * tiles + kSsaaSpreadSlots / 16) / 64) + 256;
+	if (tiles >= (1u << 24)) return fail(RTX_ERR_ARG, "frame too large for rtx_render_frame");
+	if (64 * perQueue > s->queueCap) {
+		HIPCHK(hipDeviceSynchronize());
+		if (s->ssaaQueue) HIPCHK(hipFree(s->ssaaQueue));
+		s->ssaaQueue = nullptr; s->queueCap = 0;
+		HIPCHK(hipMalloc((void**)&s->ssaaQueue, 64 * perQueue * sizeof(unsigned long long)));
+		HIPCHK(hipMemset(s->ssaaQueue, 0, 64 * perQueue * sizeof(unsigned long long)));
+		s->queueCap = 64 * perQueue;
+	}
+	if (!s->frameCtl) HIPCHK(hipMalloc((void**)&s->frameCtl, kFrameCtlBytes));
+	if (++s->epoch == 0) s->epoch = 1;
+	p.tileReady = s->tileDeps; p.tileSobel = s->tileDeps + tiles;
+	p.tileNeed = tq->need; p.tileFlags = s->tileFlags;
+	p.ssaaQueue = s->ssaaQueue; p.frameCtl = s->frameCtl;
+	p.listedTiles = tq->listed; p.epoch = s->epoch; p.queueCap = (uint32_t)perQueue; p.veryBudget = kSsaaSpreadSlots / 16;
+	p.countExpect = tq->countExpect; p.countGroups = tq->countGroups;
+	p.heavyTicks = 25000u;
+	if (const char* e = getenv("RTX_SSAA_HEAVY_TICKS")) p.heavyTicks = (uint32_t)strtoul(e, nullptr, 10);       // test knobs
+	if (const char* e = getenv("RTX_SSAA_SPREAD_SLOTS")) p.veryBudget = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), kSsaaSpreadSlots) / 16;
+	p.tileList = tq->list;
+	p.splitLimits = s->work + 18;
+	if (!tq->costValid) HIPCHK(hipMemsetAsync(s->work + 18, 0xff, 2 * sizeof(uint32_t), st));      // no costs yet: nothing is split
+	if (tq->costValid) {
+		// the previous launch rendered exactly these tiles from this view: start with the ones that were expensive
+		HIPCHK(hipMemsetAsync(s->work + 16, 0, 2 * sizeof(uint32_t), st));
+		hipLaunchKernelGGL(rtxTileClassKernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, s->tileCost, p.tilesXFull, p.tilesYFull, s->tileClass, (unsigned long long*)(s->work + 16));
+		uint32_t splitPercent = 100, splitFloor = 2000u;            // floor: 20 us (100 MHz)
+		if (const char* e = getenv("RTX_SPLIT_PERCENT")) splitPercent = (uint32_t)strtoul(e, nullptr, 10);       // experiment knob; 0 = never
+		hipLaunchKernelGGL(rtxTileOrderKernel, dim3(8), dim3(1024), 0, st, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)s->tileClass,
+		                   (const unsigned long long*)(s->work + 16), (uint32_t)s->blocksFrame * 4u, splitPercent, splitFloor, s->work + 18);
+		p.tileList = tq->list + tq->cap;
+	}
+	tq->costValid = true;
+	HIPCHK(hipMemsetAsync(s->work + 128, 0, 128 * sizeof(uint32_t), st));
+	HIPCHK(hipMemsetAsync(s->tileDeps, 0, 4 * tiles * sizeof(uint32_t), st));
+	HIPCHK(hipMemsetAsync(s->frameCtl, 0, kFrameCtlBytes, st));
+	uint32_t blocks = (uint32_t)s->blocksFrame;
+	const uint32_t wavesNeeded = p.nTiles;       // (blocks: quarters of slow tiles and SSAA items want waves too)
+	if (blocks > wavesNeeded) blocks = wavesNeeded ? wavesNeeded : 1;
+	if ((rc = stamp(s, 4, st))) return rc;
+	if (s->analytic) hipLaunchKernelGGL(rtxFrameKernel<false>, dim3(blocks), dim3(256), 0, st, p);
+	else hipLaunchKernelGGL(rtxFrameKernel<true>, dim3(blocks), dim3(256), 0, st, p);
+	HIPCHK(hipGetLastError());
+	if ((rc = stamp(s, 4, st))) return rc;
+	return RTX_OK;
+}
+
+// One launch or three?  The single launch overlaps the stages and splits the slowest tiles -- it wins when the frame is
+// bounded by its slowest tiles (small and medium frames, a shard of a large one), by up to 3x; its per-tile bookkeeping
+// (a dozen device-scope round trips of ~5 us) loses to three plain launches when the frame is throughput-bound and its
+// tiles are cheap.  Which case a view is in is measured, not guessed: the frames are bracketed by events that later
+// calls read back without waiting; both ways are tried on warm frames, the faster one is kept and the other one is
+// tried again every 64 frames.  The pixels are the same either way.
+int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, uint8_t* mask_dev, void* stream)
+{
+	if (!s || !fb_dev || !mask_dev) return fail(RTX_ERR_ARG, "scene/fb/mask is NULL");
+	if (s->stats) return fail(RTX_ERR_UNSUPPORTED, "rtx_render_frame has no instrumented variant: use rtx_render_pass1 / rtx_sobel / rtx_render_ssaa for statistics");
+	const uint32_t W = s->params.view.width, H = s->params.view.height;
+	if (rowEnd > H) rowEnd = H;
+	if (rowBegin >= rowEnd) return RTX_OK;
+	int rc = ensureWork(s);
+	if (rc) return rc;
+	hipStream_t st = (hipStream_t)stream;
+	const uint32_t lastRow = (rowEnd < H - 1 ? rowEnd : H - 1);
+	rtx_scene::TileQueues* tq = nullptr;
+	if (lastRow > rowBegin) {
+		const uint32_t tilesX = (W - 1 + 7) / 8, tileRow0 = rowBegin / 8;
+		if ((rc = buildTileList(s, rowBegin, lastRow, tilesX, tileRow0, (lastRow + 7) / 8 - tileRow0, &tq))) return rc;
+	}
+	// finished frames: take their durations
+	for (auto& pr : s->probes) {
+		if (!pr.pending || hipEventQuery(pr.b) != hipSuccess) continue;
+		pr.pending = false;
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, pr.a, pr.b) != hipSuccess) continue;
+		if (pr.queue < s->tileQueues.size() && s->tileQueues[pr.queue].generation == pr.generation && pr.mode >= 0)
+			{ s->tileQueues[pr.queue].frameMs[pr.mode] = ms; s->tileQueues[pr.queue].frameSamples[pr.mode]++; }
+	}
+	(void)hipGetLastError();
+	int mode;
+	static const int envForced = [] { const char* e = getenv("RTX_FRAME_MODE"); return !e ? -1 : (!strcmp(e, "split") ? 0 : (!strcmp(e, "fused") ? 1 : -1)); }();
+	const int forced = s->frameModeForced >= 0 ? s->frameModeForced : envForced;
+	const bool warm = tq && tq->costValid;
+	if (forced >= 0) mode = forced;
+	else if (!tq) mode = 0;
+	else if (!warm) mode = tq->listed <= 65536u ? 1 : 0;       // no costs yet (nothing can be split or ordered): by size
+	// not measured yet: one launch, again (its first frame of a view also sets up its buffers and has no tile split yet), three
+	else if (tq->frameSamples[0] < 1 || tq->frameSamples[1] < 2) mode = tq->framesSeen % 3u == 0 ? 0 : 1;
+	else {
+		mode = tq->frameMs[1] <= tq->frameMs[0] ? 1 : 0;
+		if ((tq->framesSeen & 63u) == 63u) mode ^= 1;
+	}
+	rtx_scene::FrameProbe& pr = s->probes[s->probeNext++ & 7u];
+	if (!pr.a) { HIPCHK(hipEventCreate(&pr.a)); HIPCHK(hipEventCreate(&pr.b)); }
+	pr.pending = false;
+	HIPCHK(hipEventRecord(pr.a, st));
+	if ((rc = stamp(s, 3, st))) return rc;
+	if (mode == 1) rc = renderFrameFused(s, rowBegin, rowEnd, fb_dev, mask_dev, stream);
+	else {
+		rc = rtx_render_pass1(s, rowBegin, rowEnd, fb_dev, stream);
+		if (!rc) rc = rtx_sobel(s, fb_dev, rowBegin, rowEnd, mask_dev, stream);
+		if (!rc) rc = rtx_render_ssaa(s, mask_dev, rowBegin, rowEnd, fb_dev, stream);
+	}
+	if (rc) return rc;
+	if ((rc = stamp(s, 3, st))) return rc;
+	HIPCHK(hipEventRecord(pr.b, st));
+	if (tq) {
+		// (a cold frame is not a sample: it is slower either way)
+		pr.mode = warm ? mode : -1; pr.queue = (size_t)(tq - s->tileQueues.data()); pr.generation = tq->generation; pr.pending = true;
+		tq->framesSeen++;
+	}
+	s->lastFrameMode = mode;
+	return RTX_OK;
+}
+
+int rtx_set_frame_mode(rtx_scene* s, int mode)
+{
+	if (!s || mode < -1 || mode > 1) return fail(RTX_ERR_ARG, "scene is NULL or mode not in -1 (measure), 0 (three launches), 1 (one launch)");
+	s->frameModeForced = mode;
+	return RTX_OK;
+}
+
+int rtx_frame_mode(rtx_scene* s, int* mode, float* split_ms, float* fused_ms)
+{
+	if (!s || !mode) return fail(RTX_ERR_ARG, "scene/mode is NULL");
+	*mode = s->lastFrameMode;
+	const rtx_scene::TileQueues* best = nullptr;
+	for (const auto& q : s->tileQueues) if (q.list && (!best || q.lastUse > best->lastUse)) best = &q;
+	if (split_ms) *split_ms = best ? best->frameMs[0] : -1.f;
+	if (fused_ms) *fused_ms = best ? best->frameMs[1] : -1.f;
+	return RTX_OK;
+}
+
+int rtx_frame_status(rtx_scene* s, uint32_t* status)
+{
+	if (!s || !status) return fail(RTX_ERR_ARG, "scene/status is NULL");
+	*status = 0;
+	if (!s->frameCtl) return RTX_OK;
+	HIPCHK(hipSetDevice(s->device));
+	HIPCHK(hipDeviceSynchronize());
+#if RTX_DBG
+	if (const char* path = getenv("RTX_DBG_TIMELINE")) {      // work items of the frame launches since the last dump: start, duration, kind << 32 | item
+		std::vector<unsigned long long> tl(3 * 8192 * 160), keep;
+		HIPCHK(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(gDbgTimeline), tl.size() * 8));
+		for (size_t e = 0; e < tl.size() / 3; e++) if (tl[3 * e]) { keep.push_back(tl[3 * e]); keep.push_back(tl[3 * e + 1]); keep.push_back(tl[3 * e + 2] | (unsigned long long)(e / 160) << 48); }
+		std::fill(tl.begin(), tl.end(), 0ull);
+		HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gDbgTimeline), tl.data(), tl.size() * 8));
+		if (FILE* f = fopen(path, "wb")) { fwrite(keep.data(), 8, keep.size(), f); fclose(f); }
+	}
+#endif
+	uint32_t err = 0;
+	HIPCHK(hipMemcpy(&err, (const uint32_t*)s->frameCtl + FC_ERROR, sizeof(err), hipMemcpyDeviceToHost));
+	*status = err;
+	if (err) return fail(RTX_ERR_DEVICE, "rtx_render_frame: the frame kernel gave up (1: queue entry never written, 2: work never completed, 3: SSAA queue overflow)");
+	return RTX_OK;
+}
+
 int rtx_sobel(rtx_scene* s, const float* fb_dev, uint32_t rowBegin, uint32_t rowEnd, uint8_t* mask_dev, void* stream)
 {
 	if (!s || !fb_dev || !mask_dev) return fail(RTX_ERR_ARG, "scene/fb/mask is NULL");
@@ -601,8 +857,10 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	const uint32_t scanN = 2 * p.nTiles + 1;
 	if (const char* e = getenv("RTX_SSAA_HEAVY_TICKS")) heavyTicks = (uint32_t)strtoul(e, nullptr, 10);       // test knobs
 	if (const char* e = getenv("RTX_SSAA_SPREAD_SLOTS")) spreadSlots = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), kSsaaSpreadSlots);
-	// fewer flagged pixels than two full rounds of waves: tile-local waves (see rtxSsaaCountKernel)
-	uint32_t localBelow = (uint32_t)s->blocksSsaa * 4u * 16u * 2u;
+	// tile-local waves (see rtxSsaaCountKernel) unless a test asks for the packed layout
+	// (measured: tile-local waves win at every size -- 4096^2 1.00 against 1.54 ms, 8192^2 1.29 against 1.75 -- so the
+	// packed layout is only what a test asks for)
+	uint32_t localBelow = 0xffffffffu;
 	if (const char* e = getenv("RTX_SSAA_LOCAL_BELOW")) localBelow = (uint32_t)strtoul(e, nullptr, 10);   // test knob: 0 = always packed
 	uint32_t* mode = s->work + 8;             // [0] local mode, [1] flagged pixels, [2] extra slots handed to 4-pixel tiles
 	uint32_t launches = 0;
@@ -724,7 +982,7 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 
 int rtx_last_kernel_ms(rtx_scene* s, int which, float* ms)
 {
-	if (!s || !ms || which < 0 || which > 2) return fail(RTX_ERR_ARG, "bad argument");
+	if (!s || !ms || which < 0 || which > 4) return fail(RTX_ERR_ARG, "bad argument");
 	const size_t n = s->evUsed[which];
 	if (n < 2) return fail(RTX_ERR_ARG, "no such launch recorded yet");
 	HIPCHK(hipSetDevice(s->device));
@@ -736,14 +994,14 @@ int rtx_last_kernel_ms(rtx_scene* s, int which, float* ms)
 int rtx_kernel_time_reset(rtx_scene* s)
 {
 	if (!s) return fail(RTX_ERR_ARG, "scene is NULL");
-	for (int i = 0; i < 3; i++) s->evUsed[i] = 0;
+	for (int i = 0; i < 5; i++) s->evUsed[i] = 0;
 	s->evCollect = true;
 	return RTX_OK;
 }
 
 int rtx_kernel_time_stats(rtx_scene* s, int which, uint32_t* launches, double* total_ms)
 {
-	if (!s || !launches || !total_ms || which < 0 || which > 2) return fail(RTX_ERR_ARG, "bad argument");
+	if (!s || !launches || !total_ms || which < 0 || which > 4) return fail(RTX_ERR_ARG, "bad argument");
 	HIPCHK(hipSetDevice(s->device));
 	*launches = 0; *total_ms = 0;
 	for (size_t i = 0; i + 1 < s->evUsed[which]; i += 2) {

@@ -135,6 +135,17 @@ struct Params {
 	uint32_t nProbe;
 	uint32_t pad1;
 	unsigned long long* counters;   // rays, boxTests, triTests
+	// whole frame in one launch (rtxFrameKernel): per-tile dependency counters, the SSAA item queue
+	uint32_t* tileReady;            // [tile] pass-1 completions seen among the listed tiles of the tile's 3x3 neighbourhood
+	uint32_t* tileSobel;            // [tile] Sobel completions seen among them
+	const uint8_t* tileNeed;        // [tile] number of listed tiles in the 3x3 neighbourhood; 0 = the tile itself is not listed
+	unsigned long long* tileFlags;  // [tile] Sobel-flagged pixels of the tile (bit r * 8 + c)
+	unsigned long long* ssaaQueue;  // 64 queues of queueCap SSAA items: epoch << 32 | tile << 8 | group << 2 | (0: 16, 1: 4, 2: 1 pixels per group)
+	unsigned long long* frameCtl;   // control block (rtx_kernels.hip, FC_*)
+	const uint32_t* countExpect;    // [k], k < 64: listed tiles with index % 64 == k
+	const uint32_t* splitLimits;    // [0], [1]: pass-1 cost (ticks) above which a tile is rendered / re-sampled in 4, in 16 parts (rtxTileOrderKernel)
+	uint8_t* maskOut;               // Sobel mask written by the frame kernel
+	uint32_t listedTiles, epoch, queueCap, veryBudget, tilesYFull, heavyTicks, countGroups, padF;
 };
 
 constexpr int kFrameFields = 14;

@@ -320,6 +320,7 @@ __device__ __forceinline__ float attenuation(float intensity, float l2)
 // ------------------------------------------------------------------------------------------------
 struct Hit { int obj; float t; uint32_t tri; float u, v; };
 #if RTX_DBG
+__device__ unsigned long long gDbgTimeline[3 * 8192 * 160];   // frame kernel: per wave up to 160 work items (start, duration, kind << 32 | item); start 0 = unused
 __device__ unsigned long long gDbgWave[3 * 16384];   // per wave of the last pass 1: first pop, last tile end, busy ticks
 __device__ unsigned long long gDbgHist[64];   // [0,8) certificate outcomes (one sampled lane per evaluation), [16,64) by log2(leaf size)
 #endif
@@ -1394,26 +1395,76 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 // longest-job-first keeps the end of the launch free of long tiles).  One block per queue: histogram of the cost
 // classes (log2 of the ticks), offsets in descending class order, scatter.  The order inside a class is arbitrary --
 // the picture does not depend on the order tiles are rendered in.
-__global__ void __launch_bounds__(1024) rtxTileOrderKernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ cost,
-                                                           uint32_t tilesXFull, uint32_t* __restrict__ out)
+// klass != null (rtx_render_frame): the class of a tile is the highest one within two tiles of it (rtxTileClassKernel) --
+// the SSAA items of a slow tile can only be queued once the 5 x 5 tiles around it have been rendered.
+__global__ void __launch_bounds__(256) rtxTileClassKernel(const uint32_t* __restrict__ cost, uint32_t tilesXFull, uint32_t tilesYFull,
+                                                          uint8_t* __restrict__ klass, unsigned long long* __restrict__ costSum)
 {
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	{
+		// sum of the tile costs = wave-ticks of pass 1 in the previous frame (rtxTileOrderKernel: which tiles to split)
+		unsigned long long mine = t < tilesXFull * tilesYFull ? cost[t] : 0;
+		for (int sh = 32; sh > 0; sh >>= 1) mine += __shfl_xor(mine, sh);
+		if ((threadIdx.x & 63) == 0 && mine) atomicAdd(costSum, mine);
+	}
+	if (t >= tilesXFull * tilesYFull) return;
+	const int ty = (int)(t / tilesXFull), tx = (int)(t - (uint32_t)ty * tilesXFull);
+	uint32_t c = 0;
+	for (int dy = -2; dy <= 2; ++dy)
+		for (int dx = -2; dx <= 2; ++dx) {
+			const int x = tx + dx, y = ty + dy;
+			if (x >= 0 && y >= 0 && x < (int)tilesXFull && y < (int)tilesYFull) c = max(c, cost[(uint32_t)y * tilesXFull + (uint32_t)x]);
+		}
+	klass[t] = (uint8_t)(c ? 31u - (uint32_t)__builtin_clz(c) : 0u);
+}
+
+// splitPercent != 0 (rtx_render_frame): a slow tile is listed as four 4x4-pixel quarters (tile | 0x8000 | part << 13) or
+// sixteen 2x2-pixel parts (| 0x80000000, the upper two bits of the part in bits 29-30), rendered by as many waves --
+// the frame cannot end before its slowest tile has been rendered AND re-sampled, and a wave's time on a tile is mostly
+// the walk of its ray bundle, which a smaller part shortens.  The output queue q starts at 16 + 16 (base_q - 16).
+// Splitting multiplies the work on a tile (each part walks its own bundle), so it is for the tiles that decide when
+// the frame ends: those that took a good part of the time pass 1 would need if its work were spread evenly over the
+// waves (cost sum / waves).  In a small frame that is every tile -- and there are idle waves to take the parts.
+// thresholds[0..1] = the two limits (ticks), also used for the size of the SSAA items (rtxFrameKernel).
+__global__ void __launch_bounds__(1024) rtxTileOrderKernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ cost,
+                                                           uint32_t tilesXFull, uint32_t* __restrict__ out, const uint8_t* __restrict__ klassIn = nullptr,
+                                                           const unsigned long long* __restrict__ costSum = nullptr, uint32_t nWaves = 1,
+                                                           uint32_t splitPercent = 0, uint32_t splitFloor = 0, uint32_t* __restrict__ thresholds = nullptr)
+{
+	uint32_t split4 = 0xffffffffu, split16 = 0xffffffffu;
+	if (costSum && splitPercent) {
+		const unsigned long long even = *costSum / nWaves * splitPercent / 100;
+		split4 = even > 0x0fffffffull ? 0x0fffffffu : (uint32_t)even;
+		if (split4 < splitFloor) split4 = splitFloor;
+		split16 = split4 * 4;
+	}
 	__shared__ uint32_t hist[32], cursor[32];
 	const uint32_t q = blockIdx.x;
 	const uint32_t base = list[q], n = list[8 + q];
+	const uint32_t obase = costSum ? 16 + 16 * (base - 16) : base;
 	if (threadIdx.x < 32) hist[threadIdx.x] = 0;
-	if (threadIdx.x == 0) { out[q] = base; out[8 + q] = n; }
+	if (thresholds && q == 0 && threadIdx.x == 0) { thresholds[0] = split4; thresholds[1] = split16; }
 	__syncthreads();
-	auto klass = [&](uint32_t tile) { const uint32_t c = cost[(tile >> 16) * tilesXFull + (tile & 0xffffu)]; return c ? 31u - (uint32_t)__builtin_clz(c) : 0u; };
-	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[klass(list[base + i])], 1u);
+	auto klass = [&](uint32_t tile) {
+		if (klassIn) return (uint32_t)klassIn[(tile >> 16) * tilesXFull + (tile & 0xffffu)];
+		const uint32_t c = cost[(tile >> 16) * tilesXFull + (tile & 0xffffu)];
+		return c ? 31u - (uint32_t)__builtin_clz(c) : 0u;
+	};
+	auto parts = [&](uint32_t tile) { const uint32_t c = cost[(tile >> 16) * tilesXFull + (tile & 0xffffu)]; return c > split16 ? 16u : (c > split4 ? 4u : 1u); };
+	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t tile = list[base + i]; atomicAdd(&hist[klass(tile)], parts(tile)); }
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		uint32_t run = 0;
 		for (int k = 31; k >= 0; k--) { cursor[k] = run; run += hist[k]; }
+		out[q] = obase; out[8 + q] = run;
 	}
 	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-		const uint32_t tile = list[base + i];
-		out[base + atomicAdd(&cursor[klass(tile)], 1u)] = tile;
+		const uint32_t tile = list[base + i], np = parts(tile);
+		const uint32_t at = obase + atomicAdd(&cursor[klass(tile)], np);
+		if (np == 1) out[at] = tile;
+		else if (np == 4) for (uint32_t e = 0; e < 4; ++e) out[at + e] = tile | 0x8000u | e << 13;
+		else for (uint32_t e = 0; e < 16; ++e) out[at + e] = tile | 0x80008000u | (e & 3u) << 13 | (e >> 2) << 29;
 	}
 }
 
@@ -1517,6 +1568,26 @@ __global__ void __launch_bounds__(256) rtxProbeKernel(const Params P)
 // ------------------------------------------------------------------------------------------------
 // Sobel mask (scene.cpp:547-568)
 // ------------------------------------------------------------------------------------------------
+// The operator on one interior pixel; fetch(a, b) returns the pixel at (x - 1 + b, y - 1 + a).  One body for both
+// kernels that compute the mask, so the two cannot differ in a rounding.
+template <typename Fetch>
+__device__ __forceinline__ bool sobelFlag(Fetch fetch)
+{
+	V3 gx = mk(0, 0, 0), gy = mk(0, 0, 0);
+	const float op[3][3] = { { -1, 0, 1 }, { -2, 0, 2 }, { -1, 0, 1 } };
+#pragma unroll
+	for (int a = 0; a < 3; ++a)
+#pragma unroll
+		for (int b = 0; b < 3; ++b) {
+			const V3 p = fetch(a, b);
+			gx = gx + p * op[a][b];
+			gy = gy + p * op[b][a];
+		}
+	const float lx = length(gx), ly = length(gy);
+	const float val = __builtin_sqrtf(lx * lx + ly * ly);       // powf(.,2) == x*x (g++ folds it)
+	return val > 0.5f;
+}
+
 __global__ void __launch_bounds__(256) rtxSobelKernel(const float* __restrict__ fb, uint8_t* __restrict__ mask,
                                                       uint32_t W, uint32_t H, uint32_t rowBegin, uint32_t rowEnd,
                                                       uint32_t bandH, uint32_t nParts, uint32_t part)
@@ -1525,22 +1596,342 @@ __global__ void __launch_bounds__(256) rtxSobelKernel(const float* __restrict__ 
 	const uint32_t y = rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
 	bool flag = false;
 	const bool inImage = x < W && y < rowEnd && y < H && rowOwned(bandH, nParts, part, y);
-	if (inImage && x >= 1 && x + 1 < W && y >= 1 && y + 1 < H) {
-		V3 gx = mk(0, 0, 0), gy = mk(0, 0, 0);
-		const float op[3][3] = { { -1, 0, 1 }, { -2, 0, 2 }, { -1, 0, 1 } };
-#pragma unroll
-		for (int a = 0; a < 3; ++a)
-#pragma unroll
-			for (int b = 0; b < 3; ++b) {
-				const V3 p = load3(fb + ((size_t)(y - 1 + a) * W + (x - 1 + b)) * 3);
-				gx = gx + p * op[a][b];
-				gy = gy + p * op[b][a];
-			}
-		const float lx = length(gx), ly = length(gy);
-		const float val = __builtin_sqrtf(lx * lx + ly * ly);       // powf(.,2) == x*x (g++ folds it)
-		flag = val > 0.5f;
-	}
+	if (inImage && x >= 1 && x + 1 < W && y >= 1 && y + 1 < H)
+		flag = sobelFlag([&](int a, int b) { return load3(fb + ((size_t)(y - 1 + a) * W + (x - 1 + b)) * 3); });
 	if (inImage) mask[(size_t)y * W + x] = flag ? 1 : 0;       // borders are defined as 0 (reference: uninitialised)
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole frame in one launch: pass 1, Sobel mask and SSAA (scene.cpp:444-568) driven by per-tile dependencies.
+//
+// Three separate launches cost the frame its two tails: every launch lasts as long as its slowest wave, and the SSAA
+// launch consists of little else (its slow items are the silhouette and pole tiles that were slow in pass 1).  Here a
+// wave that finishes a pass-1 tile counts it in at the 3x3 tiles around it; whoever completes a tile's neighbourhood
+// computes that tile's Sobel flags, counts THAT in at the 3x3 around, and whoever completes the second count queues the
+// tile's SSAA items (16 flagged pixels x 4 sub-samples, or 4 x 4 for a tile that was very slow).  SSAA may overwrite a
+// pixel only when no Sobel will read its pass-1 value any more -- that is the second count.  Waves take SSAA items
+// before pass-1 tiles, and pass-1 tiles are ordered by the cost of their surroundings in the previous frame, so the
+// slow SSAA items start while most of pass 1 is still to be done.
+//
+// Coherence between XCDs (each has its own L2): everything one wave writes for another to read -- pass-1 pixels, tile
+// costs, flags, queue entries -- is stored with agent-scope atomic stores (write-through, sc1), read with agent-scope
+// atomic loads, and the writer waits for its stores to be acknowledged (s_waitcnt vmcnt(0)) before the atomic that
+// publishes them.  No cache-wide write-back or invalidate is involved.
+// The picture does not depend on any of the scheduling: every pixel is a pure function of the scene.
+// ------------------------------------------------------------------------------------------------
+#define RTX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#ifndef RTX_FRAME_CUT
+#define RTX_FRAME_CUT 0       // experiment: 1 no SSAA items, 2 no Sobel either, 3 no dependency counting (pass 1 only)
+#endif
+__device__ __forceinline__ void storesAcknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__shared__ float sobelStage[4][304];      // per wave: the 10 x 10 pixels around a tile
+
+// Sobel flags of tile (nx, ny); writes the tile's part of the mask.  All the listed tiles around it are complete.
+__device__ __forceinline__ uint64_t frameSobelTile(const Params& P, uint32_t nx, uint32_t ny, uint32_t lane)
+{
+	const uint32_t W = P.view.width, H = P.view.height;
+	float* stage = sobelStage[threadIdx.x >> 6];
+	for (uint32_t i = lane; i < 300; i += 64) {
+		const uint32_t r = i / 30, c3 = i - r * 30, c = c3 / 3, ch = c3 - c * 3;
+		// pixels outside the image are never used (only interior pixels get a flag): any valid address will do
+		int yy = (int)(ny * 8 + r) - 1, xx = (int)(nx * 8 + c) - 1;
+		yy = yy < 0 ? 0 : (yy > (int)H - 1 ? (int)H - 1 : yy);
+		xx = xx < 0 ? 0 : (xx > (int)W - 1 ? (int)W - 1 : xx);
+		stage[i] = __hip_atomic_load(P.fb + ((size_t)yy * W + xx) * 3 + ch, RTX_AGENT);
+	}
+	const uint32_t cx = lane & 7, cy = lane >> 3;
+	const uint32_t x = nx * 8 + cx, y = ny * 8 + cy;
+	bool flag = false;
+	const bool inImage = x < W && y < P.rowEnd && y < H && y >= P.rowBegin && rowOwned(P.bandH, P.nParts, P.part, y);
+	if (inImage && x >= 1 && x + 1 < W && y >= 1 && y + 1 < H)
+		flag = sobelFlag([&](int a, int b) { return load3(stage + (cy + a) * 30 + (cx + b) * 3); });
+	if (inImage) P.maskOut[(size_t)y * W + x] = flag ? 1 : 0;
+	return ballot(flag);
+}
+
+// Counts tile (tx, ty) in at the listed tiles of its 3x3 neighbourhood; lanes whose neighbour is thereby complete
+// return true and its index in nIdx.
+__device__ __forceinline__ bool frameCountIn(const Params& P, uint32_t* counters, uint32_t tx, uint32_t ty, uint32_t lane, uint32_t& nIdx)
+{
+	bool mine = false;
+	nIdx = 0;
+	if (lane < 9) {
+		const uint32_t nx = tx + lane % 3 - 1, ny = ty + lane / 3 - 1;      // (unsigned wrap: -1 is out of range)
+		if (nx < P.tilesXFull && ny < P.tilesYFull) {
+			nIdx = ny * P.tilesXFull + nx;
+			const uint32_t need = P.tileNeed[nIdx];
+			if (need) mine = atomicAdd(counters + nIdx, 1u) + 1 == need;
+		}
+	}
+	return mine;
+}
+
+// Control block (P.frameCtl, 32-bit words, every item on its own 64-byte line: one address takes about 30 M atomic
+// operations or coherent reads per second, whoever issues them):
+enum : uint32_t {
+	FC_QUEUE = 0,                 // + 16 q, q < 64: head, tail of SSAA item queue q
+	FC_COUNT = 16 * 64,           // + 16 k, k < 64: tiles with index % 64 == k whose SSAA items are queued
+	FC_GROUPS = 16 * 128,         // number of k whose count is complete
+	FC_ERROR = 16 * 129,
+	FC_VERY = 16 * 130,           // extra items handed to tiles that get 4-pixel items
+	FC_ALL = 16 * 131,            // + 16 r, r < 64: copies of "every tile has queued its items"
+	FC_WORDS = 16 * 195
+};
+#define RTX_FRAME_QUEUES 64u
+
+template <bool MESH>
+__global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rtxFrameKernel(const Params P)
+{
+	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t lane = __lane_id();
+	const uint32_t W = P.view.width, H = P.view.height;
+	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	const uint32_t xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
+	uint32_t* const ctl = (uint32_t*)P.frameCtl;
+	const uint32_t wave = gl >> 6;
+	uint32_t attempt = 0;                       // pass-1 queues found empty so far (see rtxPass1Kernel)
+	uint32_t rot = wave * 5u;                   // where this wave's next SSAA item goes
+#if RTX_DBG
+	uint32_t dbgItems = 0;
+#endif
+	const unsigned long long started = wall_clock64();
+	// a wave never waits for another one except on a queue entry that is being written; the watchdog (10 s) only turns a
+	// bug into an error code instead of a hung device
+	auto expired = [&]() { return wall_clock64() - started > 1000000000ull; };
+	// SSAA items travel through 64 queues.  A working wave looks at ONE of them (wave % 64) between two work items; the
+	// wave that queues items deals them round; an idle wave watches four.  So no address is read by more than 1/64 of the
+	// waves, and an item is seen by about a hundred waves as soon as one of them finishes what it is doing.
+	auto popFrom = [&](uint32_t q, uint32_t& item) -> int {       // 1: got an item, 0: queue empty, -1: gave up on an entry (error set)
+		uint32_t got = 0xffffffffu;
+		if (lane == 0) {
+			const unsigned long long v = __hip_atomic_load((const unsigned long long*)(ctl + FC_QUEUE + 16 * q), RTX_AGENT);
+			uint32_t head = (uint32_t)v;
+			const uint32_t tail = (uint32_t)(v >> 32);
+			for (int tries = 0; tries < 4 && head < tail; ++tries) {
+				const uint32_t old = atomicCAS(ctl + FC_QUEUE + 16 * q, head, head + 1);
+				if (old == head) { got = head; break; }
+				head = old;
+			}
+		}
+		got = __builtin_amdgcn_readfirstlane(got);
+		if (got == 0xffffffffu) return 0;
+		const unsigned long long* entry = P.ssaaQueue + (size_t)q * P.queueCap + got;
+		unsigned long long e;
+		bool late = false;
+		do {                              // the tail is advanced before the entry is written
+			e = __hip_atomic_load(entry, RTX_AGENT);
+			late = (uint32_t)(e >> 32) != P.epoch && expired();
+		} while ((uint32_t)(e >> 32) != P.epoch && !late);
+		if (late) { if (lane == 0) atomicExch(ctl + FC_ERROR, 1u); return -1; }
+		item = __builtin_amdgcn_readfirstlane((uint32_t)e);
+		return 1;
+	};
+	// the first non-empty queue among `n` starting at q0 (idle waves), or ~0
+	auto scan = [&](uint32_t q0, uint32_t n) -> uint32_t {
+		unsigned long long v = 0;
+		if (lane < n) v = __hip_atomic_load((const unsigned long long*)(ctl + FC_QUEUE + 16 * ((q0 + lane) & (RTX_FRAME_QUEUES - 1))), RTX_AGENT);
+		const uint64_t nonEmpty = ballot((uint32_t)v < (uint32_t)(v >> 32));
+		return nonEmpty ? (q0 + (uint32_t)__builtin_ctzll(nonEmpty)) & (RTX_FRAME_QUEUES - 1) : 0xffffffffu;
+	};
+	for (;;) {
+		uint32_t kind = 0, item = 0;
+		// 1. an SSAA item from this wave's queue
+		{
+			const int r = popFrom(wave & (RTX_FRAME_QUEUES - 1), item);
+			if (r < 0) break;
+			if (r > 0) kind = 2;
+		}
+		// 2. a pass-1 tile: the queue of this XCD, then the others
+		while (kind == 0 && attempt < 8) {
+			const uint32_t q = (xcd + attempt) & 7u;
+			const uint32_t qBase = sload1(P.tileList + q), qSize = sload1(P.tileList + 8 + q);
+			const uint32_t j = nextWork(P.workCounter + q * 16);
+			if (j < qSize) { item = sload1(P.tileList + qBase + j); kind = 1; }
+			else attempt = uni(attempt + 1);
+		}
+		// 3. no tiles left, nothing in this wave's queue.  Items may still come until every tile has queued its own (the
+		// FC_ALL words); then the frame is finished when the queues are empty.  A wave waits for items in its own queue;
+		// the first wave of every block also looks into four others (all of them at the end), so that nothing is left
+		// behind in a queue whose own waves are busy or gone.
+		if (kind == 0) {
+#if RTX_FRAME_CUT
+			break;
+#endif
+			const bool helper = (threadIdx.x >> 6) == 0;
+			const uint32_t all = __hip_atomic_load(ctl + FC_ALL + 16 * (wave & 63u), RTX_AGENT);
+			if (!helper && all) {
+				// nothing more will be queued: leave when this queue and the seven after it are empty (the rest is looked after
+				// by their own waves and by the helpers; everybody reading all 64 words at the end would take longer)
+				const uint32_t q = scan(wave & (RTX_FRAME_QUEUES - 1), 8);
+				if (q == 0xffffffffu) break;
+				const int r = popFrom(q, item);
+				if (r < 0) break;
+				if (r > 0) kind = 2;
+			}
+			if (helper) {
+				const uint32_t q = all ? scan(0, RTX_FRAME_QUEUES) : scan((blockIdx.x * 4u) & (RTX_FRAME_QUEUES - 1), 4);
+				if (q != 0xffffffffu) {
+					const int r = popFrom(q, item);
+					if (r < 0) break;
+					if (r > 0) kind = 2;
+				}
+				else if (all) break;
+			}
+			if (kind == 0) {
+				uint32_t stop = 0;
+				if (lane == 0) {
+					stop = __hip_atomic_load(ctl + FC_ERROR, RTX_AGENT) != 0;
+					if (!stop && expired()) { atomicExch(ctl + FC_ERROR, 2u); stop = 1; }
+				}
+				if (__builtin_amdgcn_readfirstlane(stop)) break;
+				for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127);      // about 14 us
+				continue;
+			}
+		}
+		// the 64 rays of the work item
+		uint32_t tx, ty, x, y;
+		bool valid;
+		float fx, fy;
+		bool slow;
+		if (kind == 1) {
+			tx = item & 0x1fffu; ty = (item >> 16) & 0x1fffu;
+			x = tx * 8 + (lane & 7); y = ty * 8 + (lane >> 3);
+			uint32_t lanes = 64;
+			if (item & 0x80000000u) {               // one of sixteen parts of a very slow tile (rtxTileOrderKernel): 2 x 2 pixels
+				const uint32_t e = ((item >> 13) & 3u) | ((item >> 29) & 3u) << 2;
+				x = tx * 8 + (e & 3u) * 2 + (lane & 1); y = ty * 8 + (e >> 2) * 2 + ((lane >> 1) & 1);
+				lanes = 4;
+			}
+			else if (item & 0x8000u) {              // a quarter of a slow tile: 4 x 4 pixels
+				const uint32_t e = (item >> 13) & 3u;
+				x = tx * 8 + (e & 1u) * 4 + (lane & 3); y = ty * 8 + (e >> 1) * 4 + ((lane >> 2) & 3);
+				lanes = 16;
+			}
+			// x1/y1 are clamped to W-1/H-1: the last column and row are never rendered (scene.cpp:369-372)
+			valid = x < W - 1 && y < H - 1 && y >= P.rowBegin && y < P.rowEnd && rowRendered(P, y) && lane < lanes;
+			fx = (float)x + 0.5f; fy = (float)y + 0.5f;
+			slow = sload1(P.tileCost + ty * P.tilesXFull + tx) > RTX_PRIO_TICKS;
+		}
+		else {
+			const uint32_t m = item >> 8, k = (item >> 2) & 63u, per = 16u >> (2 * (item & 3u));      // 16, 4 or 1 pixels
+			const unsigned long long flags = __hip_atomic_load(P.tileFlags + m, RTX_AGENT);
+			ty = m / P.tilesXFull; tx = m - ty * P.tilesXFull;
+			const uint32_t n = k * per + (lane >> 2), sub = lane & 3;
+			valid = (lane >> 2) < per && n < (uint32_t)__popcll(flags);
+			const uint32_t pos = nthSetBit(flags, valid ? n : 0u);
+			x = tx * 8 + (pos & 7); y = ty * 8 + (pos >> 3);
+			// offsets in the reference's order: (.25,.25) (.25,.75) (.75,.25) (.75,.75)  (scene.cpp:527-534)
+			fx = (float)x + ((sub & 2) ? 0.75f : 0.25f); fy = (float)y + ((sub & 1) ? 0.75f : 0.25f);
+			slow = __hip_atomic_load(P.tileCost + m, RTX_AGENT) > P.heavyTicks;
+		}
+		V3 o, d;
+		primaryRay(P, fx, fy, o, d);
+#if RTX_PRIO
+		if (slow) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
+		const unsigned long long t0 = wall_clock64();
+		const V3 c = castRayWave<false, MESH>(P, valid, o, d, gl, cnt);
+		const unsigned long long dt = wall_clock64() - t0;
+#if RTX_DBG
+		if (lane == 0 && wave < 8192 && dbgItems < 160) {
+			const size_t e = (size_t)wave * 160 + dbgItems;
+			gDbgTimeline[3 * e] = t0; gDbgTimeline[3 * e + 1] = dt; gDbgTimeline[3 * e + 2] = (unsigned long long)kind << 32 | item;
+		}
+		dbgItems++;
+#endif
+		if (kind == 2) {
+			// color = 0; color += c0; += c1; += c2; += c3; fb = color / 4
+			const int base = (int)(lane & ~3u);
+			V3 sum = mk(0, 0, 0);
+			for (int k = 0; k < 4; ++k)
+				sum = sum + mk(__shfl(c.x, base + k), __shfl(c.y, base + k), __shfl(c.z, base + k));
+			if (valid && (lane & 3) == 0) {
+				float* px = P.fb + ((size_t)y * W + x) * 3;
+				__hip_atomic_store(px, sum.x / 4, RTX_AGENT); __hip_atomic_store(px + 1, sum.y / 4, RTX_AGENT); __hip_atomic_store(px + 2, sum.z / 4, RTX_AGENT);
+			}
+			continue;
+		}
+		if (valid) {
+			float* px = P.fb + ((size_t)y * W + x) * 3;
+			__hip_atomic_store(px, c.x, RTX_AGENT); __hip_atomic_store(px + 1, c.y, RTX_AGENT); __hip_atomic_store(px + 2, c.z, RTX_AGENT);
+		}
+		__builtin_amdgcn_s_setprio(0);
+		uint32_t cost = dt > 0x3fffffffull ? 0x3fffffffu : (uint32_t)dt;
+		if (item & 0x8000u) {
+			// the wave that finishes the last part speaks for the tile; its cost is the sum of the parts' 
+			storesAcknowledged();
+			uint32_t last = 0;
+			if (lane == 0) {
+				const uint32_t t = ty * P.tilesXFull + tx;
+				cost += atomicAdd(P.tileSobel + P.tilesXFull * P.tilesYFull + t, cost);      // (third array of the counters: cost so far)
+				last = atomicAdd(P.tileSobel + 2 * P.tilesXFull * P.tilesYFull + t, 1u) == ((item & 0x80000000u) ? 15u : 3u);
+				if (last) cost = __hip_atomic_load(P.tileSobel + P.tilesXFull * P.tilesYFull + t, RTX_AGENT);
+			}
+			if (!__builtin_amdgcn_readfirstlane(last)) continue;
+		}
+		if (lane == 0) __hip_atomic_store(P.tileCost + ty * P.tilesXFull + tx, cost, RTX_AGENT);
+		storesAcknowledged();
+#if RTX_FRAME_CUT >= 3
+		continue;
+#endif
+		// count the tile in; Sobel for the tiles whose surroundings are now complete
+		uint32_t nIdx;
+		uint64_t todo = ballot(frameCountIn(P, P.tileReady, tx, ty, lane, nIdx));
+		while (todo) {
+			const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+			todo &= todo - 1;
+			const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)nIdx, (int)l);
+			const uint32_t ny = n / P.tilesXFull, nx = n - ny * P.tilesXFull;
+#if RTX_FRAME_CUT >= 2
+			continue;
+#endif
+			const uint64_t flags = frameSobelTile(P, nx, ny, lane);
+			if (lane == 0) __hip_atomic_store(P.tileFlags + n, (unsigned long long)flags, RTX_AGENT);
+			storesAcknowledged();
+			// second count; the tiles it completes may now be overwritten by SSAA: queue their items
+			uint32_t mIdx;
+			uint64_t todo2 = ballot(frameCountIn(P, P.tileSobel, nx, ny, lane, mIdx));
+			while (todo2) {
+				const uint32_t l2 = (uint32_t)__builtin_ctzll(todo2);
+				todo2 &= todo2 - 1;
+				const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mIdx, (int)l2);
+				const uint32_t nf = (uint32_t)__popcll(__hip_atomic_load(P.tileFlags + m, RTX_AGENT));
+				uint32_t mode = 0, items = (nf + 15u) >> 4;
+#if RTX_FRAME_CUT >= 1
+				items = 0;
+#endif
+				// A tile that was slow in pass 1 (a silhouette, a pole) gets 4-pixel or 1-pixel items: what matters is when its
+				// last ray returns.  Limits: as for splitting the tile in pass 1, and 4 x heavyTicks whatever the frame.
+				if (items) {
+					const uint32_t c = __hip_atomic_load(P.tileCost + m, RTX_AGENT);
+					const uint32_t want = c > sload1(P.splitLimits + 1) ? 2u : (c > sload1(P.splitLimits) || c > RTX_SSAA_VERY * P.heavyTicks ? 1u : 0u);
+					if (want) {
+						const uint32_t spread = want == 2 ? nf : (nf + 3u) >> 2;
+						uint32_t ok = 0;
+						if (lane == 0) ok = atomicAdd(ctl + FC_VERY, spread - items) + (spread - items) <= P.veryBudget;
+						if (__builtin_amdgcn_readfirstlane(ok)) { mode = want; items = spread; }
+					}
+				}
+				if (items) {
+					if (lane < items) {
+						const uint32_t q = (rot + lane) & (RTX_FRAME_QUEUES - 1);
+						const uint32_t slot = atomicAdd(ctl + FC_QUEUE + 16 * q + 1, 1u);
+						if (slot >= P.queueCap) atomicExch(ctl + FC_ERROR, 3u);
+						else __hip_atomic_store(P.ssaaQueue + (size_t)q * P.queueCap + slot, (unsigned long long)P.epoch << 32 | (m << 8 | lane << 2 | mode), RTX_AGENT);
+					}
+					rot = uni(rot + items);
+					storesAcknowledged();
+				}
+				// the tile is accounted for; the last one tells the idle waves that nothing more will be queued
+				if (lane == 0) {
+					const uint32_t k = m & 63u;
+					if (atomicAdd(ctl + FC_COUNT + 16 * k, 1u) + 1 == P.countExpect[k] && atomicAdd(ctl + FC_GROUPS, 1u) + 1 == P.countGroups)
+						for (uint32_t r = 0; r < 64; ++r) __hip_atomic_store(ctl + FC_ALL + 16 * r, 1u, RTX_AGENT);
+				}
+			}
+		}
+	}
 }
 
 // saveImage's quantiser (util.cpp:46-58)
@@ -1589,3 +1980,5 @@ template __global__ void rtxSsaaKernel<false>(const Params);
 template __global__ void rtxSsaaKernel<true>(const Params);
 template __global__ void rtxPass1Kernel<false, false>(const Params);
 template __global__ void rtxSsaaKernel<false, false>(const Params);
+template __global__ void rtxFrameKernel<true>(const Params);
+template __global__ void rtxFrameKernel<false>(const Params);

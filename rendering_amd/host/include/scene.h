@@ -78,7 +78,7 @@ public:
 	// Multi-GPU (one process per GPU): with a communicator of the C ABI attached (rtx_comm_create), render() renders this
 	// rank's rows only and collects the image on rank 0 (rtx_gather), which writes the file.
 	void attachComm(rtx_comm* comm, int nRanks, int rank);
-	double lastPass1Ms = 0, lastSobelMs = 0, lastSsaaMs = 0;
+	double lastPass1Ms = 0, lastSobelMs = 0, lastSsaaMs = 0, lastFrameMs = 0;      // (lastFrameMs: the whole of render(), rtx_render_frame)
 	// The switches the render reads are process-global in the reference (options::useBackfaceCulling, useSkybox,
 	// collectStatistics).  A host that keeps several scenes alive (the C API in capi.cpp) pins them per scene here:
 	// -1 = follow the global (the reference's behaviour), 0 / 1 = this scene's own value.

@@ -577,6 +577,7 @@ void Scene::readTimes()
 	if (rtx_last_kernel_ms(gpu_, 0, &ms) == RTX_OK) lastPass1Ms = ms;
 	if (rtx_last_kernel_ms(gpu_, 1, &ms) == RTX_OK) lastSobelMs = ms;
 	if (rtx_last_kernel_ms(gpu_, 2, &ms) == RTX_OK) lastSsaaMs = ms;
+	if (rtx_last_kernel_ms(gpu_, 3, &ms) == RTX_OK) lastFrameMs = ms;
 }
 
 // The reference's entry points keep their meaning for a caller that owns a host framebuffer (scene.h:68-100): the
@@ -626,15 +627,25 @@ void Scene::render()
 	const bool sharded = comm_ && nRanks_ > 1;
 	gpuCheck(rtx_set_row_ownership(g, sharded ? 64u : 0u, (uint32_t)nRanks_, (uint32_t)rank_, 1), "rtx_set_row_ownership");
 	hipCheck(hipMemset(d.fb, 0, options.width * options.height * sizeof(Vec3f)), "hipMemset");    // new Vec3f[H*W]() (scene.cpp:599)
-	{
-		Timer tp("Render scene");
-		pass1OnDevice();
-		hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+	if (options::enableSSAA && !statisticsOn()) {
+		// launchWorkers + launchSSAA as one call: the stages overlap on the device (rtx_render_frame)
+		Timer tp("Render scene + MSAA");
+		gpuCheck(rtx_counters_enable(g, 0), "rtx_counters_enable");
+		gpuCheck(rtx_render_frame(g, 0, (uint32_t)options.height, d.fb, d.mask, nullptr), "rtx_render_frame");
+		uint32_t status = 0;
+		gpuCheck(rtx_frame_status(g, &status), "rtx_frame_status");
 	}
-	if (options::enableSSAA) {
-		Timer ts("MSAA");
-		ssaaOnDevice();
-		hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+	else {
+		{
+			Timer tp("Render scene");
+			pass1OnDevice();
+			hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+		}
+		if (options::enableSSAA) {
+			Timer ts("MSAA");
+			ssaaOnDevice();
+			hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+		}
 	}
 	readTimes();
 	if (options::imageOutput || sharded) {

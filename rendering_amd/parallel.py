@@ -26,10 +26,10 @@ def shard_frame(scene, fb, mask, n_parts, part, band=BAND, ssaa=True, stream=Non
     """Renders this rank's rows of one frame into the device tensors fb (H,W,3 f32) / mask (H,W u8)."""
     fb.zero_()
     scene.set_row_ownership(band if n_parts > 1 else 0, n_parts, part, halo=True)
-    scene.render_pass1(fb, stream=stream)
     if ssaa:
-        scene.sobel(fb, mask, stream=stream)
-        scene.render_ssaa(mask, fb, stream=stream)
+        scene.render_frame(fb, mask, stream=stream)      # pass 1 + Sobel + SSAA (rtx_render_frame: one launch or three)
+    else:
+        scene.render_pass1(fb, stream=stream)
 
 
 def band_ranges(height, band, n_parts, part):
