@@ -962,6 +962,8 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 		static const char* names[10] = { "depth limit sky", "next light", "lights done: mirror", "lights done: transparent", "return: mirror", "return: transparent 1", "return: transparent 2", "consume: miss", "consume: shade", "consume: shadow" };
 		for (int k = 0; k < 10; k++) if (h[17 + 2 * k]) fprintf(stderr, "[rtx]   %-26s %8llu wave-level executions, %7.0f cycles each\n", names[k], h[17 + 2 * k], (double)h[16 + 2 * k] / (double)h[17 + 2 * k]);
 		{ unsigned long long z[32] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gDbgHist), z, sizeof(z), 16 * sizeof(unsigned long long))); }
+		if (h[32] + h[33] + h[34]) fprintf(stderr, "[rtx] walk cycles (waves whose walk ended early inside the reference passes are not counted for that batch): nodes %llu, reference passes without the exact tests %llu, exact tests %llu\n", h[32], h[33], h[34]);
+		{ unsigned long long z[3] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gDbgHist), z, sizeof(z), 32 * sizeof(unsigned long long))); }
 		if (h[15]) fprintf(stderr, "[rtx] work items %llu: slowest = %llu trace rounds, %llu cycles in Render::trace + %llu in the castRay state machine; "
 		                   "all items: %llu rounds, %.0f + %.0f cycles per round\n", h[15], h[9], h[10], h[11], h[12], (double)h[13] / (double)h[12], (double)h[14] / (double)h[12]);
 	}

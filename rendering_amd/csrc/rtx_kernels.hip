@@ -331,7 +331,7 @@ __device__ unsigned long long gDbgHist[64];   // [0,8) certificate outcomes (one
 #define RTX_T0
 #define RTX_ACC(k)
 #endif
-struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips, wChunks, wChunkSkips, triLanes, moot; };
+struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips, wChunks, wChunkSkips, triLanes, moot, cNodes, cFilter, cExact; };
 
 // Ordering of scalar loads.  SMEM returns out of order, so lgkmcnt can only be waited down to zero: a load issued
 // before the first use of the previous one is covered by the same wait and nothing overlaps.  after(x, v) is an
@@ -616,6 +616,9 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 		sp = 1;
 	}
 	for (;;) {
+#if RTX_DBG
+		const unsigned long long dbgP1 = __builtin_readcyclecounter();
+#endif
 		// ---- phase 1: nodes.  The reached leaves are noted in a small per-wave table in LDS.
 		uint32_t batch = 0, total = 0;      // total = references of the batch: its leaves form ONE stream, entry k starts at entries[k].start
 		if (WIDE) {
@@ -742,6 +745,11 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 		// classifies reference k of the pass against the bundle; the survivors are then tested exactly, in stream order,
 		// by the lanes that passed the box of the survivor's leaf.
 		const uint32_t lane = laneNow();
+#if RTX_DBG
+		const unsigned long long dbgP2 = __builtin_readcyclecounter();
+		cnt.cNodes += dbgP2 - dbgP1;
+		unsigned long long dbgExact = 0;
+#endif
 		uint32_t ecur = 0;                 // first entry that is not finished yet
 		// which reference, of which entry, a lane holds in the pass that starts at p0: later entries overwrite earlier ones
 		// from their start on
@@ -773,6 +781,9 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 			if (RTX_DBG) { cnt.wTri += __popcll(cand); if (cand == 0) cnt.wS2++; }
 			if (cand == 0) return false;
 			bool improved = false;
+#if RTX_DBG
+			const unsigned long long dbgE0 = __builtin_readcyclecounter();
+#endif
 			while (cand != 0) {
 				const int c = __builtin_ctzll(cand);
 				cand &= cand - 1;
@@ -789,6 +800,9 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				if (pass) triTestOne<CULL, STATS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, tri, o, d, bt, bu, bv, btri);
 				improved = improved || bt < before;
 			}
+#if RTX_DBG
+			dbgExact += __builtin_readcyclecounter() - dbgE0;
+#endif
 			if (ballot(improved) != 0) {
 				// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is true
 				// for this lane no later triangle or object can change the answer.
@@ -813,6 +827,9 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 			if (process(p0, vaA, vbA, vcA, entA)) return;
 			if (two && process(p0 + 64, vaB, vbB, vcB, entB)) return;
 		}
+#if RTX_DBG
+		cnt.cExact += dbgExact; cnt.cFilter += __builtin_readcyclecounter() - dbgP2 - dbgExact;
+#endif
 		if (WIDE ? sp == 0 : i >= nN) break;
 	}
 }
@@ -1260,6 +1277,9 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 		atomicAdd(P.counters + 10, c.wLeaves); atomicAdd(P.counters + 11, c.wLeafSkips);
 		atomicAdd(P.counters + 12, c.wChunks); atomicAdd(P.counters + 13, c.wChunkSkips); atomicAdd(P.counters + 14, c.triLanes);
 		atomicAdd(P.counters + 15, c.moot);
+#if RTX_DBG
+		atomicAdd(&gDbgHist[32], c.cNodes); atomicAdd(&gDbgHist[33], c.cFilter); atomicAdd(&gDbgHist[34], c.cExact);
+#endif
 	}
 }
 
@@ -1274,7 +1294,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	Counts cnt = {};
 	// XCD-affine work distribution.  Each XCD has its own 4 MB L2; if consecutive tiles went to different XCDs
 	// (one global queue) every L2 would have to hold the triangles of the whole sweep.  Instead the frame is cut
 	// into bands of 8 tile rows (64 pixel rows), band b belongs to queue b % 8, and a wave first drains the queue
@@ -1354,7 +1374,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	Counts cnt = {};
 	for (;;) {
 		// work item = 16 consecutive entries of the flagged-pixel list (rtxSsaaCountKernel / rtxSsaaScatterKernel):
 		// full waves even where a tile has only a few flagged pixels; the pixels of tiles that were expensive in pass 1
@@ -1543,7 +1563,7 @@ __global__ void __launch_bounds__(256) rtxProbeKernel(const Params P)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t nWork = (P.nProbe + 63) / 64;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	Counts cnt = {};
 	for (;;) {
 		const uint32_t work = nextWork(P.workCounter);
 		if (work >= nWork) break;
@@ -1686,7 +1706,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
-	Counts cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	Counts cnt = {};
 	const uint32_t xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
 	uint32_t* const ctl = (uint32_t*)P.frameCtl;
 	const uint32_t wave = gl >> 6;
