@@ -108,6 +108,7 @@ struct rtx_scene {
 	FrameProbe probes[8];
 	unsigned probeNext = 0;
 	int lastFrameMode = -1, frameModeForced = -1;
+	size_t lastFrameQueue = ~(size_t)0;      // the view of the last rtx_render_frame (index into tileQueues)
 	std::vector<TileQueues> tileQueues;   // a few entries: a frame may be rendered in several row ranges
 	uint64_t tileUse = 0;
 	// HIP-event pairs around every launch of {pass 1, sobel, ssaa} since the last rtx_kernel_time_reset
@@ -247,6 +248,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 	HIPCHK(hipGetDeviceProperties(&prop, device));
 
 	rtx_scene* s = new rtx_scene;
+	s->tileQueues.reserve(16);
 	gUploadedBytes = 0;
 	s->device = device;
 	s->numCUs = prop.multiProcessorCount;
@@ -482,16 +484,23 @@ void meshTileRect(const rtx_scene* s, uint32_t tilesX, uint32_t tilesYFull, uint
 }
 
 // The eight per-XCD queues of one pass-1 launch.  Only tiles with a row this launch renders are listed.
-int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t tilesX, uint32_t tileRow0, uint32_t tilesY, rtx_scene::TileQueues** out)
+// strips (the three-launch path): a tile row of which this launch renders a single pixel row -- the halo row of a band
+// that belongs to another device -- is listed as 64 x 1 pixel strips (0x10000000 | strip << 16 | y) instead of 8 x 8
+// tiles with one live row each: a wave's time goes into walking its bundle whatever the number of live lanes, and the
+// halo rows are a quarter of the tile rows of a 64-row band.
+int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t tilesX, uint32_t tileRow0, uint32_t tilesY, rtx_scene::TileQueues** out, bool strips = false)
 {
 	const Params& p = s->params;
-	std::vector<uint32_t> key = { rowBegin, lastRow, tilesX, p.bandH, p.nParts, p.part, p.halo, p.view.width, p.view.height };
+	if (p.view.height > 32768u || p.view.width > 262144u) strips = false;
+	std::vector<uint32_t> key = { rowBegin, lastRow, tilesX, p.bandH, p.nParts, p.part, p.halo, p.view.width, p.view.height, strips ? 1u : 0u };
 	for (int i = 0; i < 16; i++) { uint32_t w; memcpy(&w, &p.view.camM[i], 4); key.push_back(w); }
 	for (int i = 0; i < 3; i++) { uint32_t w; memcpy(&w, &p.view.camPos[i], 4); key.push_back(w); }
 	{ uint32_t w; memcpy(&w, &p.view.scale, 4); key.push_back(w); memcpy(&w, &p.view.aspect, 4); key.push_back(w); }
 	for (auto& q : s->tileQueues)
 		if (q.list && q.key == key) { q.lastUse = ++s->tileUse; *out = &q; return RTX_OK; }
-	// new entry (the least recently used one is recycled once there are 16)
+	// new entry (the least recently used one is recycled once there are 16; callers keep pointers to entries across calls
+	// that may add one: the vector never reallocates)
+	if (s->tileQueues.capacity() < 16) s->tileQueues.reserve(16);
 	if (s->tileQueues.size() < 16) s->tileQueues.emplace_back();
 	rtx_scene::TileQueues* e = &s->tileQueues[0];
 	for (auto& q : s->tileQueues) { if (!q.list) { e = &q; break; } if (q.lastUse < e->lastUse) e = &q; }
@@ -509,11 +518,28 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 	std::vector<uint32_t> q[8][2];
 	for (uint32_t t = 0; t < tilesY; t++) {
 		const uint32_t ty = tileRow0 + t;
-		bool any = false;
-		for (uint32_t y = std::max(ty * 8, rowBegin); y < std::min(ty * 8 + 8, lastRow) && !any; y++) any = rowRenderedH(y);
-		if (!any) continue;
-		const uint32_t xq = (t / 8) & 7u;
+		uint32_t live = 0, only = 0;
+		for (uint32_t y = std::max(ty * 8, rowBegin); y < std::min(ty * 8 + 8, lastRow); y++) if (rowRenderedH(y)) { live++; only = y; }
+		if (!live) continue;
+		// queue = XCD: bands of 8 tile rows are dealt round the eight queues.  When the rows are shared among devices it is
+		// the bands of THIS device that are dealt round (band p, p + nParts, ... of the frame would otherwise all land in
+		// queue p % 8 for 8 devices, and every wave of the chip would pop from one address); a halo row goes with the band
+		// it serves.
+		uint32_t xq = (t / 8) & 7u;
+		if (p.bandH) {
+			uint32_t b = only / p.bandH;
+			if (!rowOwnedH(only)) b = (only > 0 && rowOwnedH(only - 1)) ? (only - 1) / p.bandH : (only + 1) / p.bandH;
+			xq = ((b / p.nParts) * (p.bandH / 64 ? p.bandH / 64 : 1) + (only % p.bandH) / 64) & 7u;
+		}
 		const bool inY = ty >= rect[2] && ty < rect[3];
+		if (strips && live == 1) {
+			const uint32_t W1 = p.view.width - 1;      // (the last column is never rendered)
+			for (uint32_t sx = 0; sx * 64 < W1; sx++) {
+				const uint32_t tx0 = sx * 8, tx1 = std::min(tx0 + 8, tilesX);
+				q[xq][(inY && tx1 > rect[0] && tx0 < rect[1]) ? 0 : 1].push_back(0x10000000u | sx << 16 | only);
+			}
+			continue;
+		}
 		for (uint32_t tx = 0; tx < tilesX; tx++) q[xq][(inY && tx >= rect[0] && tx < rect[1]) ? 0 : 1].push_back(ty << 16 | tx);
 	}
 	std::vector<uint32_t> list(16);
@@ -531,7 +557,7 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 		e->cap = list.size();
 	}
 	HIPCHK(hipMemcpy(e->list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	{
+	if (!strips) {
 		// rtx_render_frame: how many listed tiles each tile has in its 3x3 neighbourhood (itself included; 0 = not listed)
 		const uint32_t txFull = p.tilesXFull, tyFull = (H + 7) / 8;
 		std::vector<uint8_t> listedAt((size_t)txFull * tyFull, 0), need((size_t)txFull * tyFull, 0);
@@ -594,11 +620,15 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	p.workCounter = s->work + 128;            // eight per-XCD queue heads, 64 bytes apart
 	if (p.view.width > 0x7fff8u || p.view.height > 0x7fff8u) return fail(RTX_ERR_ARG, "frame too large");
 	rtx_scene::TileQueues* tq = nullptr;
-	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY, &tq))) return rc;
+	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY, &tq, true))) return rc;
 	p.tileList = tq->list;
 	if (tq->costValid) {
 		// the previous launch rendered exactly these tiles from this view: start with the ones that were expensive
-		hipLaunchKernelGGL(rtxTileOrderKernel, dim3(8), dim3(1024), 0, st, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap);
+		uint32_t stripLimit = 100000u;
+		if (const char* e = getenv("RTX_STRIP_LIMIT")) stripLimit = (uint32_t)strtoul(e, nullptr, 10);      // experiment knob (100 MHz ticks)
+		// (a strip of a halo row that took more than 1 ms is listed as its tiles again: rtxTileOrderKernel)
+		hipLaunchKernelGGL(rtxTileOrderKernel, dim3(8), dim3(1024), 0, st, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
+		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit);
 		p.tileList = tq->list + tq->cap;
 	}
 	tq->costValid = true;
@@ -767,6 +797,7 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 		tq->framesSeen++;
 	}
 	s->lastFrameMode = mode;
+	s->lastFrameQueue = tq ? (size_t)(tq - s->tileQueues.data()) : ~(size_t)0;
 	return RTX_OK;
 }
 
@@ -781,8 +812,7 @@ int rtx_frame_mode(rtx_scene* s, int* mode, float* split_ms, float* fused_ms)
 {
 	if (!s || !mode) return fail(RTX_ERR_ARG, "scene/mode is NULL");
 	*mode = s->lastFrameMode;
-	const rtx_scene::TileQueues* best = nullptr;
-	for (const auto& q : s->tileQueues) if (q.list && (!best || q.lastUse > best->lastUse)) best = &q;
+	const rtx_scene::TileQueues* best = s->lastFrameQueue < s->tileQueues.size() && s->tileQueues[s->lastFrameQueue].list ? &s->tileQueues[s->lastFrameQueue] : nullptr;
 	if (split_ms) *split_ms = best ? best->frameMs[0] : -1.f;
 	if (fused_ms) *fused_ms = best ? best->frameMs[1] : -1.f;
 	return RTX_OK;
@@ -857,10 +887,10 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	const uint32_t scanN = 2 * p.nTiles + 1;
 	if (const char* e = getenv("RTX_SSAA_HEAVY_TICKS")) heavyTicks = (uint32_t)strtoul(e, nullptr, 10);       // test knobs
 	if (const char* e = getenv("RTX_SSAA_SPREAD_SLOTS")) spreadSlots = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), kSsaaSpreadSlots);
-	// tile-local waves (see rtxSsaaCountKernel) unless a test asks for the packed layout
-	// (measured: tile-local waves win at every size -- 4096^2 1.00 against 1.54 ms, 8192^2 1.29 against 1.75 -- so the
-	// packed layout is only what a test asks for)
-	uint32_t localBelow = 0xffffffffu;
+	// tile-local waves (see rtxSsaaCountKernel) below eight full rounds of waves' worth of flagged pixels -- measured:
+	// 250k scene 4096^2 (88 k flagged) 1.00 against 1.54 ms packed, 8192^2 (350 k) 1.29 against 1.75; the glass-and-
+	// mirror scene at 1080p (746 k flagged, no slow tiles) 0.82 against 0.68 packed
+	uint32_t localBelow = (uint32_t)s->blocksSsaa * 4u * 16u * 8u;      // (about 650 000 flagged pixels)
 	if (const char* e = getenv("RTX_SSAA_LOCAL_BELOW")) localBelow = (uint32_t)strtoul(e, nullptr, 10);   // test knob: 0 = always packed
 	uint32_t* mode = s->work + 8;             // [0] local mode, [1] flagged pixels, [2] extra slots handed to 4-pixel tiles
 	uint32_t launches = 0;

@@ -1316,8 +1316,11 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 #if RTX_DBG
 			if (P.pad3 != 0 && tile != P.pad3 - 1) continue;      // RTX_DBG_TILE=tx,ty: only this tile (counters of one work item)
 #endif
-			const uint32_t tx = tile & 0xffffu, ty = tile >> 16;
-			const uint32_t x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+			// a tile (ty << 16 | tx), or a 64 x 1 strip of a halo row (0x10000000 | strip << 16 | y: rtx_api.hip, buildTileList),
+			// which is accounted to the first of the eight tiles it runs through
+			const bool strip = (tile & 0x10000000u) != 0;
+			const uint32_t tx = strip ? ((tile >> 16) & 0xfffu) * 8 : tile & 0xffffu, ty = strip ? (tile & 0x7fffu) >> 3 : tile >> 16;
+			const uint32_t x = strip ? tx * 8 + lane : tx * 8 + (lane & 7), y = strip ? tile & 0x7fffu : ty * 8 + (lane >> 3);
 			// x1/y1 are clamped to W-1/H-1: the last column and row are never rendered (scene.cpp:369-372)
 			const bool valid = x < W - 1 && y < H - 1 && y >= P.rowBegin && y < P.rowEnd && rowRendered(P, y);
 			if (ballot(valid) == 0) continue;
@@ -1336,9 +1339,10 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 #endif
 			if (lane == 0) {
 				// remembered per tile: the SSAA pass starts with the tiles that were expensive here (longest job first)
-				P.tileCost[ty * P.tilesXFull + tx] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
+				if (!strip) P.tileCost[ty * P.tilesXFull + tx] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
 				if (STATS) { atomicMax(P.counters + 3, dt); atomicAdd(P.counters + 4, dt); }
 			}
+			if (strip && lane < 8 && tx + lane < P.tilesX) P.tileCost[ty * P.tilesXFull + tx + lane] = (uint32_t)((dt > 0xffffffffull ? 0xffffffffull : dt) / 8);
 			if (valid) {
 				float* px = P.fb + ((size_t)y * W + x) * 3;
 				px[0] = c.x; px[1] = c.y; px[2] = c.z;
@@ -1449,7 +1453,8 @@ __global__ void __launch_bounds__(256) rtxTileClassKernel(const uint32_t* __rest
 __global__ void __launch_bounds__(1024) rtxTileOrderKernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ cost,
                                                            uint32_t tilesXFull, uint32_t* __restrict__ out, const uint8_t* __restrict__ klassIn = nullptr,
                                                            const unsigned long long* __restrict__ costSum = nullptr, uint32_t nWaves = 1,
-                                                           uint32_t splitPercent = 0, uint32_t splitFloor = 0, uint32_t* __restrict__ thresholds = nullptr)
+                                                           uint32_t splitPercent = 0, uint32_t splitFloor = 0, uint32_t* __restrict__ thresholds = nullptr,
+                                                           uint32_t tilesX = 0, uint32_t stripLimit = 0xffffffffu)
 {
 	uint32_t split4 = 0xffffffffu, split16 = 0xffffffffu;
 	if (costSum && splitPercent) {
@@ -1461,16 +1466,32 @@ __global__ void __launch_bounds__(1024) rtxTileOrderKernel(const uint32_t* __res
 	__shared__ uint32_t hist[32], cursor[32];
 	const uint32_t q = blockIdx.x;
 	const uint32_t base = list[q], n = list[8 + q];
-	const uint32_t obase = costSum ? 16 + 16 * (base - 16) : base;
+	const uint32_t obase = 16 + 16 * (base - 16);
 	if (threadIdx.x < 32) hist[threadIdx.x] = 0;
 	if (thresholds && q == 0 && threadIdx.x == 0) { thresholds[0] = split4; thresholds[1] = split16; }
 	__syncthreads();
+	auto entry = [&](uint32_t tile) {      // (a strip: the first tile it runs through)
+		return (tile & 0x10000000u) ? ((tile & 0x7fffu) >> 3) * tilesXFull + ((tile >> 16) & 0xfffu) * 8 : (tile >> 16) * tilesXFull + (tile & 0xffffu);
+	};
 	auto klass = [&](uint32_t tile) {
-		if (klassIn) return (uint32_t)klassIn[(tile >> 16) * tilesXFull + (tile & 0xffffu)];
-		const uint32_t c = cost[(tile >> 16) * tilesXFull + (tile & 0xffffu)];
+		if (klassIn) return (uint32_t)klassIn[entry(tile)];
+		uint32_t c = cost[entry(tile)];
+		if (tile & 0x10000000u) c = c > 0x1fffffffu ? 0xffffffffu : c * 8;      // (a strip's time is spread over eight entries)
 		return c ? 31u - (uint32_t)__builtin_clz(c) : 0u;
 	};
-	auto parts = [&](uint32_t tile) { const uint32_t c = cost[(tile >> 16) * tilesXFull + (tile & 0xffffu)]; return c > split16 ? 16u : (c > split4 ? 4u : 1u); };
+	// A strip that was slow (it runs through dense geometry: its wide bundle is halved again and again, and ONE wave does
+	// all of it) goes back to being up to eight tiles for eight waves.  Its cost is spread over the entries of those tiles
+	// (rtxPass1Kernel), so the sum is the strip's time in either form.
+	auto parts = [&](uint32_t tile) {
+		if (tile & 0x10000000u) {
+			const uint32_t tx0 = ((tile >> 16) & 0xfffu) * 8, n = tilesX - tx0 < 8u ? tilesX - tx0 : 8u;
+			unsigned long long sum = 0;
+			for (uint32_t e = 0; e < n; ++e) sum += cost[entry(tile) + e];
+			return sum > stripLimit ? n : 1u;
+		}
+		const uint32_t c = cost[entry(tile)];
+		return c > split16 ? 16u : (c > split4 ? 4u : 1u);
+	};
 	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t tile = list[base + i]; atomicAdd(&hist[klass(tile)], parts(tile)); }
 	__syncthreads();
 	if (threadIdx.x == 0) {
@@ -1483,6 +1504,7 @@ __global__ void __launch_bounds__(1024) rtxTileOrderKernel(const uint32_t* __res
 		const uint32_t tile = list[base + i], np = parts(tile);
 		const uint32_t at = obase + atomicAdd(&cursor[klass(tile)], np);
 		if (np == 1) out[at] = tile;
+		else if (tile & 0x10000000u) for (uint32_t e = 0; e < np; ++e) out[at + e] = ((tile & 0x7fffu) >> 3) << 16 | (((tile >> 16) & 0xfffu) * 8 + e);
 		else if (np == 4) for (uint32_t e = 0; e < 4; ++e) out[at + e] = tile | 0x8000u | e << 13;
 		else for (uint32_t e = 0; e < 16; ++e) out[at + e] = tile | 0x80008000u | (e & 3u) << 13 | (e >> 2) << 29;
 	}

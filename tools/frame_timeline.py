@@ -7,12 +7,16 @@ import rendering_amd as RA
 scene = sys.argv[1] if len(sys.argv) > 1 else "scenes/cfg2_smooth_250k.scene"
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
+parts = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+part = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 path = os.environ.setdefault("RTX_DBG_TIMELINE", "/tmp/tl.bin")
 g = RA.Scene(scene, W, H)
 fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"); mask = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
-for it in range(3):
-    if it == 2:
-        os.environ["RTX_DBG_TIMELINE"] = path
+g.set_frame_mode(1)
+g.set_row_ownership(64 if parts > 1 else 0, parts, part, True)
+for it in range(4):
+    if it >= 2:
+        os.environ["RTX_DBG_TIMELINE"] = path      # (the dump of frame 2 empties the buffer; the one of frame 3 is read)
     else:
         os.environ.pop("RTX_DBG_TIMELINE", None)
     g.render_frame(fb, mask); g.frame_status()
