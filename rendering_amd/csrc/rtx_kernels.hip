@@ -44,6 +44,9 @@ using namespace rtxd;
 
 namespace {
 
+#ifndef RTX_RAY_MAJOR
+#define RTX_RAY_MAJOR 1       // exact tests one step per ray where the rays are fewer than the surviving triangles (kernels whose work items can be parts of tiles)
+#endif
 #define RTX_AS4 __attribute__((address_space(4)))
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -537,6 +540,31 @@ __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, floa
 	if (t < bt) { bt = t; bu = u; bv = v; btri = tri; }                             // objects.cpp:623: strict <, first wins
 }
 
+// The same test the other way round: the lane's OWN triangle against ONE ray whose origin / direction are wave-uniform.
+// Operation for operation the arithmetic of triTestOne (objects.cpp:59-95); t stays as passed in where the reference
+// returns without a hit.
+template <bool CULL>
+__device__ __forceinline__ void triTestLane(const RefA& ra, const RefB& rb, const RefC& rc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                            float& t, float& u, float& v)
+{
+	const float e1x = rb.e1x, e1y = rb.e1y, e1z = rb.e1z, e2x = rb.e2x, e2y = rc.e2y, e2z = rc.e2z;
+	const float px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
+	const float det = e1x * px + e1y * py + e1z * pz;
+	if ((CULL ? det : fabsf(det)) < RTX_EPS8) return;
+	const float tx = ox - ra.v0x, ty = oy - ra.v0y, tz = oz - ra.v0z;
+	const float nu = tx * px + ty * py + tz * pz;
+	if (CULL) { if (nu < -0x1p-20f || nu > det * (1.0f + 0x1p-20f)) return; }      // (exact-safe: see triTestOne)
+	const float inv = 1 / det;
+	const float uu = nu * inv;
+	if (uu < 0 || uu > 1) return;
+	const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+	const float vv = (dx * qx + dy * qy + dz * qz) * inv;
+	if (vv < 0 || uu + vv > 1) return;
+	const float tt = (e2x * qx + e2y * qy + e2z * qz) * inv;
+	if (tt < 0) return;
+	t = tt; u = uu; v = vv;
+}
+
 // AccelerationStructure::intersectAccelStruct (objects.cpp:587-631) for a whole wave: stackless pre-order walk of the
 // nodes (phase 1: scalar-fed box tests, reached leaves are noted), then the noted leaves are processed in the same
 // order (phase 2: bundle filter with the lanes acting as triangles, exact test of the survivors with the lanes acting as
@@ -583,7 +611,7 @@ __device__ __forceinline__ bool boxFailsRegular(float blox, float bhix, float bl
 	asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx), "v"(fy), "v"(fz));
 	return tn > tf;
 }
-template <bool STATS, bool CULL, bool REGULAR, bool WIDE = false>
+template <bool STATS, bool CULL, bool REGULAR, bool WIDE = false, bool FEWRAYS = false>
 __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
                                          float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
                                          float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
@@ -599,6 +627,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 	// lane (tightened whenever a lane finds a closer hit)
 	float tmaxB = unif(waveMax(consider ? tLimit : -__builtin_inff()));
 	uint32_t resume = consider ? 0u : kNever;
+	const uint32_t nRays4 = 4u * (uint32_t)__popcll(ballot(consider));      // (4 x the rays of this walk: see the exact tests)
 	uint32_t i = 0;
 	const uint32_t last = nN - 1;
 	u32x8 nd = sload8(nodes);
@@ -784,6 +813,40 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 #if RTX_DBG
 			const unsigned long long dbgE0 = __builtin_readcyclecounter();
 #endif
+#if RTX_RAY_MAJOR
+			// Few rays, many survivors (a part of a slow tile, an SSAA item of one pixel, at a pole where hundreds of sliver
+			// triangles pass every filter): one step per RAY instead of one per survivor -- the ray is broadcast, every
+			// surviving lane tests its own triangle against it, and the nearest hit is the wave minimum; among equal t the
+			// lowest lane = the first in the reference's order, as its strict "<" has it (objects.cpp:623).
+			if (FEWRAYS && !STATS && nRays4 <= (uint32_t)__popcll(cand) * 3u) {
+				const uint64_t raysOpen = ballot(resume != kNever);
+				const uint32_t mLo = entries[myEnt].maskLo, mHi = entries[myEnt].maskHi;      // the rays that reached this lane's leaf
+				const bool isCand = ((cand >> lane) & 1ull) != 0;
+				uint64_t rays = raysOpen;
+				while (rays != 0) {
+					const int r = __builtin_ctzll(rays);
+					rays &= rays - 1;
+#define RTX_RL(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), r))
+					const float rox = RTX_RL(o.x), roy = RTX_RL(o.y), roz = RTX_RL(o.z), rdx = RTX_RL(d.x), rdy = RTX_RL(d.y), rdz = RTX_RL(d.z);
+					const float rbt = RTX_RL(bt);
+#undef RTX_RL
+					const bool reached = ((((uint32_t)r & 32u) ? mHi : mLo) >> ((uint32_t)r & 31u)) & 1u;
+					float t = __builtin_inff(), u = 0, v = 0;
+					if (isCand && reached) triTestLane<CULL>(ra, rb, rc, rox, roy, roz, rdx, rdy, rdz, t, u, v);
+					const bool better = t < rbt;
+					const float tmin = -waveMax(better ? -t : -__builtin_inff());
+					const uint64_t at = ballot(better && t == tmin);
+					if (at != 0) {
+						const int w = __builtin_ctzll(at);
+						const float wt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), w)), wu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), w));
+						const float wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), w));
+						const uint32_t wtri = (uint32_t)__builtin_amdgcn_readlane((int)ra.tri, w);
+						if (lane == (uint32_t)r) { bt = wt; bu = wu; bv = wv; btri = wtri; improved = true; }
+					}
+				}
+				cand = 0;
+			}
+#endif
 			while (cand != 0) {
 				const int c = __builtin_ctzll(cand);
 				cand &= cand - 1;
@@ -836,7 +899,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 
 // MESH = false: the variant for scenes without triangle meshes (spheres and planes only).  Without the walk the castRay
 // state machine fits the register file, and a small frame lasts as long as its slowest wave's chain of dependent rays.
-template <bool STATS, bool MESH = true>
+template <bool STATS, bool MESH = true, bool FEWRAYS = false>
 __device__ __forceinline__ void traceWave(const Params& P, bool active, bool shadow, V3 o, V3 d, float tmax,
                                           Hit& h, Counts& cnt)
 {
@@ -902,10 +965,10 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 					B = makeBundle(cl, o, d);
 				}
 				float bt, bu, bv; uint32_t btri;
-				if (!STATS && cull && regular && wideOk) meshWalk<STATS, true, true, true>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
-				else if (cull && regular) meshWalk<STATS, true, true>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
-				else if (cull) meshWalk<STATS, true, false>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
-				else meshWalk<STATS, false, false>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				if (!STATS && cull && regular && wideOk) meshWalk<STATS, true, true, true, FEWRAYS>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				else if (cull && regular) meshWalk<STATS, true, true, false, FEWRAYS>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				else if (cull) meshWalk<STATS, true, false, false, FEWRAYS>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				else meshWalk<STATS, false, false, false, FEWRAYS>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				if (cl && bt < kFltMax && bt < h.t) { h.obj = (int)oi; h.t = bt; h.tri = btri; h.u = bu; h.v = bv; }   // scene.cpp:740-745
 				pending = pending && !cl;
 			}
@@ -1196,7 +1259,7 @@ __device__ __forceinline__ void primaryRay(const Params& P, float x, float y, V3
 	d = r;
 }
 
-template <bool STATS, bool MESH = true>
+template <bool STATS, bool MESH = true, bool FEWRAYS = false>
 __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 d, uint32_t gl, Counts& cnt)
 {
 	Lane s;
@@ -1222,7 +1285,7 @@ __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 
 		// the pending request of every lane: a shadow ray from the point being shaded, or the lane's current ray
 		const bool qshadow = s.state == ST_WAIT_SHADOW;
 		const V3 qo = qshadow ? s.P + s.N * P.view.bias : s.ro, qd = qshadow ? -s.L : s.rd;
-		traceWave<STATS, MESH>(P, s.state != ST_DONE && (STATS || !moot), qshadow, qo, qd, s.qtmax, h, cnt);
+		traceWave<STATS, MESH, FEWRAYS>(P, s.state != ST_DONE && (STATS || !moot), qshadow, qo, qd, s.qtmax, h, cnt);
 #if RTX_DBG
 		const unsigned long long dbgT1 = __builtin_readcyclecounter();
 #endif
@@ -1400,7 +1463,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 		V3 o, d;
 		primaryRay(P, fx, fy, o, d);
 		const unsigned long long t0 = STATS ? wall_clock64() : 0;
-		const V3 c = castRayWave<STATS, MESH>(P, valid, o, d, gl, cnt);
+		const V3 c = castRayWave<STATS, MESH, true>(P, valid, o, d, gl, cnt);      // (work items of 16, 4 or 1 pixels: see the exact tests of meshWalk)
 		if (STATS && lane == 0) { atomicMax(P.counters + 3, wall_clock64() - t0); atomicAdd(P.counters + 4, wall_clock64() - t0); }
 		// color = 0; color += c0; += c1; += c2; += c3; fb = color / 4
 		const int base = (int)(lane & ~3u);
@@ -1873,7 +1936,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 		if (slow) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 #endif
 		const unsigned long long t0 = wall_clock64();
-		const V3 c = castRayWave<false, MESH>(P, valid, o, d, gl, cnt);
+		const V3 c = castRayWave<false, MESH, true>(P, valid, o, d, gl, cnt);
 		const unsigned long long dt = wall_clock64() - t0;
 #if RTX_DBG
 		if (lane == 0 && wave < 8192 && dbgItems < 160) {
