@@ -134,16 +134,21 @@ def stamped(path):
     return d, None
 
 
-def pmc_roofline(avg_ms, scene_bytes, fb_bytes, kernel="rtxPass1Kernel<false>"):
-    """Hardware-counter side of the roofline of rtxPass1Kernel<false>: VALU wave-instructions and HBM-side bytes per
-    launch from profiles/r02_pass1_pmc.json (tools/pmc_pass1.sh: separate rocprofv3 --pmc passes of this command), over
-    the launch duration measured live in THIS run."""
+def pmc_roofline(avg_ms, scene_bytes, fb_bytes, kernel="rtxPass1Kernel<false, true>", workload="headline"):
+    """Hardware-counter side of the roofline of the dominant kernel (rtxPass1Kernel where the frame is three launches,
+    rtxFrameKernel where it is one): VALU wave-instructions and HBM-side bytes per launch from profiles/r02_pass1_pmc.json
+    (tools/pmc_pass1.sh: separate rocprofv3 --pmc passes of this command), over the launch duration measured live in THIS run."""
     d, why = stamped(PMC_JSON)
     if d is None:
         return {"counters": None, "note": why}
-    k = [v for n, v in d["kernels"].items() if kernel.replace("rtx", "") in n]
+    # counters belong to a workload: they are quoted for the BASELINE configuration they were collected on, and for the kernel
+    # this run actually spent its time in
+    w = d.get("workloads", {}).get(workload)
+    if w is None:
+        return {"counters": None, "note": "%s holds no counters of workload '%s'" % (os.path.basename(PMC_JSON), workload)}
+    k = [v for n, v in w["kernels"].items() if kernel.replace("rtx", "") in n]
     if not k:
-        return {"counters": None, "note": "no %s in %s" % (kernel, os.path.basename(PMC_JSON))}
+        return {"counters": None, "note": "no %s among the counters of workload '%s' (collected with the frame rendered in %s)" % (kernel, workload, w["frame"])}
     k = k[0]
     valu = k["SQ_INSTS_VALU"]
     # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced streaming reads (the leaf-reference
@@ -190,9 +195,12 @@ def main():
     ap.add_argument("--verify", action="store_true", help="N > 1: rank 0 also renders the whole frame alone and compares the gathered image with it")
     args = ap.parse_args()
     cscene, cw, ch = CONFIGS[args.config]
+    custom = bool(args.scene or args.width or args.height or args.no_ssaa)
     args.scene = args.scene or cscene
     args.width = args.width or cw
     args.height = args.height or ch
+    if custom and (args.scene, args.width, args.height) != (cscene, cw, ch) or args.no_ssaa:
+        args.config = "custom"
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -331,7 +339,7 @@ def main():
     frame_mode, split_ms, fused_ms = scene.frame_mode() if ssaa else (0, -1.0, -1.0)
     # the dominant kernel: pass 1, or the single kernel of the frame where that is what ran
     one_launch = ssaa and n4 > n1
-    dom_kernel = "rtxFrameKernel<true>" if one_launch else "rtxPass1Kernel<false>"
+    dom_kernel = "rtxFrameKernel<true>" if one_launch else "rtxPass1Kernel<false, true>"
     avg_ms = ms4 / max(n4, 1) if one_launch else ms1 / max(n1, 1)
     # cold frame: a freshly created scene in the warm process -- its first pass 1 has no tile costs of a previous launch to
     # order its queues by (the reference's use case is one frame per process)
@@ -355,7 +363,7 @@ def main():
             "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINSTR, "achieved": None, "frac": None, "traffic": None,
             "algorithmic_ref_semantics_bytes": int(alg_bytes), "box_tests": int(c1[1]), "tri_tests": int(c1[2])}
     if world == 1:
-        pm = pmc_roofline(avg_ms, scene.scene_bytes(), 12.0 * rendered_px, dom_kernel)
+        pm = pmc_roofline(avg_ms, scene.scene_bytes(), 12.0 * rendered_px, dom_kernel, args.config)
         if pm.get("valu_instructions"):
             roof["achieved"] = round(pm["valu_ginstr_s"], 1)
             roof["frac"] = round(min(pm["valu_ginstr_s"] / VALU_PEAK_GINSTR, 1.0), 4)

@@ -796,6 +796,7 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 		pr.mode = warm ? mode : -1; pr.queue = (size_t)(tq - s->tileQueues.data()); pr.generation = tq->generation; pr.pending = true;
 		tq->framesSeen++;
 	}
+	if (tq) tq->costValid = true;      // (either way the tile costs of this view are now known)
 	s->lastFrameMode = mode;
 	s->lastFrameQueue = tq ? (size_t)(tq - s->tileQueues.data()) : ~(size_t)0;
 	return RTX_OK;

@@ -27,7 +27,10 @@
 using namespace rtxd;
 
 #ifndef RTX_WAVES_SSAA
-#define RTX_WAVES_SSAA 5   // the SSAA launch lasts as long as its slowest wave: fewer, less spilled waves
+#define RTX_WAVES_SSAA 4   // the SSAA launch lasts as long as its slowest wave: fewer, barely spilled waves (128 VGPRs)
+#endif
+#ifndef RTX_WAVES_FRAME
+#define RTX_WAVES_FRAME 4  // rtxFrameKernel runs where the frame is bounded by its slowest work items: likewise
 #endif
 #ifndef RTX_SSAA_VERY
 #define RTX_SSAA_VERY 4u   // x 0.25 ms of pass-1 time: tiles above get 4-pixel SSAA waves
@@ -39,7 +42,8 @@ using namespace rtxd;
 #define RTX_WAVES_ANALYTIC 4   // scenes without meshes: the whole castRay state in registers (128 VGPRs)
 #endif
 #ifndef RTX_WAVES
-#define RTX_WAVES 6   // target waves per SIMD of the two ray kernels (register budget = 512 / RTX_WAVES VGPRs)
+#define RTX_WAVES 5   // target waves per SIMD of the pass-1 kernel (register budget = 512 / RTX_WAVES VGPRs): 6 (80 VGPRs, 240 B of
+                      // scratch per lane) is as fast at 4096^2 and 3-5 % slower on the other configurations
 #endif
 
 namespace {
@@ -1786,7 +1790,7 @@ enum : uint32_t {
 #define RTX_FRAME_QUEUES 64u
 
 template <bool MESH>
-__global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rtxFrameKernel(const Params P)
+__global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYTIC) rtxFrameKernel(const Params P)
 {
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();

@@ -10,7 +10,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from srchash import source_hash, ROOT
 
-KERNEL = "_Z14rtxPass1KernelILb0EEvN4rtxd6ParamsE"
+KERNELS = {"rtxPass1Kernel<false, true>": "_Z14rtxPass1KernelILb0ELb1EEvN4rtxd6ParamsE", "rtxFrameKernel<true>": "_Z14rtxFrameKernelILb1EEvN4rtxd6ParamsE",
+           "rtxSsaaKernel<false, true>": "_Z13rtxSsaaKernelILb0ELb1EEvN4rtxd6ParamsE"}
 
 
 def klass(op, line):
@@ -37,10 +38,7 @@ def klass(op, line):
     return "other"
 
 
-def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-    path = os.path.join(ROOT, "build", "rtx_api-hip-amdgcn-amd-amdhsa-gfx950.s")
-    lines = open(path).read().split("\n")
+def one(path, lines, name, KERNEL):
     start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
     total = {}
     loops = {}
@@ -60,21 +58,31 @@ def main():
         d = loops.setdefault("%s (depth %d)" % cur, {})
         d[k] = d.get(k, 0) + 1
     valu = sum(v for k, v in total.items() if k.startswith("valu_"))
-    res = {"source_hash": source_hash(), "kernel": "rtxPass1Kernel<false>", "what": "static instruction counts from " + os.path.basename(path),
-           "kernel_total": total, "valu_total": valu,
+    res = {"kernel": name, "kernel_total": total, "valu_total": valu,
            "valu_fraction_by_class": {k: round(v / valu, 4) for k, v in total.items() if k.startswith("valu_")},
-           "by_innermost_loop": {k: v for k, v in sorted(loops.items(), key=lambda kv: -sum(kv[1].values()))}}
-    txt = open(path).read()
+           "by_innermost_loop": {k: v for k, v in sorted(loops.items(), key=lambda kv: -sum(kv[1].values()))[:12]}}
+    txt = "\n".join(lines)
     i = txt.index(".name:           " + KERNEL)
     blk = txt[max(0, i - 1500):i + 1500]
     for key in ("sgpr_count", "vgpr_count", "sgpr_spill_count", "vgpr_spill_count", "private_segment_fixed_size"):
         m = re.search(r"\.%s:\s+(\d+)" % key, blk)
         if m:
             res[key] = int(m.group(1))
+    return res
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    path = os.path.join(ROOT, "build", "rtx_api-hip-amdgcn-amd-amdhsa-gfx950.s")
+    lines = open(path).read().split("\n")
+    per = {name: one(path, lines, name, sym) for name, sym in KERNELS.items()}
+    # top level = the pass-1 kernel (what bench.py quotes beside the headline roofline); "kernels" holds all three
+    res = {"source_hash": source_hash(), "what": "static instruction counts from " + os.path.basename(path)}
+    res.update(per["rtxPass1Kernel<false, true>"])
+    res["kernels"] = per
     json.dump(res, open(os.path.join(ROOT, "profiles", "%s_pass1_isa.json" % tag), "w"), indent=1)
-    print(json.dumps({k: res[k] for k in res if k != "by_innermost_loop"}, indent=1))
-    for k, v in list(res["by_innermost_loop"].items())[:8]:
-        print(k, v)
+    for name, r in per.items():
+        print(name, {k: r[k] for k in r if k not in ("by_innermost_loop", "kernel")})
 
 
 if __name__ == "__main__":

@@ -1,37 +1,48 @@
 #!/bin/bash
-# GPU box: regenerates profiles/<round>_pass1_pmc.json -- hardware counters of the pass-1 / SSAA kernels of the CURRENT
-# sources, stamped with the source hash (tools/srchash.py) so that bench.py only quotes them for the kernels they were
-# measured on.  Three rocprofv3 --pmc passes (counters only, no trace domains) of
-#     python bench.py --steps 2 --warmup 1 --no-cpu-baseline [args]
+# GPU box: regenerates profiles/<round>_pass1_pmc.json -- hardware counters of the ray kernels of the CURRENT sources,
+# stamped with the source hash (tools/srchash.py) so that bench.py only quotes them for the kernels they were measured on.
+# Two workloads: the headline (three launches: rtxPass1Kernel / rtxSsaaKernel) and cfg2 at 1920x1080 (one launch:
+# rtxFrameKernel); the way the frame is rendered is fixed (RTX_FRAME_MODE) to what rtx_render_frame settles on without a
+# profiler attached.  Per workload four rocprofv3 --pmc passes (counters only, no trace domains) of
+#     python bench.py --steps 2 --warmup 1 --no-cpu-baseline [--config cfg2]
 # FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots); the SQ counters fill one pass.
-# Usage: tools/pmc_pass1.sh <round tag, e.g. r02> [bench args]
-TAG=${1:-r02}; shift
+# Usage: tools/pmc_pass1.sh <round tag, e.g. r02>
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "tcc:TCC_HIT_sum TCC_MISS_sum"; do
-  name=${pass%%:*}; cnt=${pass#*:}
-  rocprofv3 --pmc $cnt --output-format csv -d $OUT/$name -o $name -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/$name.log 2>&1
+for wl in "headline:split" "cfg2:fused"; do
+  cfg=${wl%%:*}; mode=${wl#*:}
+  for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "tcc:TCC_HIT_sum TCC_MISS_sum"; do
+    name=${pass%%:*}; cnt=${pass#*:}
+    RTX_FRAME_MODE=$mode rocprofv3 --pmc $cnt --output-format csv -d $OUT/$cfg/$name -o $name -- python $R/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$cfg.$name.log 2>&1
+  done
 done
 cd $R
-python - "$OUT" "$TAG" "$@" <<'PY'
+python - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, os, sys, collections
 sys.path.insert(0, "tools")
 from srchash import source_hash
 out, tag = sys.argv[1], sys.argv[2]
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
-for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0].replace("void ", "")
-        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
-        disp[(k, row["Counter_Name"])].add(row["Dispatch_Id"])
-res = {"source_hash": source_hash(), "command": "rocprofv3 --pmc <counters> -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline " + " ".join(sys.argv[3:]),
-       "units": "per launch (average over the dispatches of the kernel); FETCH_SIZE / WRITE_SIZE in KB as reported; SQ_*_CYCLES in quad-cycles", "kernels": {}}
-for k in agg:
-    if "Pass1Kernel<false>" in k or "SsaaKernel<false>" in k or "Sobel" in k:
-        res["kernels"][k] = {c: v / max(len(disp[(k, c)]), 1) for c, v in agg[k].items()}
-        res["kernels"][k]["dispatches"] = max(len(disp[(k, c)]) for c in agg[k])
+res = {"source_hash": source_hash(),
+       "command": "RTX_FRAME_MODE=<split|fused> rocprofv3 --pmc <counters> -- python bench.py --config <headline|cfg2> --steps 2 --warmup 1 --no-cpu-baseline",
+       "units": "per launch (average over the dispatches of the kernel); FETCH_SIZE / WRITE_SIZE in KB as reported; SQ_*_CYCLES in quad-cycles",
+       "workloads": {}}
+for cfg, mode in (("headline", "three launches"), ("cfg2", "one launch")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
+    for f in glob.glob(out + "/" + cfg + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            disp[(k, row["Counter_Name"])].add(row["Dispatch_Id"])
+    ks = {}
+    for k in agg:
+        if "Pass1Kernel<false, true>" in k or "SsaaKernel<false, true>" in k or "FrameKernel<true>" in k or "Sobel" in k:
+            ks[k] = {c: v / max(len(disp[(k, c)]), 1) for c, v in agg[k].items()}
+            ks[k]["dispatches"] = max(len(disp[(k, c)]) for c in agg[k])
+    res["workloads"][cfg] = {"frame": mode, "kernels": ks}
+res["kernels"] = res["workloads"]["headline"]["kernels"]      # (the headline's, under the key earlier rounds used)
 json.dump(res, open("profiles/%s_pass1_pmc.json" % tag, "w"), indent=1)
 json.dump(res, open(out + "/%s_pass1_pmc.json" % tag, "w"), indent=1)     # gpurun merges gpurun_out/ back: copy this one to profiles/ and commit it
 print(json.dumps(res, indent=1))
