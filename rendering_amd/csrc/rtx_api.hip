@@ -95,7 +95,7 @@ struct rtx_scene {
 		std::vector<uint32_t> key;        // what the list was built for (view, row range, row ownership)
 		uint32_t* list = nullptr; size_t cap = 0;   // [0, cap): queues in geometric order, [cap, 2 cap): ordered by cost
 		uint8_t* need = nullptr; size_t needCap = 0; uint32_t listed = 0;
-		uint32_t* countExpect = nullptr; uint32_t countGroups = 0;          // listed tiles by index % 64 (the frame kernel's completion counters)   // rtx_render_frame: listed tiles in each tile's 3x3 neighbourhood
+		uint32_t* countExpect = nullptr; bool needValid = false;          // listed tiles by index % 64 (the frame kernel's completion counters)   // rtx_render_frame: listed tiles in each tile's 3x3 neighbourhood
 		bool costValid = false;           // tileCost holds the costs of a launch with this key
 		uint64_t lastUse = 0;
 		// rtx_render_frame: measured duration of the frame in either mode (0: three launches, 1: one launch), -1 = not yet
@@ -557,36 +557,8 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 		e->cap = list.size();
 	}
 	HIPCHK(hipMemcpy(e->list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	if (!strips) {
-		// rtx_render_frame: how many listed tiles each tile has in its 3x3 neighbourhood (itself included; 0 = not listed)
-		const uint32_t txFull = p.tilesXFull, tyFull = (H + 7) / 8;
-		std::vector<uint8_t> listedAt((size_t)txFull * tyFull, 0), need((size_t)txFull * tyFull, 0);
-		for (size_t i = 16; i < list.size(); i++) listedAt[(size_t)(list[i] >> 16) * txFull + (list[i] & 0xffffu)] = 1;
-		for (size_t i = 16; i < list.size(); i++) {
-			const uint32_t tx = list[i] & 0xffffu, ty = list[i] >> 16;
-			uint8_t n = 0;
-			for (int dy = -1; dy <= 1; dy++)
-				for (int dx = -1; dx <= 1; dx++) {
-					const int64_t nx = (int64_t)tx + dx, ny = (int64_t)ty + dy;
-					if (nx >= 0 && ny >= 0 && nx < txFull && ny < tyFull) n += listedAt[(size_t)ny * txFull + nx];
-				}
-			need[(size_t)ty * txFull + tx] = n;
-		}
-		if (need.size() > e->needCap) {
-			if (e->need) HIPCHK(hipFree(e->need));
-			e->need = nullptr; e->needCap = 0;
-			HIPCHK(hipMalloc((void**)&e->need, need.size()));
-			e->needCap = need.size();
-		}
-		HIPCHK(hipMemcpy(e->need, need.data(), need.size(), hipMemcpyHostToDevice));
-		e->listed = (uint32_t)(list.size() - 16);
-		uint32_t expect[64] = { 0 };
-		for (size_t i = 16; i < list.size(); i++) expect[((size_t)(list[i] >> 16) * txFull + (list[i] & 0xffffu)) & 63u]++;
-		e->countGroups = 0;
-		for (int k = 0; k < 64; k++) e->countGroups += expect[k] != 0;
-		if (!e->countExpect) HIPCHK(hipMalloc((void**)&e->countExpect, sizeof(expect)));
-		HIPCHK(hipMemcpy(e->countExpect, expect, sizeof(expect), hipMemcpyHostToDevice));
-	}
+	e->listed = (uint32_t)(list.size() - 16);
+	e->needValid = false;      // (computed on the device when the single launch first uses this list: renderFrameFused)
 	e->key = key;
 	e->lastUse = ++s->tileUse;
 	*out = e;
@@ -646,7 +618,7 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 }
 
 // The frame in one launch (rtxFrameKernel).
-static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, uint8_t* mask_dev, void* stream)
+static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, uint8_t* mask_dev, void* stream, bool costsKnown)
 {
 	const uint32_t W = s->params.view.width, H = s->params.view.height;
 	if (rowEnd > H) rowEnd = H;
@@ -695,19 +667,38 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 		s->queueCap = 64 * perQueue;
 	}
 	if (!s->frameCtl) HIPCHK(hipMalloc((void**)&s->frameCtl, kFrameCtlBytes));
+	if (!tq->needValid) {
+		// once per tile list, on the device: the listed tiles around every tile and the expected values of the completion counters
+		if (tiles > tq->needCap) {
+			HIPCHK(hipDeviceSynchronize());
+			if (tq->need) HIPCHK(hipFree(tq->need));
+			tq->need = nullptr; tq->needCap = 0;
+			HIPCHK(hipMalloc((void**)&tq->need, tiles));
+			tq->needCap = tiles;
+		}
+		if (!tq->countExpect) HIPCHK(hipMalloc((void**)&tq->countExpect, 66 * sizeof(uint32_t)));
+		HIPCHK(hipMemsetAsync(s->tileClass, 0, tiles, st));      // (scratch here: the marks; the classes are written later)
+		HIPCHK(hipMemsetAsync(tq->countExpect, 0, 66 * sizeof(uint32_t), st));
+		hipLaunchKernelGGL(rtxTileMarkKernel, dim3(64, 8), dim3(256), 0, st, (const uint32_t*)tq->list, p.tilesXFull, s->tileClass);
+		hipLaunchKernelGGL(rtxTileNeedKernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, (const uint8_t*)s->tileClass, p.tilesXFull, p.tilesYFull,
+		                   tq->need, tq->countExpect, tq->countExpect + 65);
+		HIPCHK(hipGetLastError());
+		tq->needValid = true;
+	}
 	if (++s->epoch == 0) s->epoch = 1;
 	p.tileReady = s->tileDeps; p.tileSobel = s->tileDeps + tiles;
 	p.tileNeed = tq->need; p.tileFlags = s->tileFlags;
 	p.ssaaQueue = s->ssaaQueue; p.frameCtl = s->frameCtl;
 	p.listedTiles = tq->listed; p.epoch = s->epoch; p.queueCap = (uint32_t)perQueue; p.veryBudget = kSsaaSpreadSlots / 16;
-	p.countExpect = tq->countExpect; p.countGroups = tq->countGroups;
+	p.countExpect = tq->countExpect;
 	p.heavyTicks = 25000u;
 	if (const char* e = getenv("RTX_SSAA_HEAVY_TICKS")) p.heavyTicks = (uint32_t)strtoul(e, nullptr, 10);       // test knobs
 	if (const char* e = getenv("RTX_SSAA_SPREAD_SLOTS")) p.veryBudget = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), kSsaaSpreadSlots) / 16;
 	p.tileList = tq->list;
 	p.splitLimits = s->work + 18;
-	if (!tq->costValid) HIPCHK(hipMemsetAsync(s->work + 18, 0xff, 2 * sizeof(uint32_t), st));      // no costs yet: nothing is split
-	if (tq->costValid) {
+	const bool ordered = tq->costValid || costsKnown;      // (the costs of this view may come from frames rendered in three launches)
+	if (!ordered) HIPCHK(hipMemsetAsync(s->work + 18, 0xff, 2 * sizeof(uint32_t), st));      // no costs yet: nothing is split
+	if (ordered) {
 		// the previous launch rendered exactly these tiles from this view: start with the ones that were expensive
 		HIPCHK(hipMemsetAsync(s->work + 16, 0, 2 * sizeof(uint32_t), st));
 		hipLaunchKernelGGL(rtxTileClassKernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, s->tileCost, p.tilesXFull, p.tilesYFull, s->tileClass, (unsigned long long*)(s->work + 16));
@@ -752,7 +743,8 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	rtx_scene::TileQueues* tq = nullptr;
 	if (lastRow > rowBegin) {
 		const uint32_t tilesX = (W - 1 + 7) / 8, tileRow0 = rowBegin / 8;
-		if ((rc = buildTileList(s, rowBegin, lastRow, tilesX, tileRow0, (lastRow + 7) / 8 - tileRow0, &tq))) return rc;
+		// (the list of the three-launch path: its entry also keeps what was measured for this view)
+		if ((rc = buildTileList(s, rowBegin, lastRow, tilesX, tileRow0, (lastRow + 7) / 8 - tileRow0, &tq, true))) return rc;
 	}
 	// finished frames: take their durations
 	for (auto& pr : s->probes) {
@@ -782,7 +774,7 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	pr.pending = false;
 	HIPCHK(hipEventRecord(pr.a, st));
 	if ((rc = stamp(s, 3, st))) return rc;
-	if (mode == 1) rc = renderFrameFused(s, rowBegin, rowEnd, fb_dev, mask_dev, stream);
+	if (mode == 1) rc = renderFrameFused(s, rowBegin, rowEnd, fb_dev, mask_dev, stream, warm);
 	else {
 		rc = rtx_render_pass1(s, rowBegin, rowEnd, fb_dev, stream);
 		if (!rc) rc = rtx_sobel(s, fb_dev, rowBegin, rowEnd, mask_dev, stream);

@@ -142,10 +142,10 @@ struct Params {
 	unsigned long long* tileFlags;  // [tile] Sobel-flagged pixels of the tile (bit r * 8 + c)
 	unsigned long long* ssaaQueue;  // 64 queues of queueCap SSAA items: epoch << 32 | tile << 8 | group << 2 | (0: 16, 1: 4, 2: 1 pixels per group)
 	unsigned long long* frameCtl;   // control block (rtx_kernels.hip, FC_*)
-	const uint32_t* countExpect;    // [k], k < 64: listed tiles with index % 64 == k
+	const uint32_t* countExpect;    // [k], k < 64: listed tiles with index % 64 == k; [64]: how many of those are not zero
 	const uint32_t* splitLimits;    // [0], [1]: pass-1 cost (ticks) above which a tile is rendered / re-sampled in 4, in 16 parts (rtxTileOrderKernel)
 	uint8_t* maskOut;               // Sobel mask written by the frame kernel
-	uint32_t listedTiles, epoch, queueCap, veryBudget, tilesYFull, heavyTicks, countGroups, padF;
+	uint32_t listedTiles, epoch, queueCap, veryBudget, tilesYFull, heavyTicks, padF0, padF1;
 };
 
 constexpr int kFrameFields = 14;

@@ -1486,6 +1486,46 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 // longest-job-first keeps the end of the launch free of long tiles).  One block per queue: histogram of the cost
 // classes (log2 of the ticks), offsets in descending class order, scatter.  The order inside a class is arbitrary --
 // the picture does not depend on the order tiles are rendered in.
+// rtx_render_frame, once per tile list: which tiles are listed (mark), then for every listed tile the number of listed
+// tiles in its 3x3 neighbourhood, itself included (need; 0 = not listed), the number of listed tiles by index % 64
+// (expect[k]) and how many of those are not zero (expect[64]; the last block to finish counts them).
+__global__ void __launch_bounds__(256) rtxTileMarkKernel(const uint32_t* __restrict__ list, uint32_t tilesXFull, uint8_t* __restrict__ mark)
+{
+	const uint32_t q = blockIdx.y, base = list[q], n = list[8 + q];
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t t = list[base + i];
+		mark[(t >> 16) * tilesXFull + (t & 0xffffu)] = 1;
+	}
+}
+
+__global__ void __launch_bounds__(256) rtxTileNeedKernel(const uint8_t* __restrict__ mark, uint32_t tilesXFull, uint32_t tilesYFull,
+                                                         uint8_t* __restrict__ need, uint32_t* __restrict__ expect, uint32_t* __restrict__ blocksDone)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < tilesXFull * tilesYFull) {
+		uint32_t n = 0;
+		if (mark[t]) {
+			const int ty = (int)(t / tilesXFull), tx = (int)(t - (uint32_t)ty * tilesXFull);
+			for (int dy = -1; dy <= 1; ++dy)
+				for (int dx = -1; dx <= 1; ++dx) {
+					const int x = tx + dx, y = ty + dy;
+					if (x >= 0 && y >= 0 && x < (int)tilesXFull && y < (int)tilesYFull) n += mark[(uint32_t)y * tilesXFull + (uint32_t)x];
+				}
+			atomicAdd(expect + (t & 63u), 1u);
+		}
+		need[t] = (uint8_t)n;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__threadfence();
+		if (atomicAdd(blocksDone, 1u) + 1 == gridDim.x) {
+			uint32_t groups = 0;
+			for (int k = 0; k < 64; ++k) groups += atomicAdd(expect + k, 0u) != 0;
+			expect[64] = groups;
+		}
+	}
+}
+
 // klass != null (rtx_render_frame): the class of a tile is the highest one within two tiles of it (rtxTileClassKernel) --
 // the SSAA items of a slow tile can only be queued once the 5 x 5 tiles around it have been rendered.
 __global__ void __launch_bounds__(256) rtxTileClassKernel(const uint32_t* __restrict__ cost, uint32_t tilesXFull, uint32_t tilesYFull,
@@ -2035,7 +2075,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 				// the tile is accounted for; the last one tells the idle waves that nothing more will be queued
 				if (lane == 0) {
 					const uint32_t k = m & 63u;
-					if (atomicAdd(ctl + FC_COUNT + 16 * k, 1u) + 1 == P.countExpect[k] && atomicAdd(ctl + FC_GROUPS, 1u) + 1 == P.countGroups)
+					if (atomicAdd(ctl + FC_COUNT + 16 * k, 1u) + 1 == P.countExpect[k] && atomicAdd(ctl + FC_GROUPS, 1u) + 1 == sload1(P.countExpect + 64))
 						for (uint32_t r = 0; r < 64; ++r) __hip_atomic_store(ctl + FC_ALL + 16 * r, 1u, RTX_AGENT);
 				}
 			}
