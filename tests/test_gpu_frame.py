@@ -149,3 +149,28 @@ def test_frame_1080p_against_oracle_bands(ra, oracle, torch_cuda):
     ref = o.ssaa(p1, band_mask)
     for y0, y1 in bands:
         assert np.array_equal(np.ascontiguousarray(ref[y0:y1], np.float32).view(np.uint32), np.ascontiguousarray(got[y0:y1], np.float32).view(np.uint32)), "rows %d..%d" % (y0, y1)
+
+
+def test_halo_strips_and_their_expansion(ra, torch_cuda, monkeypatch):
+    """Three-launch path of a sharded frame: halo rows rendered as 64x1 strips (cold frame), as strips ordered by cost
+    (warm frame), and -- with the limit forced to 0 -- expanded back into tiles: always the pixels of the unsharded frame."""
+    from rendering_amd import parallel
+    torch = torch_cuda
+    W, H = 200, 330
+    g = ra.Scene("scenes/cfg2_smooth_4k.scene", W, H)
+    g.set_frame_mode(SPLIT)
+    full, full_mask = stages(torch, g)
+    for limit in (None, "0"):
+        if limit is not None:
+            monkeypatch.setenv("RTX_STRIP_LIMIT", limit)
+        for parts in (2, 3):
+            acc = torch.zeros_like(full)
+            for part in range(parts):
+                for it in range(3):
+                    fb, mask = frame(torch, g, SPLIT, parts=parts, part=part)
+                rows = torch.as_tensor(parallel.owned_rows(H, 64, parts, part), device="cuda")
+                acc.index_copy_(0, rows, fb.index_select(0, rows))
+                assert torch.equal(mask.index_select(0, rows), full_mask.index_select(0, rows)), "mask, part %d of %d" % (part, parts)
+            assert same(torch, full, acc), "%d parts, strip limit %s" % (parts, limit)
+    g.set_row_ownership(0, 1, 0, False)
+    g.set_frame_mode(AUTO)
