@@ -1851,10 +1851,11 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 	// SSAA items travel through 64 queues.  A working wave looks at ONE of them (wave % 64) between two work items; the
 	// wave that queues items deals them round; an idle wave watches four.  So no address is read by more than 1/64 of the
 	// waves, and an item is seen by about a hundred waves as soon as one of them finishes what it is doing.
-	auto popFrom = [&](uint32_t q, uint32_t& item) -> int {       // 1: got an item, 0: queue empty, -1: gave up on an entry (error set)
+	// (known: the head / tail word of the queue as read a moment ago by lane 0, or ~0 = read it now)
+	auto popFrom = [&](uint32_t q, uint32_t& item, unsigned long long known = ~0ull) -> int {       // 1: got an item, 0: queue empty, -1: gave up on an entry (error set)
 		uint32_t got = 0xffffffffu;
 		if (lane == 0) {
-			const unsigned long long v = __hip_atomic_load((const unsigned long long*)(ctl + FC_QUEUE + 16 * q), RTX_AGENT);
+			const unsigned long long v = known != ~0ull ? known : __hip_atomic_load((const unsigned long long*)(ctl + FC_QUEUE + 16 * q), RTX_AGENT);
 			uint32_t head = (uint32_t)v;
 			const uint32_t tail = (uint32_t)(v >> 32);
 			for (int tries = 0; tries < 4 && head < tail; ++tries) {
@@ -1883,13 +1884,27 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 		const uint64_t nonEmpty = ballot((uint32_t)v < (uint32_t)(v >> 32));
 		return nonEmpty ? (q0 + (uint32_t)__builtin_ctzll(nonEmpty)) & (RTX_FRAME_QUEUES - 1) : 0xffffffffu;
 	};
+	// The look into this wave's item queue is a coherent read of its own; after a pass-1 tile it is issued BEFORE waiting
+	// for that tile's stores to be acknowledged, so that the two round trips are one.  (Taking the next tile at the same
+	// time was measured too: a wave then sits on a tile -- the slowest ones come first -- while it works through items.)
+	unsigned long long reqV = 0;             // lane 0: head / tail of the item queue
+	bool reqPending = false;
+	auto request = [&]() {
+		if (lane == 0) reqV = __hip_atomic_load((const unsigned long long*)(ctl + FC_QUEUE + 16 * (wave & (RTX_FRAME_QUEUES - 1))), RTX_AGENT);
+		reqPending = true;
+	};
 	for (;;) {
 		uint32_t kind = 0, item = 0;
+		if (!reqPending) request();
+		reqPending = false;
 		// 1. an SSAA item from this wave's queue
 		{
-			const int r = popFrom(wave & (RTX_FRAME_QUEUES - 1), item);
-			if (r < 0) break;
-			if (r > 0) kind = 2;
+			const uint32_t vlo = __builtin_amdgcn_readfirstlane((uint32_t)reqV), vhi = __builtin_amdgcn_readfirstlane((uint32_t)(reqV >> 32));
+			if (vlo < vhi) {
+				const int r = popFrom(wave & (RTX_FRAME_QUEUES - 1), item, (unsigned long long)vhi << 32 | vlo);
+				if (r < 0) break;
+				if (r > 0) kind = 2;
+			}
 		}
 		// 2. a pass-1 tile: the queue of this XCD, then the others
 		while (kind == 0 && attempt < 8) {
@@ -2006,6 +2021,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 			__hip_atomic_store(px, c.x, RTX_AGENT); __hip_atomic_store(px + 1, c.y, RTX_AGENT); __hip_atomic_store(px + 2, c.z, RTX_AGENT);
 		}
 		__builtin_amdgcn_s_setprio(0);
+		request();              // (its round trip overlaps the acknowledgement of the stores above)
 		uint32_t cost = dt > 0x3fffffffull ? 0x3fffffffu : (uint32_t)dt;
 		if (item & 0x8000u) {
 			// the wave that finishes the last part speaks for the tile; its cost is the sum of the parts' 
