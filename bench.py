@@ -117,7 +117,14 @@ def cpu_baseline_port(scene_path, width, height, gpu_scene, target_s=15.0):
             "sample": "pass 1 (Scene::launchWorkers) of the %dx%d frame, %s: %d rays in %.1f s" % (width, height, what, rays, ms * 1e-3)}
 
 
-VALU_PEAK_GINSTR = 1024 * 2.4 / 4      # 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles per SIMD, 2.4 GHz (profiles/r01_pmc_sq.txt: measured 4.16-4.4 cycles)
+# VALU issue peak.  On gfx950 a wave64 VALU instruction does not cost "4 cycles": fp32 add / mul / fma / moves / simple
+# integer operations on VGPR sources issue in ~2.4 cycles per SIMD, everything else (any SGPR source, min / max, compares,
+# selects, v_readlane, DPP, packed, fp64) in ~4.2, the transcendental unit in ~8.2 (tools/ubench/valu_rate.hip,
+# profiles/r02_valu_rate.txt).  The peak of a KERNEL is therefore 1024 SIMDs x 2.4 GHz / the mean issue cost of its
+# instructions; that mean is taken from the kernel's ISA (tools/isa_mix.py: static counts by class -- the dynamic mix is
+# not observable with the counters at hand), falling back to 4 cycles per instruction when no stamped ISA summary exists.
+SIMDS, CLOCK_GHZ = 1024, 2.4
+VALU_PEAK_GINSTR = SIMDS * CLOCK_GHZ / 4
 PMC_JSON = os.path.join(ROOT, "profiles", "r02_pass1_pmc.json")
 ISA_JSON = os.path.join(ROOT, "profiles", "r02_pass1_isa.json")
 
@@ -364,10 +371,18 @@ def main():
             "algorithmic_ref_semantics_bytes": int(alg_bytes), "box_tests": int(c1[1]), "tri_tests": int(c1[2])}
     if world == 1:
         pm = pmc_roofline(avg_ms, scene.scene_bytes(), 12.0 * rendered_px, dom_kernel, args.config)
+        isa, _ = stamped(ISA_JSON)
+        mean_cycles = (isa or {}).get("kernels", {}).get(dom_kernel, {}).get("valu_issue_cycles_static_mean")
+        if mean_cycles:
+            roof["peak"] = round(SIMDS * CLOCK_GHZ / mean_cycles, 1)
+            roof["peak_basis"] = "1024 SIMDs x 2.4 GHz / %.2f cycles per VALU instruction (static mix of %s by issue class: %s)" % (
+                mean_cycles, dom_kernel, isa["kernels"][dom_kernel]["valu_by_issue_cycles"])
+        else:
+            roof["peak_basis"] = "1024 SIMDs x 2.4 GHz / 4 cycles per VALU instruction (no ISA summary of these sources)"
         if pm.get("valu_instructions"):
             roof["achieved"] = round(pm["valu_ginstr_s"], 1)
-            roof["frac"] = round(min(pm["valu_ginstr_s"] / VALU_PEAK_GINSTR, 1.0), 4)
-            roof["frac_unclamped"] = round(pm["valu_ginstr_s"] / VALU_PEAK_GINSTR, 4)
+            roof["frac"] = round(min(pm["valu_ginstr_s"] / roof["peak"], 1.0), 4)
+            roof["frac_unclamped"] = round(pm["valu_ginstr_s"] / roof["peak"], 4)
             roof["traffic"] = pm["hbm"]["fetch_bytes"] + pm["hbm"]["write_bytes"]
         roof["counters"] = pm
     out = {

@@ -38,10 +38,32 @@ def klass(op, line):
     return "other"
 
 
+# Issue cost of a VALU instruction on gfx950 (tools/ubench/valu_rate.hip, profiles/r02_valu_rate.txt): fp32 add / sub /
+# mul / fma / fmac, moves and simple integer / logic operations whose sources are VGPRs or inline constants issue in ~2.4
+# cycles per wave64 instruction per SIMD; everything else -- any instruction with an SGPR (or VCC / literal) source, min / max /
+# max3 / med3, compares, selects, shifts, integer multiplies, v_readlane, DPP, packed and fp64 arithmetic -- in ~4.2; the
+# transcendental unit (rcp, rsq, sqrt, ...) in ~8.2.
+FAST = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_mac_f32", "v_mov_b32", "v_and_b32", "v_or_b32", "v_xor_b32",
+        "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_not_b32")
+TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
+
+
+def issue_cycles(op, t):
+    base = op.replace("_e32", "").replace("_e64", "").replace("_dpp", "").replace("_sdwa", "")
+    if base.startswith(TRANS):
+        return 8.2
+    operands = t[len(op):]
+    scalar_src = bool(re.search(r"(?<![a-z0-9_\[])(s\d+|s\[\d+:\d+\]|vcc|exec|m0|0x[0-9a-f]+)\b", operands.split(",", 1)[1] if "," in operands else ""))
+    if base in FAST and not scalar_src and "row_" not in t and "quad_perm" not in t:
+        return 2.4
+    return 4.2
+
+
 def one(path, lines, name, KERNEL):
     start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
     total = {}
     loops = {}
+    cyc = {}
     cur = ("top", 0)
     for ln in lines[start + 1:]:
         t = ln.strip()
@@ -57,8 +79,13 @@ def one(path, lines, name, KERNEL):
         total[k] = total.get(k, 0) + 1
         d = loops.setdefault("%s (depth %d)" % cur, {})
         d[k] = d.get(k, 0) + 1
+        if k.startswith("valu_"):
+            c = issue_cycles(op, t)
+            cyc[c] = cyc.get(c, 0) + 1
     valu = sum(v for k, v in total.items() if k.startswith("valu_"))
     res = {"kernel": name, "kernel_total": total, "valu_total": valu,
+           "valu_by_issue_cycles": {str(k): v for k, v in sorted(cyc.items())},
+           "valu_issue_cycles_static_mean": round(sum(k * v for k, v in cyc.items()) / max(valu, 1), 3),
            "valu_fraction_by_class": {k: round(v / valu, 4) for k, v in total.items() if k.startswith("valu_")},
            "by_innermost_loop": {k: v for k, v in sorted(loops.items(), key=lambda kv: -sum(kv[1].values()))[:12]}}
     txt = "\n".join(lines)
