@@ -51,6 +51,9 @@ namespace {
 #ifndef RTX_RAY_MAJOR
 #define RTX_RAY_MAJOR 1       // exact tests one step per ray where the rays are fewer than the surviving triangles (kernels whose work items can be parts of tiles)
 #endif
+#ifndef RTX_TRI_BPERMUTE
+#define RTX_TRI_BPERMUTE 1
+#endif
 #define RTX_AS4 __attribute__((address_space(4)))
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -830,7 +833,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				while (rays != 0) {
 					const int r = __builtin_ctzll(rays);
 					rays &= rays - 1;
-#define RTX_RL(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), r))
+#define RTX_RL(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), r))      // (through the crossbar: no measurable difference here)
 					const float rox = RTX_RL(o.x), roy = RTX_RL(o.y), roz = RTX_RL(o.z), rdx = RTX_RL(d.x), rdy = RTX_RL(d.y), rdz = RTX_RL(d.z);
 					const float rbt = RTX_RL(bt);
 #undef RTX_RL
@@ -854,7 +857,15 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 			while (cand != 0) {
 				const int c = __builtin_ctzll(cand);
 				cand &= cand - 1;
+				// The survivor's record for all lanes.  Through v_readlane it would arrive in SGPRs, and every instruction with an
+				// SGPR source issues in ~4.2 cycles instead of ~2.4 (tools/ubench/valu_rate.hip): ~40 such instructions per test.
+				// Through the LDS crossbar (ds_bpermute) it arrives in VGPRs without a VALU instruction: pass 1 at 4096^2
+				// 5.77 -> 5.58 ms, cfg2 at 1080p 2.29 -> 2.17 (RTX_TRI_BPERMUTE=0: the v_readlane form).
+#if RTX_TRI_BPERMUTE
+#define RTX_RL(x) __int_as_float(__builtin_amdgcn_ds_bpermute(c << 2, __float_as_int(x)))
+#else
 #define RTX_RL(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), c))
+#endif
 				const float v0x = RTX_RL(ra.v0x), v0y = RTX_RL(ra.v0y), v0z = RTX_RL(ra.v0z);
 				const float e1x = RTX_RL(rb.e1x), e1y = RTX_RL(rb.e1y), e1z = RTX_RL(rb.e1z);
 				const float e2x = RTX_RL(rb.e2x), e2y = RTX_RL(rc.e2y), e2z = RTX_RL(rc.e2z);
