@@ -753,7 +753,12 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 		float ms = 0;
 		if (hipEventElapsedTime(&ms, pr.a, pr.b) != hipSuccess) continue;
 		if (pr.queue < s->tileQueues.size() && s->tileQueues[pr.queue].generation == pr.generation && pr.mode >= 0)
-			{ s->tileQueues[pr.queue].frameMs[pr.mode] = ms; s->tileQueues[pr.queue].frameSamples[pr.mode]++; }
+		{
+			// (the best of the samples: the first frame of either way carries one-off work -- buffers, the first ordered list)
+			rtx_scene::TileQueues& q = s->tileQueues[pr.queue];
+			q.frameMs[pr.mode] = q.frameSamples[pr.mode] ? std::min(q.frameMs[pr.mode], ms) : ms;
+			q.frameSamples[pr.mode]++;
+		}
 	}
 	(void)hipGetLastError();
 	int mode;
@@ -763,8 +768,8 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	if (forced >= 0) mode = forced;
 	else if (!tq) mode = 0;
 	else if (!warm) mode = tq->listed <= 65536u ? 1 : 0;       // no costs yet (nothing can be split or ordered): by size
-	// not measured yet: one launch, again (its first frame of a view also sets up its buffers and has no tile split yet), three
-	else if (tq->frameSamples[0] < 1 || tq->frameSamples[1] < 2) mode = tq->framesSeen % 3u == 0 ? 0 : 1;
+	// not measured twice each yet: in turn
+	else if (tq->frameSamples[0] < 2 || tq->frameSamples[1] < 2) mode = (int)(tq->framesSeen & 1u);
 	else {
 		mode = tq->frameMs[1] <= tq->frameMs[0] ? 1 : 0;
 		if ((tq->framesSeen & 63u) == 63u) mode ^= 1;

@@ -657,6 +657,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 #endif
 		// ---- phase 1: nodes.  The reached leaves are noted in a small per-wave table in LDS.
 		uint32_t batch = 0, total = 0;      // total = references of the batch: its leaves form ONE stream, entry k starts at entries[k].start
+		uint32_t myReach = 0;               // bit k: this lane's ray reached leaf k of the batch (the lane's own column of the table's masks)
 		if (WIDE) {
 			const uint32_t lane = laneNow();
 			while (sp != 0 && batch < RTX_LEAF_BATCH) {
@@ -676,6 +677,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 							en.first = it.first; en.count = n; en.maskLo = (uint32_t)m; en.maskHi = (uint32_t)(m >> 32); en.start = total; en.pad[0] = en.pad[1] = en.pad[2] = 0;
 							entries[batch] = en;
 						}
+						myReach |= in ? 1u << batch : 0u;
 						batch = uni(batch + 1);
 						total = uni(total + n);
 					}
@@ -768,6 +770,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 							en.first = nd[7]; en.count = n; en.maskLo = (uint32_t)m; en.maskHi = (uint32_t)(m >> 32); en.start = total; en.pad[0] = en.pad[1] = en.pad[2] = 0;
 							entries[batch] = en;
 						}
+						myReach |= pass ? 1u << batch : 0u;
 						batch = uni(batch + 1);
 						total = uni(total + n);
 					}
@@ -873,7 +876,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				const uint32_t tri = (uint32_t)__builtin_amdgcn_readlane((int)ra.tri, c);
 				// the rays that reached the survivor's leaf
 				const uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)myEnt, c);
-				const bool pass = (((lane & 32u) ? entries[ent].maskHi : entries[ent].maskLo) >> (lane & 31u)) & 1u;
+				const bool pass = ((myReach >> ent) & 1u) != 0;      // (no dependent LDS read of the table's mask per survivor)
 				const float before = bt;
 				if (pass) triTestOne<CULL, STATS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, tri, o, d, bt, bu, bv, btri);
 				improved = improved || bt < before;
