@@ -873,9 +873,14 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				const float e1x = RTX_RL(rb.e1x), e1y = RTX_RL(rb.e1y), e1z = RTX_RL(rb.e1z);
 				const float e2x = RTX_RL(rb.e2x), e2y = RTX_RL(rc.e2y), e2z = RTX_RL(rc.e2z);
 #undef RTX_RL
-				const uint32_t tri = (uint32_t)__builtin_amdgcn_readlane((int)ra.tri, c);
+#if RTX_TRI_BPERMUTE
+				const uint32_t tri = (uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)ra.tri);
 				// the rays that reached the survivor's leaf
+				const uint32_t ent = (uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)myEnt);
+#else
+				const uint32_t tri = (uint32_t)__builtin_amdgcn_readlane((int)ra.tri, c);
 				const uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)myEnt, c);
+#endif
 				const bool pass = ((myReach >> ent) & 1u) != 0;      // (no dependent LDS read of the table's mask per survivor)
 				const float before = bt;
 				if (pass) triTestOne<CULL, STATS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, tri, o, d, bt, bu, bv, btri);
