@@ -287,6 +287,12 @@ __device__ __forceinline__ int toPixel(float v, int mx)               // scene.c
 	return val;
 }
 __device__ __forceinline__ V3 load3(const float* p) { return mk(p[0], p[1], p[2]); }
+// A pointer that was itself loaded from memory (mesh arrays, texture maps, skybox faces, light sample points) has no
+// known address space: the compiler reads through it with flat_load, which counts against the LDS / scalar counter as
+// well as the vector-memory one.  These all point to device memory.
+typedef const __attribute__((address_space(1))) float* GlobalFloats;
+__device__ __forceinline__ GlobalFloats inGlobal(const float* p) { return (GlobalFloats)(uintptr_t)p; }
+__device__ __forceinline__ V3 load3(GlobalFloats p) { return mk(p[0], p[1], p[2]); }
 
 // (takes the few fields it needs by value: a kernel-argument struct whose address escapes into a call is copied to scratch)
 __device__ __noinline__ V3 skyFetch(const float* const* sky, int W, int H, V3 dir)           // scene.cpp:394-441
@@ -306,7 +312,7 @@ __device__ __noinline__ V3 skyFetch(const float* const* sky, int W, int H, V3 di
 		if (dir.y < 0) { a = dir * (1 / -dir.y); face = 5; i = toPixel(a.z, H); j = toPixel(a.x, W); }
 		else { a = dir * (1 / dir.y); face = 4; i = toPixel(a.z, H); j = toPixel(a.x, W); }
 	}
-	return load3(sky[face] + ((size_t)i * W + j) * 3);
+	return load3(inGlobal(sky[face]) + ((size_t)i * W + j) * 3);
 }
 
 __device__ __forceinline__ V3 skyColor(const Params& P, V3 dir)           // scene.cpp:381-442
@@ -1068,8 +1074,8 @@ __device__ __forceinline__ void shadePrimary(const Params& P, Lane& s, const Hit
 	else {
 		// Mesh::getSurfaceData, objects.cpp:121-151
 		const Mesh* M = P.meshes + ob->mesh;
-		const float* uvp = M->uv + (size_t)h.tri * 6;
-		const float* np = M->nrm + (size_t)h.tri * 9;
+		const GlobalFloats uvp = inGlobal(M->uv) + (size_t)h.tri * 6;
+		const GlobalFloats np = inGlobal(M->nrm) + (size_t)h.tri * 9;
 		const float u = h.u, v = h.v;
 		const float w = 1 - u - v;
 		const float texx = uvp[2] * u + uvp[4] * v + uvp[0] * w;
@@ -1077,10 +1083,10 @@ __device__ __forceinline__ void shadePrimary(const Params& P, Lane& s, const Hit
 		V3 n = (load3(np + 3) * u + load3(np + 6) * v + load3(np) * (1 - u - v)) / 3;
 		n = normalized(n);
 		if (M->normal) {
-			const float* tbp = M->tb + (size_t)h.tri * 6;
+			const GlobalFloats tbp = inGlobal(M->tb) + (size_t)h.tri * 6;
 			const int x = texel((int)M->nW, texx), y = texel((int)M->nH, texy);
 			// normalise(texel as loaded): the reference's in-place re-normalisation race is resolved this way
-			const V3 tn = normalized(load3(M->normal + ((size_t)y * M->nW + x) * 3));
+			const V3 tn = normalized(load3(inGlobal(M->normal) + ((size_t)y * M->nW + x) * 3));
 			V3 r;
 			r.x = tn.x * tbp[0] + tn.y * tbp[3] + tn.z * n.x + 0.0f;
 			r.y = tn.x * tbp[1] + tn.y * tbp[4] + tn.z * n.y + 0.0f;
@@ -1089,9 +1095,9 @@ __device__ __forceinline__ void shadePrimary(const Params& P, Lane& s, const Hit
 		}
 		s.N = n;
 		if (M->diffuse)                                     // Mesh::getDiffuseColor, objects.cpp:153-163
-			s.objColor = load3(M->diffuse + ((size_t)texel((int)M->dH, texy) * M->dW + texel((int)M->dW, texx)) * 3);
+			s.objColor = load3(inGlobal(M->diffuse) + ((size_t)texel((int)M->dH, texy) * M->dW + texel((int)M->dW, texx)) * 3);
 		if (M->specular)                                    // Mesh::getSpecularValue, objects.cpp:165-175
-			s.specCoef = M->specular[(size_t)texel((int)M->sH, texy) * M->sW + texel((int)M->sW, texx)];
+			s.specCoef = inGlobal(M->specular)[(size_t)texel((int)M->sH, texy) * M->sW + texel((int)M->sW, texx)];
 	}
 	s.diff = mk(0, 0, 0); s.spec = mk(0, 0, 0);
 	s.li = 0; s.si = 0; s.dsum = 0; s.ssum = 0;
@@ -1146,7 +1152,7 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 					s.li++; s.si = 0;
 					continue;
 				}
-				V3 L = s.P - load3(l->points + (size_t)s.si * 3);
+				V3 L = s.P - load3(inGlobal(l->points) + (size_t)s.si * 3);
 				dist = length(L);
 				s.L = normalized(L);
 			}
