@@ -666,15 +666,18 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 		uint32_t myReach = 0;               // bit k: this lane's ray reached leaf k of the batch (the lane's own column of the table's masks)
 		if (WIDE) {
 			const uint32_t lane = laneNow();
+			// which rays an item concerns is wave-level bookkeeping (masks in SGPRs); only the box tests are per lane
+			const uint64_t openM = ballot(resume != kNever);      // (rays close in phase 2 only)
 			while (sp != 0 && batch < RTX_LEAF_BATCH) {
 				sp = uni(sp - 1);
 				const WideItem it = stack[sp];
 				const int32_t link = (int32_t)uni((uint32_t)it.link);
 				const uint32_t mlo = uni(it.maskLo), mhi = uni(it.maskHi);
-				const bool in = ((((lane & 32u) ? mhi : mlo) >> (lane & 31u)) & 1u) != 0 && resume != kNever;
+				const uint64_t inM = ((uint64_t)mhi << 32 | mlo) & openM;
 				if (link < 0) {
 					// a leaf, in the reference's order: note it with the rays that reached it and are still open
-					const uint64_t m = ballot(in);
+					const uint64_t m = inM;
+					const bool in = ((((lane & 32u) ? (uint32_t)(m >> 32) : (uint32_t)m) >> (lane & 31u)) & 1u) != 0;
 					const uint32_t n = (uint32_t)~link;
 					if (RTX_DBG) cnt.wLeaves++;
 					if (m != 0 && n != 0) {
@@ -689,7 +692,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 					}
 					continue;
 				}
-				if (ballot(in) == 0) continue;
+				if (inM == 0) continue;
 				if (RTX_DBG) cnt.wNodes++;
 				const WideNode* w = wideNodes + (uint32_t)(link - 1);
 				const u32x16 wa = sload16(w), wb = sload16((const char*)w + 64);
@@ -697,7 +700,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 #define RTX_SLOT(rec, base, k)                                                                                                     \
 				if ((int32_t)rec[base + 6] != 0) {                                                                                   \
 					const bool fail = boxFailsRegular(F(rec[base]), F(rec[base + 1]), F(rec[base + 2]), F(rec[base + 3]), F(rec[base + 4]), F(rec[base + 5]), o, ix, iy, iz); \
-					const uint64_t mk_ = ballot(in && !fail);                                                                       \
+					const uint64_t mk_ = ballot(!fail) & inM;                                                                       \
 					if (mk_ != 0) {                                                                                                 \
 						if (lane == 0) { WideItem ni; ni.link = (int32_t)rec[base + 6]; ni.first = rec[base + 7]; ni.maskLo = (uint32_t)mk_; ni.maskHi = (uint32_t)(mk_ >> 32); stack[sp] = ni; } \
 						sp = uni(sp + 1);                                                                                           \
