@@ -605,7 +605,8 @@ __device__ __forceinline__ void triTestLane(const RefA& ra, const RefB& rb, cons
 #define RTX_LEAF_BATCH 8
 #endif
 // one reached leaf: first reference, number of references, the lanes (rays) that passed its box, start in the batch's stream
-struct LeafEntry { uint32_t first, count, maskLo, maskHi, start, pad[3]; };
+struct LeafEntry { uint32_t start, count, first, pad0, maskLo, maskHi, pad1, pad2; };      // (what the assignment of a pass needs arrives with one 16-byte read)
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 __shared__ LeafEntry leafBatch[4][RTX_LEAF_BATCH];      // per wave of a 256-thread block; private to the wave (no barrier)
 // WIDE walk: pending subtrees / leaves of the wave, top of the stack = next in the reference's order.  link > 0: wide node
 // link - 1; link < 0: leaf with ~link references from `first`; mask = the rays that passed the item's own box.
@@ -683,7 +684,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 					if (m != 0 && n != 0) {
 						if (lane == 0) {
 							LeafEntry en;
-							en.first = it.first; en.count = n; en.maskLo = (uint32_t)m; en.maskHi = (uint32_t)(m >> 32); en.start = total; en.pad[0] = en.pad[1] = en.pad[2] = 0;
+							en.first = it.first; en.count = n; en.maskLo = (uint32_t)m; en.maskHi = (uint32_t)(m >> 32); en.start = total; en.pad0 = en.pad1 = en.pad2 = 0;
 							entries[batch] = en;
 						}
 						myReach |= in ? 1u << batch : 0u;
@@ -776,7 +777,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 					if (n != 0) {
 						if (laneNow() == 0) {
 							LeafEntry en;
-							en.first = nd[7]; en.count = n; en.maskLo = (uint32_t)m; en.maskHi = (uint32_t)(m >> 32); en.start = total; en.pad[0] = en.pad[1] = en.pad[2] = 0;
+							en.first = nd[7]; en.count = n; en.maskLo = (uint32_t)m; en.maskHi = (uint32_t)(m >> 32); en.start = total; en.pad0 = en.pad1 = en.pad2 = 0;
 							entries[batch] = en;
 						}
 						myReach |= pass ? 1u << batch : 0u;
@@ -804,9 +805,10 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 		auto assign = [&](uint32_t p0, uint32_t& r, uint32_t& myEnt) {
 			r = 0; myEnt = 0;
 			for (uint32_t e = ecur; e < batch; e = uni(e + 1)) {
-				const uint32_t st = uni(entries[e].start);
+				const u32x4v head = *(const u32x4v*)&entries[e];          // one LDS round trip per entry: start, count, first
+				const uint32_t st = uni(head.x);
 				if (st >= p0 + 64) break;
-				const uint32_t n = uni(entries[e].count), first = uni(entries[e].first);
+				const uint32_t n = uni(head.y), first = uni(head.z);
 				const int32_t rel = (int32_t)(st - p0);                   // (negative: the leaf began in an earlier pass)
 				const bool here = (int32_t)lane >= rel;
 				r = here ? first + (lane - (uint32_t)rel) : r;
