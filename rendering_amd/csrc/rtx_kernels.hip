@@ -669,6 +669,21 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 			const uint32_t lane = laneNow();
 			// which rays an item concerns is wave-level bookkeeping (masks in SGPRs); only the box tests are per lane
 			const uint64_t openM = ballot(resume != kNever);      // (rays close in phase 2 only)
+			auto noteLeaf = [&](int32_t link, uint32_t first, uint64_t m) {
+				const bool in = ((((lane & 32u) ? (uint32_t)(m >> 32) : (uint32_t)m) >> (lane & 31u)) & 1u) != 0;
+				const uint32_t n = (uint32_t)~link;
+				if (RTX_DBG) cnt.wLeaves++;
+				if (m != 0 && n != 0) {
+					if (lane == 0) {
+						LeafEntry en;
+						en.first = first; en.count = n; en.maskLo = (uint32_t)m; en.maskHi = (uint32_t)(m >> 32); en.start = total; en.pad0 = en.pad1 = en.pad2 = 0;
+						entries[batch] = en;
+					}
+					myReach |= in ? 1u << batch : 0u;
+					batch = uni(batch + 1);
+					total = uni(total + n);
+				}
+			};
 			while (sp != 0 && batch < RTX_LEAF_BATCH) {
 				sp = uni(sp - 1);
 				const WideItem it = stack[sp];
@@ -677,20 +692,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				const uint64_t inM = ((uint64_t)mhi << 32 | mlo) & openM;
 				if (link < 0) {
 					// a leaf, in the reference's order: note it with the rays that reached it and are still open
-					const uint64_t m = inM;
-					const bool in = ((((lane & 32u) ? (uint32_t)(m >> 32) : (uint32_t)m) >> (lane & 31u)) & 1u) != 0;
-					const uint32_t n = (uint32_t)~link;
-					if (RTX_DBG) cnt.wLeaves++;
-					if (m != 0 && n != 0) {
-						if (lane == 0) {
-							LeafEntry en;
-							en.first = it.first; en.count = n; en.maskLo = (uint32_t)m; en.maskHi = (uint32_t)(m >> 32); en.start = total; en.pad0 = en.pad1 = en.pad2 = 0;
-							entries[batch] = en;
-						}
-						myReach |= in ? 1u << batch : 0u;
-						batch = uni(batch + 1);
-						total = uni(total + n);
-					}
+					noteLeaf(link, it.first, inM);
 					continue;
 				}
 				if (inM == 0) continue;
@@ -707,7 +709,19 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 						sp = uni(sp + 1);                                                                                           \
 					}                                                                                                               \
 				}
-				RTX_SLOT(wb, 8, 3) RTX_SLOT(wb, 0, 2) RTX_SLOT(wa, 8, 1) RTX_SLOT(wa, 0, 0)
+				RTX_SLOT(wb, 8, 3) RTX_SLOT(wb, 0, 2) RTX_SLOT(wa, 8, 1)
+				// slot 0 would be popped next: a leaf there is noted right away (no trip through the stack) while the batch has room
+				if ((int32_t)wa[6] != 0) {
+					const bool fail = boxFailsRegular(F(wa[0]), F(wa[1]), F(wa[2]), F(wa[3]), F(wa[4]), F(wa[5]), o, ix, iy, iz);
+					const uint64_t mk_ = ballot(!fail) & inM;
+					if (mk_ != 0) {
+						if ((int32_t)wa[6] < 0 && batch < RTX_LEAF_BATCH) noteLeaf((int32_t)wa[6], wa[7], mk_);
+						else {
+							if (lane == 0) { WideItem ni; ni.link = (int32_t)wa[6]; ni.first = wa[7]; ni.maskLo = (uint32_t)mk_; ni.maskHi = (uint32_t)(mk_ >> 32); stack[sp] = ni; }
+							sp = uni(sp + 1);
+						}
+					}
+				}
 #undef RTX_SLOT
 			}
 		}
