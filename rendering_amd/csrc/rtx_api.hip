@@ -83,6 +83,7 @@ struct rtx_scene {
 	uint32_t* ssaaPixels = nullptr; size_t ssaaPixCap = 0;                         // SSAA flagged-pixel list (<= W * H entries)
 	uint32_t* work = nullptr;     // 256 words: [1] SSAA queue head, [3] probe queue head, [8] SSAA list mode, [9] flagged pixels, [128 + 16 q] pass-1 queue head of XCD q
 	unsigned long long* counters = nullptr;
+	uint32_t* orderWork = nullptr;
 	int blocksPass1 = 0, blocksSsaa = 0, blocksFrame = 0;
 	// rtx_render_frame: dependency counters (ready, sobel), flags, SSAA item queue, control words
 	uint32_t* tileDeps = nullptr; unsigned long long* tileFlags = nullptr; uint8_t* tileClass = nullptr; size_t depCap = 0;
@@ -108,6 +109,8 @@ struct rtx_scene {
 	FrameProbe probes[8];
 	unsigned probeNext = 0;
 	int lastFrameMode = -1, frameModeForced = -1;
+	uint64_t viewSerial = 1, ssaaLayoutKey = 0;      // (the SSAA list layout is decided per view: ssaaStage)
+	uint32_t ssaaLayoutAge = 0;
 	size_t lastFrameQueue = ~(size_t)0;      // the view of the last rtx_render_frame (index into tileQueues)
 	std::vector<TileQueues> tileQueues;   // a few entries: a frame may be rendered in several row ranges
 	uint64_t tileUse = 0;
@@ -146,6 +149,7 @@ int ensureWork(rtx_scene* s)
 	if (!s->work) {
 		HIPCHK(hipMalloc((void**)&s->work, 256 * sizeof(uint32_t)));
 		HIPCHK(hipMemset(s->work, 0, 256 * sizeof(uint32_t)));
+		HIPCHK(hipMalloc((void**)&s->orderWork, 8 * 32 * 32 * sizeof(uint32_t)));      // rtxTileOrderKernel: entries per (queue, block, class)
 		HIPCHK(hipMalloc((void**)&s->counters, 16 * sizeof(unsigned long long)));
 		HIPCHK(hipMemset(s->counters, 0, 16 * sizeof(unsigned long long)));
 		int b = 0;
@@ -440,7 +444,7 @@ void rtx_scene_destroy(rtx_scene* s)
 	if (s->frameCtl) (void)hipFree(s->frameCtl);
 	if (s->ssaaPixels) (void)hipFree(s->ssaaPixels);
 	if (s->work) {
-		(void)hipFree(s->work); (void)hipFree(s->counters);
+		(void)hipFree(s->work); (void)hipFree(s->counters); (void)hipFree(s->orderWork);
 		for (int i = 0; i < 5; i++) for (hipEvent_t e : s->evPool[i]) (void)hipEventDestroy(e);
 	}
 	delete s;
@@ -451,6 +455,7 @@ int rtx_scene_set_view(rtx_scene* s, const rtx_view* v)
 	if (!s || !v) return fail(RTX_ERR_ARG, "scene/view is NULL");
 	int rc = setView(s, v);
 	if (rc) return rc;
+	s->viewSerial++;
 	return ensureWork(s);
 }
 
@@ -599,7 +604,9 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 		uint32_t stripLimit = 100000u;
 		if (const char* e = getenv("RTX_STRIP_LIMIT")) stripLimit = (uint32_t)strtoul(e, nullptr, 10);      // experiment knob (100 MHz ticks)
 		// (a strip of a halo row that took more than 1 ms is listed as its tiles again: rtxTileOrderKernel)
-		hipLaunchKernelGGL(rtxTileOrderKernel, dim3(8), dim3(1024), 0, st, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
+		hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(32, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
+		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit);
+		hipLaunchKernelGGL(rtxTileOrderKernel<true>, dim3(32, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
 		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit);
 		p.tileList = tq->list + tq->cap;
 	}
@@ -704,7 +711,9 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 		hipLaunchKernelGGL(rtxTileClassKernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, s->tileCost, p.tilesXFull, p.tilesYFull, s->tileClass, (unsigned long long*)(s->work + 16));
 		uint32_t splitPercent = 100, splitFloor = 2000u;            // floor: 20 us (100 MHz)
 		if (const char* e = getenv("RTX_SPLIT_PERCENT")) splitPercent = (uint32_t)strtoul(e, nullptr, 10);       // experiment knob; 0 = never
-		hipLaunchKernelGGL(rtxTileOrderKernel, dim3(8), dim3(1024), 0, st, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)s->tileClass,
+		hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(32, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)s->tileClass,
+		                   (const unsigned long long*)(s->work + 16), (uint32_t)s->blocksFrame * 4u, splitPercent, splitFloor, s->work + 18);
+		hipLaunchKernelGGL(rtxTileOrderKernel<true>, dim3(32, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)s->tileClass,
 		                   (const unsigned long long*)(s->work + 16), (uint32_t)s->blocksFrame * 4u, splitPercent, splitFloor, s->work + 18);
 		p.tileList = tq->list + tq->cap;
 	}
@@ -868,7 +877,7 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream;
 	HIPCHK(hipMemsetAsync(s->work + 1, 0, sizeof(uint32_t), st));
-	HIPCHK(hipMemsetAsync(s->work + 8, 0, 4 * sizeof(uint32_t), st));
+	HIPCHK(hipMemsetAsync(s->work + 10, 0, sizeof(uint32_t), st));      // (the slot budget used; [8], [9]: the layout decision and its count, see below)
 	if ((rc = stamp(s, 2, st))) return rc;
 	Params p = s->params;
 	p.fb = fb_dev;
@@ -892,10 +901,18 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	if (const char* e = getenv("RTX_SSAA_LOCAL_BELOW")) localBelow = (uint32_t)strtoul(e, nullptr, 10);   // test knob: 0 = always packed
 	uint32_t* mode = s->work + 8;             // [0] local mode, [1] flagged pixels, [2] extra slots handed to 4-pixel tiles
 	uint32_t launches = 0;
-	hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, 0u, 0u, 0u);
-	if ((rc = scanExclusive(s->items, scanN, s->items + scanN, st, launches))) return rc;
-	HIPCHK(hipMemcpyAsync(mode + 1, s->items + 2 * (size_t)p.nTiles, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-	hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, 1u, localBelow, spreadSlots);
+	// The layout (tile-local or packed) follows from the number of flagged pixels: a count, a scan and a copy before the
+	// real count.  It only changes when the view does, so it is decided on the first frame of a view (and again every 16th)
+	// and kept in between -- five small launches less per frame.
+	const uint64_t key = ((((((uint64_t)s->viewSerial * 0x9e3779b97f4a7c15ull + W) * 31 + H) * 31 + rowBegin) * 31 + rowEnd) * 31 + p.bandH * 64 + p.nParts * 8 + p.part) * 31 + localBelow;
+	const bool decideNow = key != s->ssaaLayoutKey || (s->ssaaLayoutAge++ & 15u) == 15u;
+	if (decideNow) {
+		hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, 0u, 0u, 0u);
+		if ((rc = scanExclusive(s->items, scanN, s->items + scanN, st, launches))) return rc;
+		HIPCHK(hipMemcpyAsync(mode + 1, s->items + 2 * (size_t)p.nTiles, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+		s->ssaaLayoutKey = key; s->ssaaLayoutAge = 0;
+	}
+	hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, decideNow ? 1u : 2u, localBelow, spreadSlots);
 	if ((rc = scanExclusive(s->items, scanN, s->items + scanN, st, launches))) return rc;
 	hipLaunchKernelGGL(rtxSsaaScatterKernel, dim3((p.nTiles + 255) / 256), dim3(256), 0, st, p, s->items, mode, s->ssaaPixels, heavyTicks);
 	HIPCHK(hipGetLastError());

@@ -1601,7 +1601,8 @@ __global__ void __launch_bounds__(256) rtxTileClassKernel(const uint32_t* __rest
 // the frame ends: those that took a good part of the time pass 1 would need if its work were spread evenly over the
 // waves (cost sum / waves).  In a small frame that is every tile -- and there are idle waves to take the parts.
 // thresholds[0..1] = the two limits (ticks), also used for the size of the SSAA items (rtxFrameKernel).
-__global__ void __launch_bounds__(1024) rtxTileOrderKernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ cost,
+template <bool PLACE>
+__global__ void __launch_bounds__(256) rtxTileOrderKernel(uint32_t* __restrict__ global, const uint32_t* __restrict__ list, const uint32_t* __restrict__ cost,
                                                            uint32_t tilesXFull, uint32_t* __restrict__ out, const uint8_t* __restrict__ klassIn = nullptr,
                                                            const unsigned long long* __restrict__ costSum = nullptr, uint32_t nWaves = 1,
                                                            uint32_t splitPercent = 0, uint32_t splitFloor = 0, uint32_t* __restrict__ thresholds = nullptr,
@@ -1614,12 +1615,17 @@ __global__ void __launch_bounds__(1024) rtxTileOrderKernel(const uint32_t* __res
 		if (split4 < splitFloor) split4 = splitFloor;
 		split16 = split4 * 4;
 	}
+	// Two launches over 32 blocks per queue (one block per queue took 70 us: 32 dependent rounds of loads per thread), each
+	// block a contiguous piece of the queue: PLACE = false counts the entries of every class of the piece into
+	// global[(q * 32 + block) * 32 + class]; PLACE = true places the piece's entries of a class behind those of the higher
+	// classes of the queue and of the same class in the pieces before it -- the list order (= neighbouring tiles, which share
+	// their nodes in L2) survives within a class, and nothing depends on the order blocks run in.
 	__shared__ uint32_t hist[32], cursor[32];
-	const uint32_t q = blockIdx.x;
+	const uint32_t q = blockIdx.y;
 	const uint32_t base = list[q], n = list[8 + q];
 	const uint32_t obase = 16 + 16 * (base - 16);
 	if (threadIdx.x < 32) hist[threadIdx.x] = 0;
-	if (thresholds && q == 0 && threadIdx.x == 0) { thresholds[0] = split4; thresholds[1] = split16; }
+	if (thresholds && q == 0 && blockIdx.x == 0 && threadIdx.x == 0) { thresholds[0] = split4; thresholds[1] = split16; }
 	__syncthreads();
 	auto entry = [&](uint32_t tile) {      // (a strip: the first tile it runs through)
 		return (tile & 0x10000000u) ? ((tile & 0x7fffu) >> 3) * tilesXFull + ((tile >> 16) & 0xfffu) * 8 : (tile >> 16) * tilesXFull + (tile & 0xffffu);
@@ -1643,15 +1649,29 @@ __global__ void __launch_bounds__(1024) rtxTileOrderKernel(const uint32_t* __res
 		const uint32_t c = cost[entry(tile)];
 		return c > split16 ? 16u : (c > split4 ? 4u : 1u);
 	};
-	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t tile = list[base + i]; atomicAdd(&hist[klass(tile)], parts(tile)); }
-	__syncthreads();
-	if (threadIdx.x == 0) {
+	const uint32_t piece = (n + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * piece, i1 = i0 + piece < n ? i0 + piece : n;
+	if (!PLACE) {
+		for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) { const uint32_t tile = list[base + i]; atomicAdd(&hist[klass(tile)], parts(tile)); }
+		__syncthreads();
+		if (threadIdx.x < 32) global[(q * 32 + blockIdx.x) * 32 + threadIdx.x] = hist[threadIdx.x];
+		return;
+	}
+	if (threadIdx.x < 32) {
+		const uint32_t k = threadIdx.x;
+		uint32_t before = 0;
+		for (uint32_t b = 0; b < gridDim.x; ++b) {
+			for (uint32_t kk = k + 1; kk < 32; ++kk) before += global[(q * 32 + b) * 32 + kk];
+			if (b < blockIdx.x) before += global[(q * 32 + b) * 32 + k];
+		}
+		cursor[k] = before;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 32) {
 		uint32_t run = 0;
-		for (int k = 31; k >= 0; k--) { cursor[k] = run; run += hist[k]; }
+		for (uint32_t b = 0; b < gridDim.x; ++b) for (int k = 0; k < 32; ++k) run += global[(q * 32 + b) * 32 + k];
 		out[q] = obase; out[8 + q] = run;
 	}
 	__syncthreads();
-	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+	for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
 		const uint32_t tile = list[base + i], np = parts(tile);
 		const uint32_t at = obase + atomicAdd(&cursor[klass(tile)], np);
 		if (np == 1) out[at] = tile;
@@ -1689,8 +1709,9 @@ __global__ void __launch_bounds__(256) rtxSsaaCountKernel(const Params P, uint32
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t > 2 * P.nTiles) return;
 	// mode[1] = number of flagged pixels found by the previous (unpadded) count
-	const uint32_t local = decide ? (mode[1] < localBelow ? 1u : 0u) : 0u;
-	if (t >= P.nTiles) { if (t == 2 * P.nTiles) { scan[t] = 0; if (decide) mode[0] = local; } return; }
+	// decide: 0 = the plain count (for the decision), 1 = decide from it, 2 = the layout decided for an earlier frame of this view
+	const uint32_t local = decide == 2 ? mode[0] : (decide ? (mode[1] < localBelow ? 1u : 0u) : 0u);
+	if (t >= P.nTiles) { if (t == 2 * P.nTiles) { scan[t] = 0; if (decide == 1) mode[0] = local; } return; }
 	const uint32_t ty = t / P.tilesXFull, tx = t - ty * P.tilesXFull;
 	uint32_t nf = (uint32_t)__popcll(ssaaFlagged(P, tx, ty));
 	// local mode: a wave holds 16 pixels of one tile -- or only 4 of a tile that was VERY slow in pass 1 (a silhouette),
