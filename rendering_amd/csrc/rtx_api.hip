@@ -604,9 +604,10 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 		uint32_t stripLimit = 100000u;
 		if (const char* e = getenv("RTX_STRIP_LIMIT")) stripLimit = (uint32_t)strtoul(e, nullptr, 10);      // experiment knob (100 MHz ticks)
 		// (a strip of a halo row that took more than 1 ms is listed as its tiles again: rtxTileOrderKernel)
-		hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(32, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
+		const unsigned pieces = tq->listed > 16384u ? 32u : 1u;      // (short queues: one block each, one launch)
+		if (pieces > 1) hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
 		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit);
-		hipLaunchKernelGGL(rtxTileOrderKernel<true>, dim3(32, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
+		hipLaunchKernelGGL(rtxTileOrderKernel<true>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
 		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit);
 		p.tileList = tq->list + tq->cap;
 	}
@@ -711,9 +712,10 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 		hipLaunchKernelGGL(rtxTileClassKernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, s->tileCost, p.tilesXFull, p.tilesYFull, s->tileClass, (unsigned long long*)(s->work + 16));
 		uint32_t splitPercent = 100, splitFloor = 2000u;            // floor: 20 us (100 MHz)
 		if (const char* e = getenv("RTX_SPLIT_PERCENT")) splitPercent = (uint32_t)strtoul(e, nullptr, 10);       // experiment knob; 0 = never
-		hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(32, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)s->tileClass,
+		const unsigned pieces = tq->listed > 16384u ? 32u : 1u;      // (short queues: one block each, one launch)
+		if (pieces > 1) hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)s->tileClass,
 		                   (const unsigned long long*)(s->work + 16), (uint32_t)s->blocksFrame * 4u, splitPercent, splitFloor, s->work + 18);
-		hipLaunchKernelGGL(rtxTileOrderKernel<true>, dim3(32, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)s->tileClass,
+		hipLaunchKernelGGL(rtxTileOrderKernel<true>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)s->tileClass,
 		                   (const unsigned long long*)(s->work + 16), (uint32_t)s->blocksFrame * 4u, splitPercent, splitFloor, s->work + 18);
 		p.tileList = tq->list + tq->cap;
 	}

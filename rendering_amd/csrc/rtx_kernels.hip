@@ -1656,7 +1656,17 @@ __global__ void __launch_bounds__(256) rtxTileOrderKernel(uint32_t* __restrict__
 		if (threadIdx.x < 32) global[(q * 32 + blockIdx.x) * 32 + threadIdx.x] = hist[threadIdx.x];
 		return;
 	}
-	if (threadIdx.x < 32) {
+	if (gridDim.x == 1) {
+		// a short queue: one block does both steps in one launch
+		for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) { const uint32_t tile = list[base + i]; atomicAdd(&hist[klass(tile)], parts(tile)); }
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t run = 0;
+			for (int k = 31; k >= 0; k--) { cursor[k] = run; run += hist[k]; }
+			out[q] = obase; out[8 + q] = run;
+		}
+	}
+	else if (threadIdx.x < 32) {
 		const uint32_t k = threadIdx.x;
 		uint32_t before = 0;
 		for (uint32_t b = 0; b < gridDim.x; ++b) {
@@ -1665,7 +1675,7 @@ __global__ void __launch_bounds__(256) rtxTileOrderKernel(uint32_t* __restrict__
 		}
 		cursor[k] = before;
 	}
-	if (blockIdx.x == 0 && threadIdx.x == 32) {
+	if (gridDim.x != 1 && blockIdx.x == 0 && threadIdx.x == 32) {
 		uint32_t run = 0;
 		for (uint32_t b = 0; b < gridDim.x; ++b) for (int k = 0; k < 32; ++k) run += global[(q * 32 + b) * 32 + k];
 		out[q] = obase; out[8 + q] = run;
