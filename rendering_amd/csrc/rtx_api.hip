@@ -642,7 +642,9 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	p.tileRow0 = rowBegin / 8;
 	if (p.view.width > 0xffffu || p.view.height > 0xffffu) return fail(RTX_ERR_ARG, "frame too large");
 	// the mask of the rows is defined everywhere: 0 where no tile computes it (rows of other parts, the last row / column)
-	HIPCHK(hipMemsetAsync(mask_dev + (size_t)rowBegin * W, 0, (size_t)(rowEnd - rowBegin) * W, st));
+	const size_t maskBytes = (size_t)(rowEnd - rowBegin) * W;
+	const bool maskInClear = maskBytes <= (4u << 20);      // (a small frame: cleared by rtxFrameClearKernel below)
+	if (!maskInClear) HIPCHK(hipMemsetAsync(mask_dev + (size_t)rowBegin * W, 0, maskBytes, st));
 	const uint32_t lastRow = (rowEnd < H - 1 ? rowEnd : H - 1);   // exclusive; row H-1 is never rendered
 	if (lastRow <= rowBegin) return RTX_OK;
 	const uint32_t tilesY = (lastRow + 7) / 8 - p.tileRow0;
@@ -702,13 +704,17 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	p.heavyTicks = 25000u;
 	if (const char* e = getenv("RTX_SSAA_HEAVY_TICKS")) p.heavyTicks = (uint32_t)strtoul(e, nullptr, 10);       // test knobs
 	if (const char* e = getenv("RTX_SSAA_SPREAD_SLOTS")) p.veryBudget = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), kSsaaSpreadSlots) / 16;
+	{
+		const size_t most = std::max<size_t>(4 * tiles, maskInClear ? maskBytes : 0);
+		hipLaunchKernelGGL(rtxFrameClearKernel, dim3((unsigned)std::min<size_t>((most + 255) / 256, 2048)), dim3(256), 0, st, s->work, s->tileDeps, 4 * tiles,
+		                   (uint32_t*)s->frameCtl, (uint32_t)(kFrameCtlBytes / 4), maskInClear ? mask_dev + (size_t)rowBegin * W : nullptr, maskInClear ? maskBytes : 0);
+	}
 	p.tileList = tq->list;
 	p.splitLimits = s->work + 18;
 	const bool ordered = tq->costValid || costsKnown;      // (the costs of this view may come from frames rendered in three launches)
 	if (!ordered) HIPCHK(hipMemsetAsync(s->work + 18, 0xff, 2 * sizeof(uint32_t), st));      // no costs yet: nothing is split
 	if (ordered) {
 		// the previous launch rendered exactly these tiles from this view: start with the ones that were expensive
-		HIPCHK(hipMemsetAsync(s->work + 16, 0, 2 * sizeof(uint32_t), st));
 		hipLaunchKernelGGL(rtxTileClassKernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, s->tileCost, p.tilesXFull, p.tilesYFull, s->tileClass, (unsigned long long*)(s->work + 16));
 		uint32_t splitPercent = 100, splitFloor = 2000u;            // floor: 20 us (100 MHz)
 		if (const char* e = getenv("RTX_SPLIT_PERCENT")) splitPercent = (uint32_t)strtoul(e, nullptr, 10);       // experiment knob; 0 = never
@@ -720,9 +726,6 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 		p.tileList = tq->list + tq->cap;
 	}
 	tq->costValid = true;
-	HIPCHK(hipMemsetAsync(s->work + 128, 0, 128 * sizeof(uint32_t), st));
-	HIPCHK(hipMemsetAsync(s->tileDeps, 0, 4 * tiles * sizeof(uint32_t), st));
-	HIPCHK(hipMemsetAsync(s->frameCtl, 0, kFrameCtlBytes, st));
 	uint32_t blocks = (uint32_t)s->blocksFrame;
 	const uint32_t wavesNeeded = p.nTiles;       // (blocks: quarters of slow tiles and SSAA items want waves too)
 	if (blocks > wavesNeeded) blocks = wavesNeeded ? wavesNeeded : 1;

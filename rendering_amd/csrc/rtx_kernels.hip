@@ -1570,6 +1570,19 @@ __global__ void __launch_bounds__(256) rtxTileNeedKernel(const uint8_t* __restri
 	}
 }
 
+// rtx_render_frame, one launch: everything the frame kernel expects to find zeroed (the per-tile counters, its control
+// block, the tile-queue heads, the cost sum) and, for a small frame, the mask -- five memsets were five launch gaps.
+__global__ void __launch_bounds__(256) rtxFrameClearKernel(uint32_t* __restrict__ work, uint32_t* __restrict__ deps, size_t depWords,
+                                                           uint32_t* __restrict__ ctl, uint32_t ctlWords, uint8_t* __restrict__ mask, size_t maskBytes)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+	if (t < 2) work[16 + t] = 0;
+	if (t < 128) work[128 + t] = 0;
+	for (size_t i = t; i < ctlWords; i += stride) ctl[i] = 0;
+	for (size_t i = t; i < depWords; i += stride) deps[i] = 0;
+	for (size_t i = t; i < maskBytes; i += stride) mask[i] = 0;
+}
+
 // klass != null (rtx_render_frame): the class of a tile is the highest one within two tiles of it (rtxTileClassKernel) --
 // the SSAA items of a slow tile can only be queued once the 5 x 5 tiles around it have been rendered.
 __global__ void __launch_bounds__(256) rtxTileClassKernel(const uint32_t* __restrict__ cost, uint32_t tilesXFull, uint32_t tilesYFull,
