@@ -5,6 +5,7 @@ import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 os.chdir(ROOT)
+import torch
 import rendering_amd as RA
 from rendering_amd import assets
 from oracle import oracle as O
@@ -39,8 +40,19 @@ for seed in range(first, first + n):
     ref2 = o.ssaa(ref1); got2 = g.render_host(ssaa=True)
     rh, rc = o.probe(probe_rays(256)); gh, gc = g.cast_rays(probe_rays(256))
     ok = np.array_equal(bits(ref1), bits(got1)) and np.array_equal(bits(ref2), bits(got2)) and np.array_equal(bits(rh), bits(gh)) and np.array_equal(bits(rc), bits(gc))
+    # rtx_render_frame: three launches and one launch, a cold frame and two warm ones (warm frames split their slow tiles)
+    fb = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda"); mask = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+    frames = 0
+    for mode in (0, 1):
+        g.set_frame_mode(mode)
+        for it in range(3):
+            fb.zero_(); g.render_frame(fb, mask); g.frame_status()
+            if not np.array_equal(bits(ref2), bits(fb.cpu().numpy())):
+                frames += 1
+    ok = ok and frames == 0
     if not ok:
         bad += 1
+        if frames: print("   rtx_render_frame differs in %d of 6 frames" % frames)
         print("MISMATCH seed", seed, "pass-1 pixels", int((bits(ref1) != bits(got1)).any(-1).sum()), "ssaa pixels", int((bits(ref2) != bits(got2)).any(-1).sum()))
     o.close(); g.close()
 print("seeds %d..%d: %d mismatching scenes" % (first, first + n - 1, bad))
