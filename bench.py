@@ -329,6 +329,8 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0])
+    if ssaa:
+        scene.frame_status()      # raises if the frame kernel of any rtx_render_frame gave up: no number from a broken frame
 
     verified = None
     if args.verify and world > 1:

@@ -207,7 +207,8 @@ void rtx_bvh_destroy(rtx_bvh* bvh);
 
 /* Per-tile cost of the most recent rtx_render_pass1 (profiling aid; also what orders the SSAA work list):
  * out[ty * ceil(width/8) + tx] = wall-clock ticks (100 MHz) one wave spent on the 8x8 pixel tile (tx, ty).
- * n must be ceil(width/8) * ceil(height/8).  Synchronises the device. */
+ * n must be ceil(width/8) * ceil(height/8) -- or twice that: the second half then holds, per tile, the slowest SSAA
+ * work item of the most recent rtx_render_ssaa (ticks, scaled to a 16-pixel item).  Synchronises the device. */
 int rtx_tile_cost_read(rtx_scene* scene, uint32_t* out, size_t n);
 
 /* Pixel sharding across the GPUs of a node: bands of band_height rows are dealt round-robin

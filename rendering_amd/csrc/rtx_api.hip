@@ -185,9 +185,9 @@ int ensureWork(rtx_scene* s)
 	if (tiles > s->tileCap) {
 		if (s->tileCost) { HIPCHK(hipFree(s->tileCost)); HIPCHK(hipFree(s->items)); }
 		s->tileCost = nullptr; s->items = nullptr; s->tileCap = 0;
-		HIPCHK(hipMalloc((void**)&s->tileCost, tiles * sizeof(uint32_t)));
+		HIPCHK(hipMalloc((void**)&s->tileCost, 2 * tiles * sizeof(uint32_t)));      // pass-1 cost of every tile; its slowest SSAA item (rtxSsaaKernel)
 		HIPCHK(hipMalloc((void**)&s->items, (tiles * 2 + 1 + tiles / 256 + 1024) * sizeof(uint32_t)));
-		HIPCHK(hipMemset(s->tileCost, 0, tiles * sizeof(uint32_t)));
+		HIPCHK(hipMemset(s->tileCost, 0, 2 * tiles * sizeof(uint32_t)));
 		s->tileCap = tiles;
 	}
 	// every tile's pixels padded to whole waves, plus kSsaaSpreadSlots for the tiles that get 4-pixel waves (a slot budget
@@ -676,7 +676,10 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 		HIPCHK(hipMemset(s->ssaaQueue, 0, 64 * perQueue * sizeof(unsigned long long)));
 		s->queueCap = 64 * perQueue;
 	}
-	if (!s->frameCtl) HIPCHK(hipMalloc((void**)&s->frameCtl, kFrameCtlBytes));
+	if (!s->frameCtl) {
+		HIPCHK(hipMalloc((void**)&s->frameCtl, kFrameCtlBytes));
+		HIPCHK(hipMemset(s->frameCtl, 0, kFrameCtlBytes));      // (rtxFrameClearKernel keeps an error word it finds)
+	}
 	if (!tq->needValid) {
 		// once per tile list, on the device: the listed tiles around every tile and the expected values of the completion counters
 		if (tiles > tq->needCap) {
@@ -707,7 +710,7 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	{
 		const size_t most = std::max<size_t>(4 * tiles, maskInClear ? maskBytes : 0);
 		hipLaunchKernelGGL(rtxFrameClearKernel, dim3((unsigned)std::min<size_t>((most + 255) / 256, 2048)), dim3(256), 0, st, s->work, s->tileDeps, 4 * tiles,
-		                   (uint32_t*)s->frameCtl, (uint32_t)(kFrameCtlBytes / 4), maskInClear ? mask_dev + (size_t)rowBegin * W : nullptr, maskInClear ? maskBytes : 0);
+		                   (uint32_t*)s->frameCtl, (uint32_t)(kFrameCtlBytes / 4), (uint32_t)FC_ERROR, maskInClear ? mask_dev + (size_t)rowBegin * W : nullptr, maskInClear ? maskBytes : 0);
 	}
 	p.tileList = tq->list;
 	p.splitLimits = s->work + 18;
@@ -834,7 +837,7 @@ int rtx_frame_status(rtx_scene* s, uint32_t* status)
 {
 	if (!s || !status) return fail(RTX_ERR_ARG, "scene/status is NULL");
 	*status = 0;
-	if (!s->frameCtl) return RTX_OK;
+	if (!s->frameCtl && !RTX_DBG) return RTX_OK;
 	HIPCHK(hipSetDevice(s->device));
 	HIPCHK(hipDeviceSynchronize());
 #if RTX_DBG
@@ -846,9 +849,14 @@ int rtx_frame_status(rtx_scene* s, uint32_t* status)
 		HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gDbgTimeline), tl.data(), tl.size() * 8));
 		if (FILE* f = fopen(path, "wb")) { fwrite(keep.data(), 8, keep.size(), f); fclose(f); }
 	}
+	if (!s->frameCtl) return RTX_OK;
 #endif
-	uint32_t err = 0;
+	// the error word of the last frame, or the one an earlier frame left since the last call (kept by rtxFrameClearKernel)
+	uint32_t err = 0, earlier = 0;
 	HIPCHK(hipMemcpy(&err, (const uint32_t*)s->frameCtl + FC_ERROR, sizeof(err), hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(&earlier, s->work + 24, sizeof(earlier), hipMemcpyDeviceToHost));
+	if (earlier) HIPCHK(hipMemset(s->work + 24, 0, sizeof(uint32_t)));
+	if (!err) err = earlier;
 	*status = err;
 	if (err) return fail(RTX_ERR_DEVICE, "rtx_render_frame: the frame kernel gave up (1: queue entry never written, 2: work never completed, 3: SSAA queue overflow)");
 	return RTX_OK;
@@ -1077,10 +1085,10 @@ int rtx_tile_cost_read(rtx_scene* s, uint32_t* out, size_t n)
 	if (!s || !out) return fail(RTX_ERR_ARG, "scene/out is NULL");
 	HIPCHK(hipSetDevice(s->device));
 	const size_t tiles = (size_t)((s->params.view.width + 7) / 8) * ((s->params.view.height + 7) / 8);
-	if (n != tiles) return fail(RTX_ERR_ARG, "n must be ceil(width/8) * ceil(height/8)");
+	if (n != tiles && n != 2 * tiles) return fail(RTX_ERR_ARG, "n must be ceil(width/8) * ceil(height/8), or twice that");
 	if (!s->tileCost || s->tileCap < tiles) return fail(RTX_ERR_ARG, "no pass 1 has run at this size");
 	HIPCHK(hipDeviceSynchronize());
-	HIPCHK(hipMemcpy(out, s->tileCost, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(out, s->tileCost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
 	return RTX_OK;
 }
 

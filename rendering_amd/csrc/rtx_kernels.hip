@@ -1490,6 +1490,9 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
 	Counts cnt = {};
+#if RTX_DBG
+	uint32_t dbgItems = 0;
+#endif
 	for (;;) {
 		// work item = 16 consecutive entries of the flagged-pixel list (rtxSsaaCountKernel / rtxSsaaScatterKernel):
 		// full waves even where a tile has only a few flagged pixels; the pixels of tiles that were expensive in pass 1
@@ -1510,8 +1513,23 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 		const float fx = (float)x + ((sub & 2) ? 0.75f : 0.25f), fy = (float)y + ((sub & 1) ? 0.75f : 0.25f);
 		V3 o, d;
 		primaryRay(P, fx, fy, o, d);
-		const unsigned long long t0 = STATS ? wall_clock64() : 0;
+		const unsigned long long t0 = wall_clock64();
 		const V3 c = castRayWave<STATS, MESH, true>(P, valid, o, d, gl, cnt);      // (work items of 16, 4 or 1 pixels: see the exact tests of meshWalk)
+		if (!STATS) {
+			// what the item cost, as the time of a 16-pixel item (a 4-pixel item takes at least a quarter of it), kept per tile
+			// in the second half of tileCost: a profiling aid (rtx_tile_cost_read, tools/ssaa_items.py).  Ordering and sizing
+			// the next frame's items by it was measured and lost to the pass-1 costs that do it now
+			const uint32_t npx = (uint32_t)__popcll(ballot(valid)) >> 2;
+			const unsigned long long dt16 = (wall_clock64() - t0) * (npx <= 4u ? 4u : (npx <= 8u ? 2u : 1u));
+			if (lane == 0 && pxy != 0xffffffffu) atomicMax(P.tileCost + P.nTiles + (y >> 3) * P.tilesXFull + (x >> 3), (uint32_t)(dt16 > 0xffffffffull ? 0xffffffffull : dt16));
+		}
+#if RTX_DBG
+		if (!STATS && lane == 0 && (gl >> 6) < 8192 && dbgItems < 160) {      // (tools/ssaa_timeline.py)
+			const size_t e = (size_t)(gl >> 6) * 160 + dbgItems;
+			gDbgTimeline[3 * e] = t0; gDbgTimeline[3 * e + 1] = wall_clock64() - t0; gDbgTimeline[3 * e + 2] = 2ull << 32 | pxy;
+		}
+		dbgItems++;
+#endif
 		if (STATS && lane == 0) { atomicMax(P.counters + 3, wall_clock64() - t0); atomicAdd(P.counters + 4, wall_clock64() - t0); }
 		// color = 0; color += c0; += c1; += c2; += c3; fb = color / 4
 		const int base = (int)(lane & ~3u);
@@ -1573,12 +1591,13 @@ __global__ void __launch_bounds__(256) rtxTileNeedKernel(const uint8_t* __restri
 // rtx_render_frame, one launch: everything the frame kernel expects to find zeroed (the per-tile counters, its control
 // block, the tile-queue heads, the cost sum) and, for a small frame, the mask -- five memsets were five launch gaps.
 __global__ void __launch_bounds__(256) rtxFrameClearKernel(uint32_t* __restrict__ work, uint32_t* __restrict__ deps, size_t depWords,
-                                                           uint32_t* __restrict__ ctl, uint32_t ctlWords, uint8_t* __restrict__ mask, size_t maskBytes)
+                                                           uint32_t* __restrict__ ctl, uint32_t ctlWords, uint32_t errWord, uint8_t* __restrict__ mask, size_t maskBytes)
 {
 	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
 	if (t < 2) work[16 + t] = 0;
 	if (t < 128) work[128 + t] = 0;
-	for (size_t i = t; i < ctlWords; i += stride) ctl[i] = 0;
+	// (an error word left by an earlier frame is kept for rtx_frame_status: work[24])
+	for (size_t i = t; i < ctlWords; i += stride) { if (i == errWord && ctl[i]) work[24] = ctl[i]; ctl[i] = 0; }
 	for (size_t i = t; i < depWords; i += stride) deps[i] = 0;
 	for (size_t i = t; i < maskBytes; i += stride) mask[i] = 0;
 }
@@ -1759,6 +1778,7 @@ __global__ void __launch_bounds__(256) rtxSsaaScatterKernel(const Params P, cons
 	const uint32_t ty = t / P.tilesXFull, tx = t - ty * P.tilesXFull;
 	uint64_t m = ssaaFlagged(P, tx, ty);
 	const uint32_t idx = P.tileCost[t] > heavyTicks ? t : P.nTiles + t;
+	P.tileCost[P.nTiles + t] = 0;      // (the SSAA item costs of this frame are collected from here on: rtxSsaaKernel)
 	uint32_t slot = scan[idx];
 	const uint32_t slots = scan[idx + 1] - slot, nf = (uint32_t)__popcll(m);      // (the other half's entry of a tile is 0 slots wide)
 	const bool spread = mode[0] && slots > ((nf + 15u) & ~15u);      // 4 pixels per group of 16 slots
