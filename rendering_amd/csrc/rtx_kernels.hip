@@ -1307,6 +1307,19 @@ __device__ __forceinline__ void primaryRay(const Params& P, float x, float y, V3
 	d = r;
 }
 
+// The shading state of a lane that nothing reads while its ray is traced (the hit being shaded, the light, the sums):
+// parked in LDS around every trace so that the walk has the registers.  Left to the compiler it goes to scratch, i.e.
+// through L2 into HBM and back (round 1 / 2: 5.9 GB of writes per launch for a 0.2-GB framebuffer); the kernels use
+// 5-10 KB of the 32-40 KB of LDS their occupancy leaves a block.
+#ifndef RTX_PARK
+#define RTX_PARK 1
+#endif
+#ifndef RTX_PARK_MORE
+#define RTX_PARK_MORE 1
+#endif
+constexpr int kParkFields = RTX_PARK_MORE ? 26 : 21;
+__shared__ float parkedState[kParkFields][256];
+
 template <bool STATS, bool MESH = true, bool FEWRAYS = false>
 __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 d, uint32_t gl, Counts& cnt)
 {
@@ -1333,7 +1346,39 @@ __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 
 		// the pending request of every lane: a shadow ray from the point being shaded, or the lane's current ray
 		const bool qshadow = s.state == ST_WAIT_SHADOW;
 		const V3 qo = qshadow ? s.P + s.N * P.view.bias : s.ro, qd = qshadow ? -s.L : s.rd;
-		traceWave<STATS, MESH, FEWRAYS>(P, s.state != ST_DONE && (STATS || !moot), qshadow, qo, qd, s.qtmax, h, cnt);
+		const bool qactive = s.state != ST_DONE && (STATS || !moot);
+		const float qtmax = s.qtmax;
+		if (MESH && RTX_PARK) {
+			const uint32_t t = threadIdx.x;
+			parkedState[0][t] = s.P.x; parkedState[1][t] = s.P.y; parkedState[2][t] = s.P.z;
+			parkedState[3][t] = s.N.x; parkedState[4][t] = s.N.y; parkedState[5][t] = s.N.z;
+			parkedState[6][t] = s.objColor.x; parkedState[7][t] = s.objColor.y; parkedState[8][t] = s.objColor.z;
+			parkedState[9][t] = s.diff.x; parkedState[10][t] = s.diff.y; parkedState[11][t] = s.diff.z;
+			parkedState[12][t] = s.spec.x; parkedState[13][t] = s.spec.y; parkedState[14][t] = s.spec.z;
+			parkedState[15][t] = s.L.x; parkedState[16][t] = s.L.y; parkedState[17][t] = s.L.z;
+			parkedState[18][t] = s.I.x; parkedState[19][t] = s.I.y; parkedState[20][t] = s.I.z;
+			if (RTX_PARK_MORE) {
+				parkedState[21][t] = s.rd.x; parkedState[22][t] = s.rd.y; parkedState[23][t] = s.rd.z;
+				parkedState[24][t] = s.specCoef; parkedState[25][t] = s.nSpec;
+			}
+			asm volatile("" ::: "memory");
+		}
+		traceWave<STATS, MESH, FEWRAYS>(P, qactive, qshadow, qo, qd, qtmax, h, cnt);
+		if (MESH && RTX_PARK) {
+			asm volatile("" ::: "memory");
+			const uint32_t t = threadIdx.x;
+			s.P = mk(parkedState[0][t], parkedState[1][t], parkedState[2][t]);
+			s.N = mk(parkedState[3][t], parkedState[4][t], parkedState[5][t]);
+			s.objColor = mk(parkedState[6][t], parkedState[7][t], parkedState[8][t]);
+			s.diff = mk(parkedState[9][t], parkedState[10][t], parkedState[11][t]);
+			s.spec = mk(parkedState[12][t], parkedState[13][t], parkedState[14][t]);
+			s.L = mk(parkedState[15][t], parkedState[16][t], parkedState[17][t]);
+			s.I = mk(parkedState[18][t], parkedState[19][t], parkedState[20][t]);
+			if (RTX_PARK_MORE) {
+				s.rd = mk(parkedState[21][t], parkedState[22][t], parkedState[23][t]);
+				s.specCoef = parkedState[24][t]; s.nSpec = parkedState[25][t];
+			}
+		}
 #if RTX_DBG
 		const unsigned long long dbgT1 = __builtin_readcyclecounter();
 #endif
