@@ -429,6 +429,14 @@ class Scene:
         _check(self.rtx.rtx_tile_cost_read(self.gpu(), _np_ptr(out), out.size), "rtx_tile_cost_read")
         return out
 
+    def ssaa_item_cost(self):
+        """(ceil(H/8), ceil(W/8)) uint32 array: per tile, the slowest SSAA work item of the most recent render_ssaa in
+        100 MHz ticks, scaled to a 16-pixel item (0 = the tile had no flagged pixel); the second half of rtx_tile_cost_read."""
+        self._dims()
+        out = np.zeros((2, (self.height + 7) // 8, (self.width + 7) // 8), np.uint32)
+        _check(self.rtx.rtx_tile_cost_read(self.gpu(), _np_ptr(out), out.size), "rtx_tile_cost_read")
+        return out[1]
+
     def set_row_ownership(self, band_height, n_parts, part, halo=True):
         _check(self.rtx.rtx_set_row_ownership(self.gpu(), band_height, n_parts, part, int(halo)), "rtx_set_row_ownership")
 

