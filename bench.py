@@ -289,7 +289,7 @@ def main():
     # Pass 1 is counted over the OWNED rows only (halo off), so that the sum over the ranks is the ray count of the
     # frame itself -- the rays of the recomputed halo rows are extra work of the sharding, not units of the metric.
     scene.counters_enable(True)
-    scene.set_row_ownership(parallel.BAND if world > 1 else 0, world, rank, halo=False)
+    scene.set_row_ownership(parallel.band_height(H, world) if world > 1 else 0, world, rank, halo=False)
     scene.counters_reset()
     scene.render_pass1(fb)
     c1 = scene.counters()                       # pass 1, this rank's rows
@@ -399,7 +399,7 @@ def main():
                    "name": args.config,
                    "rays_per_frame": rays_per_frame, "moot_shadow_rays": int(tot[3]),
                    "walked_rays_per_frame": walked, "walked_mrays_s": round(walked * args.steps / dt / 1e6, 3),
-                   "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.BAND, world, ", BGR8 bands collected on rank 0" if world > 1 else ""),
+                   "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.band_height(H, world), world, ", BGR8 bands collected on rank 0" if world > 1 else ""),
                    "gather": gather_via,
                    "frame": ("one launch (rtxFrameKernel)" if one_launch else "three launches (pass 1, Sobel, SSAA)") if ssaa else "pass 1 only",
                    "measured_three_launches_ms": None if split_ms < 0 else round(split_ms, 3), "measured_one_launch_ms": None if fused_ms < 0 else round(fused_ms, 3),

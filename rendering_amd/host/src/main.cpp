@@ -1,7 +1,7 @@
 // CLI: render_amd [--gpus N] [scene]  (reference: src/main.cpp = Scene(path).render())
 // --gpus N: one process per GPU.  The parent forks N-1 workers BEFORE anything touches the HIP runtime, rank 0 creates
 // the RCCL id (rtx_comm_unique_id) and hands it to the workers through pipes; every rank loads the scene, renders its
-// 64-row bands on its own GPU and Scene::render() collects the image on rank 0 (rtx_gather), which writes the BMP.
+// bands of rows on its own GPU and Scene::render() collects the image on rank 0 (rtx_gather), which writes the BMP.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

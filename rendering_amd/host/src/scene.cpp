@@ -612,8 +612,16 @@ void Scene::attachComm(rtx_comm* comm, int nRanks, int rank)
 
 // Scene::render (scene.cpp:595-606): pass 1, the adaptive 4-ray pass, saveImage.  The frame stays in HBM; what comes
 // back to the host is the BGR8 image saveImage writes (3 bytes per pixel instead of 4 x 12).  With a communicator
-// attached (one process per GPU) this rank renders its own 64-row bands, and the bands are collected on rank 0 with
+// attached (one process per GPU) this rank renders its own bands of rows, and the bands are collected on rank 0 with
 // rtx_gather (RCCL over xGMI) -- rank 0 writes the file.
+// Rows per band: about eight bands per device, between 64 and 256 rows (every band costs two halo rows; the same rule as
+// rendering_amd/parallel.py band_height, measured there).
+static uint32_t bandHeight(uint32_t height, uint32_t nParts)
+{
+	const uint32_t b = height / (8u * (nParts ? nParts : 1u)) / 64u * 64u;
+	return b < 64u ? 64u : (b > 256u ? 256u : b);
+}
+
 void Scene::render()
 {
 	if (!sceneLoadSuccess) return;
@@ -625,7 +633,7 @@ void Scene::render()
 	rtx_scene* g = gpu();
 	DeviceFrame& d = deviceFrame();
 	const bool sharded = comm_ && nRanks_ > 1;
-	gpuCheck(rtx_set_row_ownership(g, sharded ? 64u : 0u, (uint32_t)nRanks_, (uint32_t)rank_, 1), "rtx_set_row_ownership");
+	gpuCheck(rtx_set_row_ownership(g, sharded ? bandHeight((uint32_t)options.height, (uint32_t)nRanks_) : 0u, (uint32_t)nRanks_, (uint32_t)rank_, 1), "rtx_set_row_ownership");
 	hipCheck(hipMemset(d.fb, 0, options.width * options.height * sizeof(Vec3f)), "hipMemset");    // new Vec3f[H*W]() (scene.cpp:599)
 	if (options::enableSSAA && !statisticsOn()) {
 		// launchWorkers + launchSSAA as one call: the stages overlap on the device (rtx_render_frame)

@@ -1,7 +1,7 @@
 """Pixel sharding of one frame over the GPUs of a node.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rows are dealt to ranks in
-round-robin bands of BAND rows (the mesh sits centre-frame, so contiguous blocks would be unbalanced).
+round-robin bands of band_height() rows (the mesh sits centre-frame, so contiguous blocks would be unbalanced).
 Per frame and rank:
     pass 1 on the owned bands + a 1-row halo (recomputed, so the Sobel mask needs no exchange)
     Sobel mask + adaptive 4-ray pass on the owned rows
@@ -13,7 +13,16 @@ point-to-point operations; it exists for the CPU (gloo) tests and for boxes wher
 """
 import numpy as np
 
-BAND = 64
+BAND = 64      # the smallest band; band_height() is what the frame is dealt in
+
+
+def band_height(height, n_parts):
+    """Rows per band for a frame of `height` rows over n_parts devices: about eight bands per device (the mesh sits
+    centre-frame, a device needs rows from everywhere), between 64 and 256 rows -- every band costs two halo rows, and
+    measured on one device's share (tools/shard_time.py) 256-row bands beat 64-row ones by 8 points of efficiency at
+    N = 2, while at N = 8 a 4096-row frame needs the small ones for balance.  Scene::render() of the C++ host uses the
+    same rule (host/src/scene.cpp)."""
+    return int(min(256, max(BAND, (height // (8 * max(n_parts, 1))) // 64 * 64)))
 
 
 def owned_rows(height, band, n_parts, part):
@@ -22,9 +31,11 @@ def owned_rows(height, band, n_parts, part):
     return y[(y // band) % n_parts == part]
 
 
-def shard_frame(scene, fb, mask, n_parts, part, band=BAND, ssaa=True, stream=None):
+def shard_frame(scene, fb, mask, n_parts, part, band=None, ssaa=True, stream=None):
     """Renders this rank's rows of one frame into the device tensors fb (H,W,3 f32) / mask (H,W u8)."""
     fb.zero_()
+    if band is None:
+        band = band_height(fb.shape[0], n_parts)
     scene.set_row_ownership(band if n_parts > 1 else 0, n_parts, part, halo=True)
     if ssaa:
         scene.render_frame(fb, mask, stream=stream)      # pass 1 + Sobel + SSAA (rtx_render_frame: one launch or three)
@@ -37,7 +48,7 @@ def band_ranges(height, band, n_parts, part):
     return [(y0, min(y0 + band, height)) for b, y0 in enumerate(range(0, height, band)) if b % n_parts == part]
 
 
-def gather_frame(img, n_parts, part, band=BAND, dst=0, group=None, bottom_up=False):
+def gather_frame(img, n_parts, part, band=None, dst=0, group=None, bottom_up=False):
     """Collects every rank's owned rows into rank `dst`'s img (in place), with no staging copies: a band is a
     contiguous slab of img, so every band travels as one point-to-point message straight from the owner's buffer into
     its final place in dst's buffer (xGMI links are point-to-point: one grouped batch of sends / receives, no ring).
@@ -48,6 +59,8 @@ def gather_frame(img, n_parts, part, band=BAND, dst=0, group=None, bottom_up=Fal
         return img
     H = img.shape[0]
     flat = img.view(H, -1)
+    if band is None:
+        band = band_height(H, n_parts)
 
     def slab(y0, y1):
         return flat[H - y1:H - y0] if bottom_up else flat[y0:y1]

@@ -10,6 +10,9 @@ args = sys.argv[1:]
 S = 4096
 if "--size" in args:
     k = args.index("--size"); S = int(args[k + 1]); del args[k:k + 2]
+BAND = None      # (parallel.band_height unless --band)
+if "--band" in args:
+    k = args.index("--band"); BAND = int(args[k + 1]); del args[k:k + 2]
 Ns = [int(a) for a in args] or [2, 4, 8]
 W = H = S
 g = RA.Scene("scenes/cfg2_smooth_250k.scene", W, H)
@@ -19,7 +22,7 @@ def settled(parts, part):
     """ms of one frame of this part (events around rtx_render_frame), after it has settled on one launch or three."""
     best = 1e9
     for it in range(10):
-        parallel.shard_frame(g, fb, mask, parts, part)
+        parallel.shard_frame(g, fb, mask, parts, part, band=BAND)
         torch.cuda.synchronize()
         if it >= 7:
             best = min(best, g.last_kernel_ms(3))
@@ -28,11 +31,11 @@ def settled(parts, part):
 
 
 one, mode, a, b = settled(1, 0)
-print("%dx%d, 1 GPU: %.3f ms per frame (%s; measured three launches %.3f ms, one launch %.3f ms)" % (W, H, one, ("three launches", "one launch")[mode], a, b))
+print("%dx%d%s, 1 GPU: %.3f ms per frame (%s; measured three launches %.3f ms, one launch %.3f ms)" % (W, H, ", bands of %d rows" % BAND if BAND else "", one, ("three launches", "one launch")[mode], a, b))
 for N in Ns:
     worst = 0; modes = ""
     for part in range(N):
         t, mode, a, b = settled(N, part)
         modes += "31"[mode]
         worst = max(worst, t)
-    print("N = %d: slowest part %.3f ms per frame (ideal %.3f; launches per part: %s) -> projected efficiency %.0f %%" % (N, worst, one / N, modes, 100.0 * one / N / worst))
+    print("N = %d (%d-row bands): slowest part %.3f ms per frame (ideal %.3f; launches per part: %s) -> projected efficiency %.0f %%" % (N, BAND or parallel.band_height(H, N), worst, one / N, modes, 100.0 * one / N / worst))
