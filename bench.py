@@ -265,7 +265,9 @@ def main():
         gather_via = "torch.distributed P2P over %s, staged through host memory (functional check)" % backend
 
     def step():
-        parallel.shard_frame(scene, fb, mask, world, rank, ssaa=ssaa)
+        # (fb was zeroed when it was allocated and only ever holds frames of this view and row ownership: the reference's
+        # zero-initialised allocation, scene.cpp:599, is outside its timers too)
+        parallel.shard_frame(scene, fb, mask, world, rank, ssaa=ssaa, clear=False)
         if world > 1:
             # the frame has to end up in ONE place: quantise to the BGR8 image saveImage writes (4x fewer bytes than
             # the fp32 framebuffer) and send every owned band straight into rank 0's image

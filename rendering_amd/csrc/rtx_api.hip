@@ -608,11 +608,11 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 		if (pieces > 1) hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
 		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit);
 		hipLaunchKernelGGL(rtxTileOrderKernel<true>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
-		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit);
+		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit, s->work + 128);      // (also zeroes the queue heads)
 		p.tileList = tq->list + tq->cap;
 	}
+	else HIPCHK(hipMemsetAsync(s->work + 128, 0, 128 * sizeof(uint32_t), st));
 	tq->costValid = true;
-	HIPCHK(hipMemsetAsync(s->work + 128, 0, 128 * sizeof(uint32_t), st));
 	uint32_t blocks = (uint32_t)s->blocksPass1;
 	const uint32_t wavesNeeded = (p.nTiles + 3) / 4;
 	if (blocks > wavesNeeded) blocks = wavesNeeded ? wavesNeeded : 1;
@@ -872,7 +872,7 @@ int rtx_sobel(rtx_scene* s, const float* fb_dev, uint32_t rowBegin, uint32_t row
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream;
 	if ((rc = stamp(s, 1, st))) return rc;
-	dim3 grid((W + 63) / 64, (rowEnd - rowBegin + 3) / 4);
+	dim3 grid((W + 61) / 62, (rowEnd - rowBegin + 4 * kSobelRows - 1) / (4 * kSobelRows));      // (a wave: 62 columns x kSobelRows rows)
 	hipLaunchKernelGGL(rtxSobelKernel, grid, dim3(256), 0, st, fb_dev, mask_dev, W, H, rowBegin, rowEnd,
 	                   s->params.bandH, s->params.nParts, s->params.part);
 	HIPCHK(hipGetLastError());
@@ -889,8 +889,8 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	int rc = ensureWork(s);
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream;
-	HIPCHK(hipMemsetAsync(s->work + 1, 0, sizeof(uint32_t), st));
-	HIPCHK(hipMemsetAsync(s->work + 10, 0, sizeof(uint32_t), st));      // (the slot budget used; [8], [9]: the layout decision and its count, see below)
+	// (work[1], the queue head, and work[10], the slot budget used, are zeroed by rtxSsaaScatterKernel; [8], [9]: the layout
+	// decision and its count, see below)
 	if ((rc = stamp(s, 2, st))) return rc;
 	Params p = s->params;
 	p.fb = fb_dev;

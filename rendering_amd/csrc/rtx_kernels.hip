@@ -1683,8 +1683,10 @@ __global__ void __launch_bounds__(256) rtxTileOrderKernel(uint32_t* __restrict__
                                                            uint32_t tilesXFull, uint32_t* __restrict__ out, const uint8_t* __restrict__ klassIn = nullptr,
                                                            const unsigned long long* __restrict__ costSum = nullptr, uint32_t nWaves = 1,
                                                            uint32_t splitPercent = 0, uint32_t splitFloor = 0, uint32_t* __restrict__ thresholds = nullptr,
-                                                           uint32_t tilesX = 0, uint32_t stripLimit = 0xffffffffu)
+                                                           uint32_t tilesX = 0, uint32_t stripLimit = 0xffffffffu, uint32_t* __restrict__ heads = nullptr)
 {
+	// (the eight queue heads of the launch that follows, 64 bytes apart: saves a memset per frame)
+	if (PLACE && heads && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 128) heads[threadIdx.x] = 0;
 	uint32_t split4 = 0xffffffffu, split16 = 0xffffffffu;
 	if (costSum && splitPercent) {
 		const unsigned long long even = *costSum / nWaves * splitPercent / 100;
@@ -1743,19 +1745,27 @@ __global__ void __launch_bounds__(256) rtxTileOrderKernel(uint32_t* __restrict__
 			out[q] = obase; out[8 + q] = run;
 		}
 	}
-	else if (threadIdx.x < 32) {
-		const uint32_t k = threadIdx.x;
-		uint32_t before = 0;
-		for (uint32_t b = 0; b < gridDim.x; ++b) {
-			for (uint32_t kk = k + 1; kk < 32; ++kk) before += global[(q * 32 + b) * 32 + kk];
-			if (b < blockIdx.x) before += global[(q * 32 + b) * 32 + k];
+	else {
+		// the counts of the queue's pieces (up to 32 x 32 words) through LDS: read once by the whole block -- a thread that
+		// summed a thousand of them straight from memory made this launch last 70 us
+		__shared__ uint32_t counts[32 * 32], classTotal[32];
+		for (uint32_t w = threadIdx.x; w < gridDim.x * 32; w += blockDim.x) counts[w] = global[q * 32 * 32 + w];
+		__syncthreads();
+		if (threadIdx.x < 32) {
+			const uint32_t k = threadIdx.x;
+			uint32_t all = 0, before = 0;
+			for (uint32_t b = 0; b < gridDim.x; ++b) { const uint32_t c = counts[b * 32 + k]; all += c; if (b < blockIdx.x) before += c; }
+			classTotal[k] = all;
+			cursor[k] = before;      // (+ the higher classes of the whole queue, below)
 		}
-		cursor[k] = before;
-	}
-	if (gridDim.x != 1 && blockIdx.x == 0 && threadIdx.x == 32) {
-		uint32_t run = 0;
-		for (uint32_t b = 0; b < gridDim.x; ++b) for (int k = 0; k < 32; ++k) run += global[(q * 32 + b) * 32 + k];
-		out[q] = obase; out[8 + q] = run;
+		__syncthreads();
+		if (threadIdx.x < 32) {
+			const uint32_t k = threadIdx.x;
+			uint32_t higher = 0;
+			for (uint32_t kk = k + 1; kk < 32; ++kk) higher += classTotal[kk];
+			cursor[k] += higher;
+			if (blockIdx.x == 0 && k == 0) { out[q] = obase; out[8 + q] = higher + classTotal[0]; }
+		}
 	}
 	__syncthreads();
 	for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
@@ -1815,10 +1825,13 @@ __global__ void __launch_bounds__(256) rtxSsaaCountKernel(const Params P, uint32
 	scan[P.nTiles + t] = heavy ? 0u : nf;
 }
 
-__global__ void __launch_bounds__(256) rtxSsaaScatterKernel(const Params P, const uint32_t* __restrict__ scan, const uint32_t* __restrict__ mode,
+__global__ void __launch_bounds__(256) rtxSsaaScatterKernel(const Params P, const uint32_t* __restrict__ scan, uint32_t* __restrict__ mode,
                                                             uint32_t* __restrict__ pixels, uint32_t heavyTicks)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	// (instead of two memsets per frame: the queue head of the SSAA launch that follows, and the slot budget the NEXT count
+	// kernel hands out -- nothing uses either while this kernel runs; both start at zero, rtx_api.hip ensureWork)
+	if (t == 0) { P.workCounter[0] = 0; mode[2] = 0; }
 	if (t >= P.nTiles) return;
 	const uint32_t ty = t / P.tilesXFull, tx = t - ty * P.tilesXFull;
 	uint64_t m = ssaaFlagged(P, tx, ty);
@@ -1890,17 +1903,48 @@ __device__ __forceinline__ bool sobelFlag(Fetch fetch)
 	return val > 0.5f;
 }
 
+constexpr uint32_t kSobelRows = 8;
 __global__ void __launch_bounds__(256) rtxSobelKernel(const float* __restrict__ fb, uint8_t* __restrict__ mask,
                                                       uint32_t W, uint32_t H, uint32_t rowBegin, uint32_t rowEnd,
                                                       uint32_t bandH, uint32_t nParts, uint32_t part)
 {
-	const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-	const uint32_t y = rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
-	bool flag = false;
-	const bool inImage = x < W && y < rowEnd && y < H && rowOwned(bandH, nParts, part, y);
-	if (inImage && x >= 1 && x + 1 < W && y >= 1 && y + 1 < H)
-		flag = sobelFlag([&](int a, int b) { return load3(fb + ((size_t)(y - 1 + a) * W + (x - 1 + b)) * 3); });
-	if (inImage) mask[(size_t)y * W + x] = flag ? 1 : 0;       // borders are defined as 0 (reference: uninitialised)
+	// A wave = 62 columns (its 64 lanes hold the columns x0 - 1 .. x0 + 62; the outer two only feed their neighbours) x
+	// kSobelRows rows, walked downwards with the last three rows of pixels in registers: every pixel is loaded ONCE per wave
+	// (one 12-byte load per lane and row) and reaches the lanes either side through the crossbar -- instead of nine
+	// pixels = 27 scalar loads per output pixel.  HBM-bound: the framebuffer is read once.
+	const uint32_t lane = threadIdx.x & 63;
+	const int x = (int)(blockIdx.x * 62 + lane) - 1;
+	const uint32_t y0 = rowBegin + (blockIdx.y * 4 + (threadIdx.x >> 6)) * kSobelRows;
+	if (y0 >= rowEnd || y0 >= H) return;
+	const bool xin = x >= 0 && x < (int)W;
+	const bool interiorX = x >= 1 && x + 1 < (int)W && lane >= 1 && lane <= 62;
+	// (all the rows requested before the first is used: walked one load at a time a wave waited for 18 memory round trips)
+	V3 own[kSobelRows + 2];
+#pragma unroll
+	for (uint32_t r = 0; r < kSobelRows + 2; ++r) {
+		const int y = (int)(y0 + r) - 1;
+		own[r] = mk(0, 0, 0);
+		if (xin && y >= 0 && y < (int)H && y <= (int)rowEnd) own[r] = load3(fb + ((size_t)y * W + (size_t)x) * 3);
+	}
+	V3 rows[3][3];      // [row above, row, row below][left, centre, right]
+	auto spread = [&](const V3& c, V3* out) {
+		out[1] = c;
+		out[0] = mk(__shfl_up(c.x, 1), __shfl_up(c.y, 1), __shfl_up(c.z, 1));
+		out[2] = mk(__shfl_down(c.x, 1), __shfl_down(c.y, 1), __shfl_down(c.z, 1));
+	};
+	spread(own[0], rows[0]);
+	spread(own[1], rows[1]);
+#pragma unroll
+	for (uint32_t r = 0; r < kSobelRows; ++r) {
+		const uint32_t y = y0 + r;
+		if (y >= rowEnd || y >= H) break;
+		spread(own[r + 2], rows[2]);
+		bool flag = false;
+		if (interiorX && y >= 1 && y + 1 < H) flag = sobelFlag([&](int a, int b) { return rows[a][b]; });
+		// borders are defined as 0 (reference: uninitialised)
+		if (xin && lane >= 1 && lane <= 62 && rowOwned(bandH, nParts, part, y)) mask[(size_t)y * W + (size_t)x] = flag ? 1 : 0;
+		for (int b = 0; b < 3; ++b) { rows[0][b] = rows[1][b]; rows[1][b] = rows[2][b]; }
+	}
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -31,9 +31,13 @@ def owned_rows(height, band, n_parts, part):
     return y[(y // band) % n_parts == part]
 
 
-def shard_frame(scene, fb, mask, n_parts, part, band=None, ssaa=True, stream=None):
-    """Renders this rank's rows of one frame into the device tensors fb (H,W,3 f32) / mask (H,W u8)."""
-    fb.zero_()
+def shard_frame(scene, fb, mask, n_parts, part, band=None, ssaa=True, stream=None, clear=True):
+    """Renders this rank's rows of one frame into the device tensors fb (H,W,3 f32) / mask (H,W u8).
+    clear: zero fb first, like the reference's `new Vec3f[H*W]()` (scene.cpp:599, outside its "Render scene" timer) -- the
+    last row / column and the rows of other ranks are never written; a caller that re-renders into a buffer that already
+    is such a frame (bench.py) passes False."""
+    if clear:
+        fb.zero_()
     if band is None:
         band = band_height(fb.shape[0], n_parts)
     scene.set_row_ownership(band if n_parts > 1 else 0, n_parts, part, halo=True)
