@@ -791,10 +791,16 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 		mode = tq->frameMs[1] <= tq->frameMs[0] ? 1 : 0;
 		if ((tq->framesSeen & 63u) == 63u) mode ^= 1;
 	}
-	rtx_scene::FrameProbe& pr = s->probes[s->probeNext++ & 7u];
-	if (!pr.a) { HIPCHK(hipEventCreate(&pr.a)); HIPCHK(hipEventCreate(&pr.b)); }
-	pr.pending = false;
-	HIPCHK(hipEventRecord(pr.a, st));
+	// The frame is bracketed by its own pair of events only while the choice is being made or re-examined (the frame that
+	// tries the other way every 64 frames and the one before it): an event costs the queue ~5 us.
+	const bool probing = forced < 0 && tq && (!warm || tq->frameSamples[0] < 2 || tq->frameSamples[1] < 2 || (tq->framesSeen & 63u) >= 62u);
+	rtx_scene::FrameProbe* pr = nullptr;
+	if (probing) {
+		pr = &s->probes[s->probeNext++ & 7u];
+		if (!pr->a) { HIPCHK(hipEventCreate(&pr->a)); HIPCHK(hipEventCreate(&pr->b)); }
+		pr->pending = false;
+		HIPCHK(hipEventRecord(pr->a, st));
+	}
 	if ((rc = stamp(s, 3, st))) return rc;
 	if (mode == 1) rc = renderFrameFused(s, rowBegin, rowEnd, fb_dev, mask_dev, stream, warm);
 	else {
@@ -804,12 +810,12 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	}
 	if (rc) return rc;
 	if ((rc = stamp(s, 3, st))) return rc;
-	HIPCHK(hipEventRecord(pr.b, st));
-	if (tq) {
+	if (pr) {
+		HIPCHK(hipEventRecord(pr->b, st));
 		// (a cold frame is not a sample: it is slower either way)
-		pr.mode = warm ? mode : -1; pr.queue = (size_t)(tq - s->tileQueues.data()); pr.generation = tq->generation; pr.pending = true;
-		tq->framesSeen++;
+		pr->mode = warm ? mode : -1; pr->queue = (size_t)(tq - s->tileQueues.data()); pr->generation = tq->generation; pr->pending = true;
 	}
+	if (tq) tq->framesSeen++;
 	if (tq) tq->costValid = true;      // (either way the tile costs of this view are now known)
 	s->lastFrameMode = mode;
 	s->lastFrameQueue = tq ? (size_t)(tq - s->tileQueues.data()) : ~(size_t)0;
