@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -285,6 +286,10 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		}
 		// the tree with every other level skipped (rtxd::WideNode), when every box lies inside its parent's
 		std::vector<WideNode> wide;
+		const bool pruneWanted = !getenv("RTX_NO_PRUNE");      // experiment knob (read once, here)
+		std::vector<PruneRec> prune;
+		std::vector<std::array<uint32_t, 4>> slotNode;      // binary node behind every wide-node slot
+		constexpr uint32_t kNoNode = 0xffffffffu;
 		if (boxesRegular && m.n_nodes > 0) {
 			bool nested = true;
 			uint32_t depthMax = 0;
@@ -299,7 +304,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			struct Item { uint32_t node, wideIndex, depth; };
 			std::vector<Item> todo;
 			wide.emplace_back(); memset(&wide[0], 0, sizeof(WideNode));
-			if (isLeaf(0)) { wide[0].slot[0] = nodes[0]; }
+			slotNode.push_back({ { kNoNode, kNoNode, kNoNode, kNoNode } });
+			if (isLeaf(0)) { wide[0].slot[0] = nodes[0]; slotNode[0][0] = 0; }
 			else todo.push_back({ 0u, 0u, 1u });
 			while (!todo.empty() && nested) {
 				const Item it = todo.back(); todo.pop_back();
@@ -318,8 +324,9 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 				// children wide nodes are created in REVERSE so that the vector stays in pre-order when popped; indices are fixed here
 				uint32_t childWide[4] = { 0, 0, 0, 0 };
 				for (int k = 0; k < ns; k++)
-					if (!isLeaf(slots[k])) { childWide[k] = (uint32_t)wide.size(); wide.emplace_back(); memset(&wide.back(), 0, sizeof(WideNode)); }
+					if (!isLeaf(slots[k])) { childWide[k] = (uint32_t)wide.size(); wide.emplace_back(); memset(&wide.back(), 0, sizeof(WideNode)); slotNode.push_back({ { kNoNode, kNoNode, kNoNode, kNoNode } }); }
 				for (int k = ns - 1; k >= 0; k--) {
+					slotNode[it.wideIndex][k] = slots[k];
 					Node sl = nodes[slots[k]];
 					if (!isLeaf(slots[k])) { sl.link = (int32_t)childWide[k] + 1; sl.first = 0; todo.push_back({ slots[k], childWide[k], it.depth + 1 }); }
 					wide[it.wideIndex].slot[k] = sl;
@@ -327,6 +334,58 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			}
 			// the walk's stack holds at most 3 entries per wide level + 4
 			if (!nested || 3 * depthMax + 4 > 60) wide.clear();
+			if (!wide.empty() && pruneWanted) {
+				// Prune records (rtxd::PruneRec): per binary node the true box of the triangles its subtree references and the
+				// largest |e1|_1 |e2|_1 among them (bottom-up over the pre-order array), then one record per wide-node slot.
+				// The triangle as the exact test sees it: v0, v0 + e1, v0 + e2 with the fp32 differences of makeRef (objects.cpp:70-71).
+				struct Agg { double lo[3], hi[3], ps; };
+				std::vector<Agg> agg(m.n_nodes);
+				for (uint32_t i = m.n_nodes; i-- > 0;) {
+					Agg& a = agg[i];
+					for (int k = 0; k < 3; k++) { a.lo[k] = INFINITY; a.hi[k] = -INFINITY; }
+					a.ps = 0;
+					auto merge = [&](const Agg& b) {
+						for (int k = 0; k < 3; k++) { a.lo[k] = std::min(a.lo[k], b.lo[k]); a.hi[k] = std::max(a.hi[k], b.hi[k]); }
+						a.ps = std::max(a.ps, b.ps);
+					};
+					if (!isLeaf(i)) { merge(agg[i + 1]); merge(agg[rightOf(i)]); continue; }
+					const uint32_t begin = (uint32_t)m.leaf_begin[i], count = (uint32_t)m.leaf_count[i];
+					for (uint32_t r = begin; r < begin + count; r++) {
+						RefA ra; RefB rb; RefC rc;
+						makeRef(m, r, ra, rb, rc);
+						const double v0[3] = { ra.v0x, ra.v0y, ra.v0z }, e1[3] = { rb.e1x, rb.e1y, rb.e1z }, e2[3] = { rb.e2x, rc.e2y, rc.e2z };
+						double s1 = 0, s2 = 0;
+						for (int k = 0; k < 3; k++) {
+							const double x1 = v0[k] + e1[k], x2 = v0[k] + e2[k];
+							a.lo[k] = std::min(a.lo[k], std::min(v0[k], std::min(x1, x2)));
+							a.hi[k] = std::max(a.hi[k], std::max(v0[k], std::max(x1, x2)));
+							s1 += std::fabs(e1[k]); s2 += std::fabs(e2[k]);
+						}
+						a.ps = std::max(a.ps, s1 * s2);
+					}
+				}
+				prune.resize(wide.size() * 4);
+				for (size_t wi = 0; wi < wide.size(); wi++)
+					for (int k = 0; k < 4; k++) {
+						PruneRec& pr = prune[wi * 4 + k];
+						memset(&pr, 0, sizeof(pr));
+						pr.h[0] = pr.h[1] = pr.h[2] = -1e30f;      // empty: nothing can meet it
+						const uint32_t nd = slotNode[wi][k];
+						if (nd == kNoNode) continue;
+						const Agg& a = agg[nd];
+						if (!(a.lo[0] <= a.hi[0])) continue;       // no triangles below this slot
+						bool finite = std::isfinite(a.ps);
+						for (int c = 0; c < 3; c++) finite = finite && std::isfinite(a.lo[c]) && std::isfinite(a.hi[c]);
+						if (!finite) { pr.h[0] = pr.h[1] = pr.h[2] = INFINITY; pr.P = INFINITY; continue; }      // never pruned
+						for (int c = 0; c < 3; c++) {
+							const double mid = 0.5 * (a.lo[c] + a.hi[c]), big = std::max(std::fabs(a.lo[c]), std::fabs(a.hi[c]));
+							pr.c[c] = (float)mid;
+							// [c - h, c + h] really contains [lo, hi] (c is rounded, h rounded up)
+							pr.h[c] = (float)((0.5 * (a.hi[c] - a.lo[c]) + std::fabs((double)pr.c[c] - mid)) * (1.0 + 0x1p-20) + 0x1p-24 * big + 1e-37);
+						}
+						pr.P = (float)(a.ps * (1.0 + 0x1p-20) + 1e-37);
+					}
+			}
 		}
 		// leaf references in the reference's order, three parallel arrays padded by one wave
 		std::vector<RefA> refA((size_t)m.n_refs + 64);
@@ -344,6 +403,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		if ((rc = upload(s->owned, nodes.data(), nodes.size(), &dm.nodes))) return bail(rc);
 		if ((rc = upload(s->owned, wide.data(), wide.size(), &dm.wide))) return bail(rc);
 		dm.nWide = (uint32_t)wide.size();
+		if ((rc = upload(s->owned, prune.data(), prune.size(), &dm.prune))) return bail(rc);
 		if ((rc = upload(s->owned, refA.data(), refA.size(), &dm.refA))) return bail(rc);
 		if ((rc = upload(s->owned, refB.data(), refB.size(), &dm.refB))) return bail(rc);
 		if ((rc = upload(s->owned, refC.data(), refC.size(), &dm.refC))) return bail(rc);

@@ -45,6 +45,14 @@ struct RefB { float e1x, e1y, e1z, e2x; };
 struct RefC { float e2y, e2z; };
 static_assert(sizeof(RefA) == 16 && sizeof(RefB) == 16 && sizeof(RefC) == 8, "reference records = dwordx4 + dwordx4 + dwordx2");
 
+// Prune record of one WideNode slot: the TRUE box of every triangle referenced in the slot's subtree, as
+// centre / half-extent, and P = the largest |e1|_1 |e2|_1 among them.  The reference finds a triangle through the loose
+// cell of its leaf (objects.cpp:587-631) but what it ACCEPTS lies near the triangle: with det_c >= 1e-8 (objects.cpp:75-79)
+// the point orig + t_c dir is within 36 u dmax |orig - v0|_inf P / 1e-8 of it, whatever the conditioning.  A slot whose
+// inflated box no ray of the bundle can meet within [0, limit] cannot contribute and is not walked.  h < 0: no triangles.
+struct PruneRec { float c[3]; float P; float h[3]; float pad; };
+static_assert(sizeof(PruneRec) == 32, "prune record = two dwordx4");
+
 struct Mesh {
 	const Node* nodes;
 	const RefA* refA;      // leaf references (see above), n_refs + 64 entries each
@@ -63,6 +71,7 @@ struct Mesh {
 	// lies inside its parent's (nWide = 0 otherwise).
 	const struct WideNode* wide;
 	uint32_t nWide, padw;
+	const PruneRec* prune;   // 4 per wide node (slot order), or null
 	// bundle splitting (rtx_kernels.hip, traceWave): a wave's rays are walked as ONE bundle unless the bundle is wider than
 	// fatRadius at this mesh (a few mean triangle edges); centre / radius = bounding sphere of the root box
 	float fatRadius, centre[3], radius;

@@ -612,6 +612,16 @@ __shared__ LeafEntry leafBatch[4][RTX_LEAF_BATCH];      // per wave of a 256-thr
 // link - 1; link < 0: leaf with ~link references from `first`; mask = the rays that passed the item's own box.
 struct WideItem { int32_t link; uint32_t first, maskLo, maskHi; };
 __shared__ WideItem wideStack[4][64];
+// WIDE walk with prune records (rtxd::PruneRec): what the slot test needs from the wave's bundle, per wave, written once per
+// walk: [0..5] the range of 1 / dir over the rays per axis (lo, hi; mirrored so that it is positive), [6..11] the range of
+// the origins per axis in the same mirrored coordinates (lo, hi), [12] 216 dmax, [13] the largest |origin| coordinate,
+// [14] bits 0-2: axis mirrored, bits 3-5: axis usable (1 / dir of one sign over the wave).
+__shared__ float pruneUni[4][16];
+#ifndef RTX_PRUNE
+#define RTX_PRUNE 1
+#endif
+// 36 u / 1e-8 (u = 2^-24) = 214.6: see pruneSlots
+constexpr float kPruneC = 216.0f;
 // the reference's box test in its min / max form (exact when no NaN can arise, see meshWalk) against a box in SGPRs
 __device__ __forceinline__ bool boxFailsRegular(float blox, float bhix, float bloy, float bhiy, float bloz, float bhiz, const V3& o, float ix, float iy, float iz)
 {
@@ -625,6 +635,47 @@ __device__ __forceinline__ bool boxFailsRegular(float blox, float bhix, float bl
 	asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx), "v"(fy), "v"(fz));
 	return tn > tf;
 }
+// Can the subtree of a wide-node slot contribute to this walk?  r0 / r1 = the slot's rtxd::PruneRec (true box T of its
+// triangles as centre c / half-extent h, P = max |e1|_1 |e2|_1), pu = the wave's pruneUni block, tmaxB = the largest limit
+// of any open ray.  Returns false only when NO ray of the bundle can have a hit accepted by the reference
+// (objects.cpp:59-95) in that subtree with t below its limit:
+//   An accepted hit has det_c >= 1e-8, 0 <= u_c <= 1, 0 <= v_c, u_c + v_c <= 1 (+ one rounding), 0 <= t_c < limit.  With the
+//   identity  det (orig - v0) = -Nt dir + Nu e1 + Nv e2  (Cramer; exact for the fp32 inputs) and the reference's rounding
+//   errors (|det_c - det| <= 5.1 u dmax s1 s2, |Nu_c - Nu| <= 12.2 u dmax ainf s2, |Nv_c - Nv| <= 12.2 u dmax ainf s1,
+//   |Nt_c - Nt| <= 6.1 u ainf s1 s2; s1 = |e1|_1, s2 = |e2|_1, ainf = |orig - v0|_inf, u = 2^-24):
+//       orig + t' dir = v0 + u' e1 + v' e2 + R / det_c,   |R|_inf <= 35.6 u dmax ainf s1 s2,
+//   where t', u', v' are the computed numerators over det_c -- within 2 roundings of t_c, u_c, v_c, so the right-hand point
+//   is in the triangle up to 3 u (s1 + s2).  Hence orig + t' dir lies in T inflated by rho = 36 u dmax ainf P / 1e-8
+//   (det_c >= 1e-8: the bound needs no assumption on the conditioning of the pair -- the reference does accept hits
+//   tenths of a unit off an edge-on triangle; tools/research/rho_check.py), and t' in [0, limit (1 + 3 u)].
+// Here: rho from ainf = the largest distance of any origin of the bundle from T's far side, plus 2^-17 of the coordinate
+// scale for the roundings of this test itself; entry / exit of the inflated box over ALL origins and 1 / dir of the bundle
+// (interval arithmetic, endpoints only: every product is monotone in each factor); alive unless the exit is certainly
+// before the entry, behind the origin, or the entry certainly beyond tmaxB.  NaN compares false -> alive.
+__device__ __forceinline__ bool pruneAlive(const f4v& r0, const f4v& r1, const float* pu, float tmaxB)
+{
+	const f4v ua = *(const f4v*)(pu + 0), ub = *(const f4v*)(pu + 4), uc = *(const f4v*)(pu + 8), ue = *(const f4v*)(pu + 12);
+	const uint32_t fl = __float_as_uint(ue.z);
+	const float cx = (fl & 1u) ? -r0.x : r0.x, cy = (fl & 2u) ? -r0.y : r0.y, cz = (fl & 4u) ? -r0.z : r0.z;
+	// largest |orig - vertex| coordinate over the bundle and the box
+	const float ainf = fmaxf(fmaxf(fmaxf(cx - ub.z, ub.w - cx) + r1.x, fmaxf(cy - uc.x, uc.y - cy) + r1.y), fmaxf(cz - uc.z, uc.w - cz) + r1.z);
+	const float rho = __builtin_fmaf(ue.x * ainf, r0.w, 0x1p-17f * (ainf + ue.y)) * (1.0f + 0x1p-20f) + 1e-30f;
+	const float hx = r1.x + rho, hy = r1.y + rho, hz = r1.z + rho;
+	const float inf = __builtin_inff();
+	// per axis (mirrored so that 1 / dir > 0): entry >= (lo' - o_hi) inv, exit <= (hi' - o_lo) inv over the ranges
+	const float ax = (cx - hx) - ub.w, bx = (cx + hx) - ub.z;
+	const float ay = (cy - hy) - uc.y, by = (cy + hy) - uc.x;
+	const float az = (cz - hz) - uc.w, bz = (cz + hz) - uc.z;
+	float ex = fminf(ax * ua.x, ax * ua.y), fx = fmaxf(bx * ua.x, bx * ua.y);
+	float ey = fminf(ay * ua.z, ay * ua.w), fy = fmaxf(by * ua.z, by * ua.w);
+	float ez = fminf(az * ub.x, az * ub.y), fz = fmaxf(bz * ub.x, bz * ub.y);
+	if (!(fl & 8u)) { ex = -inf; fx = inf; }
+	if (!(fl & 16u)) { ey = -inf; fy = inf; }
+	if (!(fl & 32u)) { ez = -inf; fz = inf; }
+	const float ent = fmaxf(fmaxf(ex, ey), ez), ext = fminf(fminf(fx, fy), fz);
+	return !(ent > ext || ext < 0.0f || ent > tmaxB * (1.0f + 0x1p-18f));
+}
+
 template <bool STATS, bool CULL, bool REGULAR, bool WIDE = false, bool FEWRAYS = false>
 __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
                                          float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
@@ -652,6 +703,33 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 	WideItem* stack = wideStack[threadIdx.x >> 6];
 	const WideNode* wideNodes = WIDE ? uni((const WideNode*)sloadp(&M->wide)) : nullptr;
 	uint32_t sp = 0;
+	const RTX_AS1 char* pruneRecs = nullptr;
+	float* pu = pruneUni[threadIdx.x >> 6];
+	if (WIDE && RTX_PRUNE) {
+		pruneRecs = (const RTX_AS1 char*)(uintptr_t)uni((const PruneRec*)sloadp(&M->prune));
+		if (pruneRecs != nullptr) {
+			// range of 1 / dir over the rays of this walk (finite: WIDE implies REGULAR), and of their origins (the bundle's box)
+			const float inf = __builtin_inff();
+			float hx = consider ? ix : -inf, lx = consider ? ix : inf, hy = consider ? iy : -inf, ly = consider ? iy : inf, hz = consider ? iz : -inf, lz = consider ? iz : inf;
+			waveMaxMin(hx, lx); waveMaxMin(hy, ly); waveMaxMin(hz, lz);
+			if (laneNow() == 0) {
+				const bool nx = hx < 0, ny = hy < 0, nz = hz < 0;
+				const bool okx = lx > 0 || nx, oky = ly > 0 || ny, okz = lz > 0 || nz;
+				f4v a, b, c, e;
+				a.x = nx ? -hx : lx; a.y = nx ? -lx : hx; a.z = ny ? -hy : ly; a.w = ny ? -ly : hy;
+				b.x = nz ? -hz : lz; b.y = nz ? -lz : hz;
+				const float ocx = nx ? -B.ocx : B.ocx, ocy = ny ? -B.ocy : B.ocy, ocz = nz ? -B.ocz : B.ocz;
+				b.z = ocx - B.rox; b.w = ocx + B.rox;
+				c.x = ocy - B.roy; c.y = ocy + B.roy; c.z = ocz - B.roz; c.w = ocz + B.roz;
+				e.x = B.kd * (kPruneC / kFilterK);      // 216 dmax (kd = K dmax, rounded up)
+				e.y = fmaxf(fmaxf(fabsf(B.ocx) + B.rox, fabsf(B.ocy) + B.roy), fabsf(B.ocz) + B.roz);
+				e.z = __uint_as_float((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u) | (okx ? 8u : 0u) | (oky ? 16u : 0u) | (okz ? 32u : 0u));
+				e.w = 0;
+				*(f4v*)(pu + 0) = a; *(f4v*)(pu + 4) = b; *(f4v*)(pu + 8) = c; *(f4v*)(pu + 12) = e;
+			}
+			if (!B.sane) pruneRecs = nullptr;      // NaN / inf / huge coordinates somewhere in the bundle: nothing is pruned
+		}
+	}
 	if (WIDE) {
 		// (the rays in `consider` have passed the root box: traceWave)
 		const uint64_t m0 = ballot(consider);
@@ -699,9 +777,17 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				if (RTX_DBG) cnt.wNodes++;
 				const WideNode* w = wideNodes + (uint32_t)(link - 1);
 				const u32x16 wa = sload16(w), wb = sload16((const char*)w + 64);
+				// Which slots can contribute at all: lane k & 3 looks at slot k & 3 (bits 0..3 of the ballot are used).
+				uint32_t aliveM = 0xfu;
+				if (RTX_PRUNE && pruneRecs != nullptr) {
+					const RTX_AS1 f4v* pr = (const RTX_AS1 f4v*)(pruneRecs + ((((uint32_t)(link - 1) << 2) | (lane & 3u)) << 5));
+					const f4v r0 = pr[0], r1 = pr[1];                  // c.xyz, P | h.xyz, -
+					aliveM = (uint32_t)ballot(pruneAlive(r0, r1, pu, tmaxB)) & 0xfu;
+					if (RTX_DBG) cnt.wLeafSkips += 4u - (uint32_t)__popc(aliveM);
+				}
 				// slots 3..0, so that slot 0 ends up on top of the stack
 #define RTX_SLOT(rec, base, k)                                                                                                     \
-				if ((int32_t)rec[base + 6] != 0) {                                                                                   \
+				if ((int32_t)rec[base + 6] != 0 && ((aliveM >> k) & 1u)) {                                                           \
 					const bool fail = boxFailsRegular(F(rec[base]), F(rec[base + 1]), F(rec[base + 2]), F(rec[base + 3]), F(rec[base + 4]), F(rec[base + 5]), o, ix, iy, iz); \
 					const uint64_t mk_ = ballot(!fail) & inM;                                                                       \
 					if (mk_ != 0) {                                                                                                 \
@@ -711,7 +797,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				}
 				RTX_SLOT(wb, 8, 3) RTX_SLOT(wb, 0, 2) RTX_SLOT(wa, 8, 1)
 				// slot 0 would be popped next: a leaf there is noted right away (no trip through the stack) while the batch has room
-				if ((int32_t)wa[6] != 0) {
+				if ((int32_t)wa[6] != 0 && (aliveM & 1u)) {
 					const bool fail = boxFailsRegular(F(wa[0]), F(wa[1]), F(wa[2]), F(wa[3]), F(wa[4]), F(wa[5]), o, ix, iy, iz);
 					const uint64_t mk_ = ballot(!fail) & inM;
 					if (mk_ != 0) {
