@@ -287,7 +287,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		// the tree with every other level skipped (rtxd::WideNode), when every box lies inside its parent's
 		std::vector<WideNode> wide;
 		const bool pruneWanted = !getenv("RTX_NO_PRUNE");      // experiment knob (read once, here)
-		std::vector<PruneRec> prune;
+		std::vector<PruneBlock> prune;
+		float vmaxMesh = 0;
 		std::vector<std::array<uint32_t, 4>> slotNode;      // binary node behind every wide-node slot
 		constexpr uint32_t kNoNode = 0xffffffffu;
 		if (boxesRegular && m.n_nodes > 0) {
@@ -338,15 +339,19 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 				// Prune records (rtxd::PruneRec): per binary node the true box of the triangles its subtree references and the
 				// largest |e1|_1 |e2|_1 among them (bottom-up over the pre-order array), then one record per wide-node slot.
 				// The triangle as the exact test sees it: v0, v0 + e1, v0 + e2 with the fp32 differences of makeRef (objects.cpp:70-71).
-				struct Agg { double lo[3], hi[3], ps; };
+				struct Agg { double lo[3], hi[3], ps, qlo[3], qhi[3], wlo, whi; bool planes; };
 				std::vector<Agg> agg(m.n_nodes);
 				for (uint32_t i = m.n_nodes; i-- > 0;) {
 					Agg& a = agg[i];
-					for (int k = 0; k < 3; k++) { a.lo[k] = INFINITY; a.hi[k] = -INFINITY; }
-					a.ps = 0;
+					for (int k = 0; k < 3; k++) { a.lo[k] = a.qlo[k] = INFINITY; a.hi[k] = a.qhi[k] = -INFINITY; }
+					a.ps = 0; a.wlo = INFINITY; a.whi = -INFINITY; a.planes = true;
 					auto merge = [&](const Agg& b) {
-						for (int k = 0; k < 3; k++) { a.lo[k] = std::min(a.lo[k], b.lo[k]); a.hi[k] = std::max(a.hi[k], b.hi[k]); }
-						a.ps = std::max(a.ps, b.ps);
+						for (int k = 0; k < 3; k++) {
+							a.lo[k] = std::min(a.lo[k], b.lo[k]); a.hi[k] = std::max(a.hi[k], b.hi[k]);
+							a.qlo[k] = std::min(a.qlo[k], b.qlo[k]); a.qhi[k] = std::max(a.qhi[k], b.qhi[k]);
+						}
+						a.ps = std::max(a.ps, b.ps); a.wlo = std::min(a.wlo, b.wlo); a.whi = std::max(a.whi, b.whi);
+						a.planes = a.planes && b.planes;
 					};
 					if (!isLeaf(i)) { merge(agg[i + 1]); merge(agg[rightOf(i)]); continue; }
 					const uint32_t begin = (uint32_t)m.leaf_begin[i], count = (uint32_t)m.leaf_count[i];
@@ -362,14 +367,26 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 							s1 += std::fabs(e1[k]); s2 += std::fabs(e2[k]);
 						}
 						a.ps = std::max(a.ps, s1 * s2);
+						// scaled plane normal q = (e2 x e1) / (s1 s2) and offset v0 . q.  A triangle with a zero edge can never be
+						// accepted (det_c = 0 exactly) and bounds nothing; one whose scale underflows spoils the slot's plane bound.
+						if (s1 == 0 || s2 == 0) continue;
+						const double sc = s1 * s2;
+						if (!(sc > 1e-30) || !std::isfinite(sc)) { a.planes = false; continue; }
+						const double mq[3] = { (e2[1] * e1[2] - e2[2] * e1[1]) / sc, (e2[2] * e1[0] - e2[0] * e1[2]) / sc, (e2[0] * e1[1] - e2[1] * e1[0]) / sc };
+						double w = 0;
+						for (int k = 0; k < 3; k++) { a.qlo[k] = std::min(a.qlo[k], mq[k]); a.qhi[k] = std::max(a.qhi[k], mq[k]); w += v0[k] * mq[k]; }
+						a.wlo = std::min(a.wlo, w); a.whi = std::max(a.whi, w);
 					}
 				}
-				prune.resize(wide.size() * 4);
+				prune.resize(wide.size());
+				for (int c = 0; c < 3; c++) vmaxMesh = std::max(vmaxMesh, (float)std::max(std::fabs(agg[0].lo[c]), std::fabs(agg[0].hi[c])));
 				for (size_t wi = 0; wi < wide.size(); wi++)
 					for (int k = 0; k < 4; k++) {
-						PruneRec& pr = prune[wi * 4 + k];
-						memset(&pr, 0, sizeof(pr));
+						PruneRec& pr = prune[wi].box[k];
+						PlaneRec& pl = prune[wi].plane[k];
+						memset(&pr, 0, sizeof(pr)); memset(&pl, 0, sizeof(pl));
 						pr.h[0] = pr.h[1] = pr.h[2] = -1e30f;      // empty: nothing can meet it
+						pl.qr[0] = pl.qr[1] = pl.qr[2] = -1.0f;    // no plane bound
 						const uint32_t nd = slotNode[wi][k];
 						if (nd == kNoNode) continue;
 						const Agg& a = agg[nd];
@@ -384,6 +401,14 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 							pr.h[c] = (float)((0.5 * (a.hi[c] - a.lo[c]) + std::fabs((double)pr.c[c] - mid)) * (1.0 + 0x1p-20) + 0x1p-24 * big + 1e-37);
 						}
 						pr.P = (float)(a.ps * (1.0 + 0x1p-20) + 1e-37);
+						if (a.planes && a.wlo <= a.whi && std::isfinite(a.wlo) && std::isfinite(a.whi)) {
+							for (int c = 0; c < 3; c++) {
+								const double mid = 0.5 * (a.qlo[c] + a.qhi[c]);
+								pl.qc[c] = (float)mid;
+								pl.qr[c] = (float)((0.5 * (a.qhi[c] - a.qlo[c]) + std::fabs((double)pl.qc[c] - mid)) * (1.0 + 0x1p-20) + 0x1p-24);
+							}
+							pl.wlo = (float)(a.wlo - (std::fabs(a.wlo) * 0x1p-22 + 1e-37)); pl.whi = (float)(a.whi + (std::fabs(a.whi) * 0x1p-22 + 1e-37));
+						}
 					}
 			}
 		}
@@ -404,6 +429,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		if ((rc = upload(s->owned, wide.data(), wide.size(), &dm.wide))) return bail(rc);
 		dm.nWide = (uint32_t)wide.size();
 		if ((rc = upload(s->owned, prune.data(), prune.size(), &dm.prune))) return bail(rc);
+		dm.vmax = vmaxMesh;
+		if (!(vmaxMesh < 0x1p40f)) dm.prune = nullptr;      // (huge or non-finite coordinates: nothing is pruned)
 		if ((rc = upload(s->owned, refA.data(), refA.size(), &dm.refA))) return bail(rc);
 		if ((rc = upload(s->owned, refB.data(), refB.size(), &dm.refB))) return bail(rc);
 		if ((rc = upload(s->owned, refC.data(), refC.size(), &dm.refC))) return bail(rc);

@@ -52,6 +52,15 @@ static_assert(sizeof(RefA) == 16 && sizeof(RefB) == 16 && sizeof(RefC) == 8, "re
 // inflated box no ray of the bundle can meet within [0, limit] cannot contribute and is not walked.  h < 0: no triangles.
 struct PruneRec { float c[3]; float P; float h[3]; float pad; };
 static_assert(sizeof(PruneRec) == 32, "prune record = two dwordx4");
+// Its companion: box (centre qc, half-extent qr) of the scaled plane normals q = (e2 x e1) / (|e1|_1 |e2|_1) of those triangles
+// (|q|_inf <= 1) and the range [wlo, whi] of their plane offsets v0 . q.  The first stage of the bundle filter -- every ray
+// certainly sees the back / starts beyond the plane / ends before it -- holds for ALL triangles of the slot when it holds for
+// the box (interval arithmetic): det / (s1 s2) = dir . q,  Nt / (s1 s2) = v0 . q - orig . q.   qr < 0: no usable bound.
+struct PlaneRec { float qc[3]; float wlo; float qr[3]; float whi; };
+static_assert(sizeof(PlaneRec) == 32, "plane record = two dwordx4");
+// per wide node: PruneRec[4] then PlaneRec[4] (slot order) = 256 bytes; lane k & 7 of a wave reads record k & 7
+struct PruneBlock { PruneRec box[4]; PlaneRec plane[4]; };
+static_assert(sizeof(PruneBlock) == 256, "prune block");
 
 struct Mesh {
 	const Node* nodes;
@@ -71,7 +80,8 @@ struct Mesh {
 	// lies inside its parent's (nWide = 0 otherwise).
 	const struct WideNode* wide;
 	uint32_t nWide, padw;
-	const PruneRec* prune;   // 4 per wide node (slot order), or null
+	const PruneBlock* prune;   // one per wide node, or null
+	float vmax, padv;          // largest |vertex coordinate| of the mesh
 	// bundle splitting (rtx_kernels.hip, traceWave): a wave's rays are walked as ONE bundle unless the bundle is wider than
 	// fatRadius at this mesh (a few mean triangle edges); centre / radius = bounding sphere of the root box
 	float fatRadius, centre[3], radius;

@@ -676,6 +676,37 @@ __device__ __forceinline__ bool pruneAlive(const f4v& r0, const f4v& r1, const f
 	return !(ent > ext || ext < 0.0f || ent > tmaxB * (1.0f + 0x1p-18f));
 }
 
+#ifndef RTX_PRUNE_PLANES
+#define RTX_PRUNE_PLANES 1
+#endif
+// The first stage of the bundle filter (bundleRejects1) for ALL triangles below a wide-node slot at once.  r0 / r1 = the slot's
+// rtxd::PlaneRec: every triangle's scaled plane normal q = (e2 x e1) / (s1 s2) lies in the box qc +- qr and its plane offset
+// v0 . q in [wlo, whi].  Dividing the filter's inequalities by s1 s2 > 0:
+//     det / (s1 s2) = dir . q,   Nt / (s1 s2) = v0 . q - orig . q,   Ed / (s1 s2) = K dmax,   Et / (s1 s2) = K ainf,
+// so with the range of dir . q and orig . q over the bundle's boxes x the normal box (exact for boxes: centre product +-
+// |centre| radius + radius (|centre| + radius) per axis) the three rejections hold for every triangle when they hold for
+// the ends of the ranges.  eB = K (|orig|_max + |vertex|_max) >= K ainf, and the 64 u it stands for cover the reference's
+// 6.1 u ainf and the ~30 u (|orig| + |vertex|) this evaluation can be off by (w and orig . q are both of coordinate size);
+// kd is doubled for the same reason (5.1 u dmax + ~24 u dmax of evaluation error against 128 u dmax).
+//     (a) max dir . q + 2 kd < 0                                  => det_c < 1e-8 for every triangle and ray (objects.cpp:75-77)
+//     (b) whi - min orig . q + eB < 0                             => t_c < 0                                  (objects.cpp:91)
+//     (c) wlo - max orig . q - eB >= tmaxB (max dir . q + 2 kd) (1 + 2^-18)  => t_c >= every ray's limit      (scene.cpp:740)
+// NaN compares false -> alive; qr < 0 (no bound for this slot) -> alive.
+__device__ __forceinline__ bool planeAlive(const f4v& r0, const f4v& r1, const Bundle& B, float eB, float tmaxB)
+{
+	const float ax = fabsf(r0.x) + r1.x, ay = fabsf(r0.y) + r1.y, az = fabsf(r0.z) + r1.z;      // |qc| + qr
+	const float dqHi = __builtin_fmaf(B.rdz, az, __builtin_fmaf(fabsf(B.dcz), r1.z, __builtin_fmaf(B.dcz, r0.z,
+	                   __builtin_fmaf(B.rdy, ay, __builtin_fmaf(fabsf(B.dcy), r1.y, __builtin_fmaf(B.dcy, r0.y,
+	                   __builtin_fmaf(B.rdx, ax, __builtin_fmaf(fabsf(B.dcx), r1.x, B.dcx * r0.x))))))));
+	const float oqC = __builtin_fmaf(B.ocz, r0.z, __builtin_fmaf(B.ocy, r0.y, B.ocx * r0.x));
+	const float oqR = __builtin_fmaf(B.roz, az, __builtin_fmaf(fabsf(B.ocz), r1.z, __builtin_fmaf(B.roy, ay, __builtin_fmaf(fabsf(B.ocy), r1.y,
+	                  __builtin_fmaf(B.rox, ax, fabsf(B.ocx) * r1.x)))));
+	const float detHi = dqHi + 2.0f * B.kd;
+	const float ntHi = (r1.w - (oqC - oqR)) + eB, ntLo = (r0.w - (oqC + oqR)) - eB;
+	const bool dead = detHi < 0.0f || ntHi < 0.0f || (detHi > 0.0f && ntLo >= tmaxB * (detHi * (1.0f + 0x1p-18f)));
+	return !(dead && r1.x >= 0.0f);
+}
+
 template <bool STATS, bool CULL, bool REGULAR, bool WIDE = false, bool FEWRAYS = false>
 __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
                                          float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
@@ -706,7 +737,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 	const RTX_AS1 char* pruneRecs = nullptr;
 	float* pu = pruneUni[threadIdx.x >> 6];
 	if (WIDE && RTX_PRUNE) {
-		pruneRecs = (const RTX_AS1 char*)(uintptr_t)uni((const PruneRec*)sloadp(&M->prune));
+		pruneRecs = (const RTX_AS1 char*)(uintptr_t)uni((const PruneBlock*)sloadp(&M->prune));
 		if (pruneRecs != nullptr) {
 			// range of 1 / dir over the rays of this walk (finite: WIDE implies REGULAR), and of their origins (the bundle's box)
 			const float inf = __builtin_inff();
@@ -724,7 +755,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				e.x = B.kd * (kPruneC / kFilterK);      // 216 dmax (kd = K dmax, rounded up)
 				e.y = fmaxf(fmaxf(fabsf(B.ocx) + B.rox, fabsf(B.ocy) + B.roy), fabsf(B.ocz) + B.roz);
 				e.z = __uint_as_float((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u) | (okx ? 8u : 0u) | (oky ? 16u : 0u) | (okz ? 32u : 0u));
-				e.w = 0;
+				e.w = kFilterK * (e.y + sloadf(&M->vmax)) * (1.0f + 0x1p-20f) + 1e-30f;      // K (|orig| + |vertex|): see planeAlive
 				*(f4v*)(pu + 0) = a; *(f4v*)(pu + 4) = b; *(f4v*)(pu + 8) = c; *(f4v*)(pu + 12) = e;
 			}
 			if (!B.sane) pruneRecs = nullptr;      // NaN / inf / huge coordinates somewhere in the bundle: nothing is pruned
@@ -780,9 +811,17 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				// Which slots can contribute at all: lane k & 3 looks at slot k & 3 (bits 0..3 of the ballot are used).
 				uint32_t aliveM = 0xfu;
 				if (RTX_PRUNE && pruneRecs != nullptr) {
-					const RTX_AS1 f4v* pr = (const RTX_AS1 f4v*)(pruneRecs + ((((uint32_t)(link - 1) << 2) | (lane & 3u)) << 5));
-					const f4v r0 = pr[0], r1 = pr[1];                  // c.xyz, P | h.xyz, -
-					aliveM = (uint32_t)ballot(pruneAlive(r0, r1, pu, tmaxB)) & 0xfu;
+					// lanes 0..3: the slots' boxes (PruneRec), lanes 4..7: their planes (PlaneRec); both tests run on every lane's record
+					const RTX_AS1 f4v* pr = (const RTX_AS1 f4v*)(pruneRecs + ((((uint32_t)(link - 1) << 3) | (lane & 7u)) << 5));
+					const f4v r0 = pr[0], r1 = pr[1];
+					const bool aliveBox = pruneAlive(r0, r1, pu, tmaxB);
+#if RTX_PRUNE_PLANES
+					const bool alivePlane = planeAlive(r0, r1, B, pu[15], tmaxB);
+					const uint32_t bal = (uint32_t)ballot((lane & 4u) ? alivePlane : aliveBox);
+					aliveM = bal & (bal >> 4) & 0xfu;
+#else
+					aliveM = (uint32_t)ballot(aliveBox) & 0xfu;
+#endif
 					if (RTX_DBG) cnt.wLeafSkips += 4u - (uint32_t)__popc(aliveM);
 				}
 				// slots 3..0, so that slot 0 ends up on top of the stack

@@ -91,6 +91,16 @@ def main():
             rho = np.where(c > KAPPA * dmax, 36 * u * dmax * ainf / (c - 6 * u * dmax), np.inf)
         return rho
 
+    def cert_rho_bundle(o, d, i):
+        d64 = d.astype(np.float64); o6 = o.astype(np.float64)
+        dlo, dhi = d64.min(0), d64.max(0)
+        c = np.minimum(np.minimum(dlo * qlo[i], dlo * qhi[i]), np.minimum(dhi * qlo[i], dhi * qhi[i])).sum()
+        dmax = np.abs(d64).max()
+        ainf = np.maximum(np.abs(o6.min(0) - thi[i]), np.abs(o6.max(0) - tlo[i])).max()
+        u = 2.0 ** -24
+        r = 36 * u * dmax * ainf / (c - 6 * u * dmax) if c > 2.0 ** -16 * dmax else np.inf
+        return np.full(len(o), r)
+
     def seg_box_rho(o, inv, lim, blo, bhi, rho):
         with np.errstate(all="ignore"):
             t0 = (blo[None] - rho[:, None] - o) * inv; t1 = (bhi[None] + rho[:, None] - o) * inv
@@ -114,7 +124,7 @@ def main():
         ainf = np.maximum(np.abs(o6.min(0) - thi[i]), np.abs(o6.max(0) - tlo[i])).max()
         return np.full(len(o), 212.0 * 1.05 * dmax * ainf * PS[i] + 2.0 ** -18 * (np.abs(o6).max() + max(np.abs(tlo[i]).max(), np.abs(thi[i]).max())))
 
-    modes = ["today", "plane", "both", "unc", "unc_plane"]
+    modes = ["today", "plane", "both", "unc", "unc_plane", "mix", "mix_plane"]
     tot = {mo: dict(nodes=0, leaves=0, refs=0, passes=0, wide=0) for mo in modes}
     ntr = [0]
     mism = [0]
@@ -141,7 +151,7 @@ def main():
                 nodes += 1
                 if not p.any():
                     continue
-                if mo in ("plane", "both", "bothc", "bothc_ord", "unc_plane") and plane_dead(o[open_], d[open_], best[open_].max(), i):
+                if mo in ("plane", "both", "bothc", "bothc_ord", "unc_plane", "mix_plane") and plane_dead(o[open_], d[open_], best[open_].max(), i):
                     continue
                 if mo in ("tbox", "both") and np.isfinite(tlo[i]).all():
                     if not seg_box(o64[open_], inv[open_], best[open_], tlo[i], thi[i], float(os.environ.get('MARGIN','1e-3'))).any():
@@ -150,8 +160,10 @@ def main():
                     rho = cert_rho(o[open_], d[open_], i)
                     if not seg_box_rho(o64[open_], inv[open_], best[open_], tlo[i], thi[i], rho).any():
                         continue
-                if mo in ("unc", "unc_plane") and np.isfinite(tlo[i]).all():
+                if mo in ("unc", "unc_plane", "mix", "mix_plane") and np.isfinite(tlo[i]).all():
                     rho = unc_rho(o[open_], d[open_], i)
+                    if mo.startswith("mix"):
+                        rho = np.minimum(rho, cert_rho_bundle(o[open_], d[open_], i))
                     if not seg_box_rho(o64[open_], inv[open_], np.full(int(open_.sum()), best[open_].max()), tlo[i], thi[i], rho).any():
                         continue
                 if is_leaf[i]:
