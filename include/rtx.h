@@ -147,8 +147,12 @@ int rtx_render_pass1(rtx_scene* scene, uint32_t row_begin, uint32_t row_end, flo
  * (scene.cpp:444-568: renderWorker, the Sobel pass and SSAAworker of Scene::render), with the three stages
  * overlapped on the device through per-tile dependencies instead of separated by launch boundaries.
  * mask_dev rows [row_begin, row_end) are written completely (0 for rows owned by another part).
- * Asynchronous on `stream`; rtx_frame_status synchronises and reports a frame kernel that gave up
- * (status != 0 -- a bug guard, see rtx_kernels.hip).
+ * Asynchronous on `stream`.  The single launch can give up (its SSAA item queues overflow, or its watchdog fires): the
+ * frame is then incomplete, which Scene::render (scene.cpp:595-606) can never deliver.  rtx_frame_status is the
+ * host's synchronisation point for a frame: it waits for the device, and if the last single launch gave up it renders
+ * that frame AGAIN through the three launches into the same buffers and keeps the view on three launches; status = 0
+ * (frame complete as rendered) or error | 0x100 (frame complete after the re-render; error 1: queue entry never
+ * written, 2: work never completed, 3: item queue overflow).  Callers that consume a frame call it first.
  * Whether the single launch or the three launches are faster depends on the view (slowest tile against total work);
  * rtx_render_frame measures both on the first warm frames of a view and keeps the faster (environment
  * RTX_FRAME_MODE=fused|split forces one).  rtx_frame_mode: what the last call used (0 three launches, 1 one launch)
@@ -158,6 +162,11 @@ int rtx_render_frame(rtx_scene* scene, uint32_t row_begin, uint32_t row_end, flo
 int rtx_frame_status(rtx_scene* scene, uint32_t* status);
 int rtx_frame_mode(rtx_scene* scene, int* mode, float* split_ms, float* fused_ms);
 int rtx_set_frame_mode(rtx_scene* scene, int mode); /* -1 measure and choose (default), 0 always three launches, 1 always one */
+/* Experiment / test knobs of a live scene.  Their environment variables (RTX_STRIP_LIMIT, RTX_SSAA_HEAVY_TICKS,
+ * RTX_SSAA_SPREAD_SLOTS, RTX_SPLIT_PERCENT, RTX_SSAA_LOCAL_BELOW, RTX_FRAME_QUEUE_CAP, RTX_DEBUG_ITEMS, ...) are read
+ * once, by rtx_scene_create; names here: strip_limit, ssaa_heavy_ticks, ssaa_spread_slots, split_percent,
+ * ssaa_local_below, frame_queue_cap, debug_items.  No knob changes a pixel. */
+int rtx_set_knob(rtx_scene* scene, const char* name, double value);
 
 /* Sobel edge mask of Scene::launchSSAA (scene.cpp:547-568) for rows [row_begin,row_end); reads the
  * 3x3 neighbourhood from fb_dev; border entries (row 0, H-1, column 0, W-1) are written as 0. */

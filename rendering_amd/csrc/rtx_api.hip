@@ -70,9 +70,27 @@ void makeRef(const rtx_mesh& m, uint32_t ref, RefA& a, RefB& b, RefC& c)
 
 } // namespace
 
+// Experiment / test knobs.  Their environment variables are read ONCE, by rtx_scene_create (never on the per-frame path);
+// rtx_set_knob changes one of a live scene.
+struct Knobs {
+	int pass1BlocksPerCU = 0, ssaaBlocksPerCU = 0, frameBlocksPerCU = 0;   // RTX_*_BLOCKS_PER_CU: 0 = what the occupancy allows
+	bool prune = true;                   // RTX_NO_PRUNE: no prune records (rtxd::PruneBlock)
+	float fatFactor = 3.0f;              // RTX_FAT_FACTOR: bundle width, in mean triangle edges, above which a bundle is split; 0 = never
+	uint32_t stripLimit = 100000u;       // RTX_STRIP_LIMIT: a halo strip slower than this (100 MHz ticks) is listed as tiles again
+	uint32_t heavyTicks = 25000u;        // RTX_SSAA_HEAVY_TICKS: tiles above go first in the SSAA list
+	uint32_t spreadSlots = 1u << 20;     // RTX_SSAA_SPREAD_SLOTS: slot budget of the 4-pixel SSAA waves
+	uint32_t splitPercent = 100;         // RTX_SPLIT_PERCENT: frame kernel, tile split limit in % of the even share; 0 = never
+	long long localBelow = -1;           // RTX_SSAA_LOCAL_BELOW: tile-local SSAA list below this many flagged pixels; -1 = by device size
+	int frameMode = -1;                  // RTX_FRAME_MODE=split|fused
+	uint32_t frameQueueCap = 0;          // RTX_FRAME_QUEUE_CAP: entries per SSAA item queue of the frame kernel; 0 = sized from the frame
+	bool debugItems = false;             // RTX_DEBUG_ITEMS: rtx_counters_read prints the wave-level counters
+	uint32_t dbgTile = 0;                // RTX_DBG_TILE=tx,ty (RTX_DBG builds): only this tile
+};
+
 struct rtx_scene {
 	int device = 0;
 	int numCUs = 0;
+	Knobs knobs;
 	std::vector<void*> owned;     // device allocations freed on destroy
 	size_t sceneBytes = 0;        // bytes of scene data resident in HBM (nodes, leaf references, shading arrays, maps, skybox)
 	Params params;                // template of the kernel argument block
@@ -104,7 +122,12 @@ struct rtx_scene {
 		float frameMs[2] = { -1.f, -1.f };
 		uint32_t frameSamples[2] = { 0, 0 };
 		uint32_t framesSeen = 0, generation = 0;
+		bool fusedGaveUp = false;         // the single launch once ended with an error for this view: three launches from then on
 	};
+	// the last frame rendered in one launch (rtx_frame_status renders it again in three if the launch gave up)
+	struct LastFused { bool valid = false; uint32_t rowBegin = 0, rowEnd = 0; float* fb = nullptr; uint8_t* mask = nullptr; void* stream = nullptr; size_t queue = ~(size_t)0; uint32_t generation = 0; };
+	LastFused lastFused;
+	uint32_t framesRecovered = 0;
 	// rtx_render_frame: event pairs around the last few frames, read back (without waiting) by later calls
 	struct FrameProbe { hipEvent_t a = nullptr, b = nullptr; int mode = -1; size_t queue = 0; uint32_t generation = 0; bool pending = false; };
 	FrameProbe probes[8];
@@ -124,6 +147,23 @@ struct rtx_scene {
 };
 
 namespace {
+
+void readKnobs(Knobs& k)
+{
+	auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? strtoll(e, nullptr, 10) : dflt; };
+	k.pass1BlocksPerCU = (int)num("RTX_PASS1_BLOCKS_PER_CU", 0); k.ssaaBlocksPerCU = (int)num("RTX_SSAA_BLOCKS_PER_CU", 0); k.frameBlocksPerCU = (int)num("RTX_FRAME_BLOCKS_PER_CU", 0);
+	k.prune = !getenv("RTX_NO_PRUNE");
+	if (const char* e = getenv("RTX_FAT_FACTOR")) k.fatFactor = strtof(e, nullptr);
+	k.stripLimit = (uint32_t)num("RTX_STRIP_LIMIT", k.stripLimit);
+	k.heavyTicks = (uint32_t)num("RTX_SSAA_HEAVY_TICKS", k.heavyTicks);
+	k.spreadSlots = (uint32_t)std::min<long long>(num("RTX_SSAA_SPREAD_SLOTS", k.spreadSlots), 1ll << 20);
+	k.splitPercent = (uint32_t)num("RTX_SPLIT_PERCENT", k.splitPercent);
+	k.localBelow = num("RTX_SSAA_LOCAL_BELOW", -1);
+	if (const char* e = getenv("RTX_FRAME_MODE")) k.frameMode = !strcmp(e, "split") ? 0 : (!strcmp(e, "fused") ? 1 : -1);
+	k.frameQueueCap = (uint32_t)num("RTX_FRAME_QUEUE_CAP", 0);
+	k.debugItems = getenv("RTX_DEBUG_ITEMS") != nullptr;
+	if (const char* e = getenv("RTX_DBG_TILE")) { unsigned tx = 0, ty = 0; if (sscanf(e, "%u,%u", &tx, &ty) == 2) k.dbgTile = ((ty << 16) | tx) + 1; }
+}
 
 int setView(rtx_scene* s, const rtx_view* v)
 {
@@ -156,16 +196,16 @@ int ensureWork(rtx_scene* s)
 		int b = 0;
 		HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxPass1Kernel<false>, 256, 0));
 		if (b < 1) b = 1;
-		if (const char* e = getenv("RTX_PASS1_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < b) b = v; }      // experiment knob
+		if (s->knobs.pass1BlocksPerCU >= 1 && s->knobs.pass1BlocksPerCU < b) b = s->knobs.pass1BlocksPerCU;
 		s->blocksPass1 = b * s->numCUs;
 		HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxSsaaKernel<false>, 256, 0));
 		if (b < 1) b = 1;
-		if (const char* e = getenv("RTX_SSAA_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < b) b = v; }
+		if (s->knobs.ssaaBlocksPerCU >= 1 && s->knobs.ssaaBlocksPerCU < b) b = s->knobs.ssaaBlocksPerCU;
 		s->blocksSsaa = b * s->numCUs;
 		if (s->analytic) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxFrameKernel<false>, 256, 0));
 		else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxFrameKernel<true>, 256, 0));
 		if (b < 1) b = 1;
-		if (const char* e = getenv("RTX_FRAME_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < b) b = v; }
+		if (s->knobs.frameBlocksPerCU >= 1 && s->knobs.frameBlocksPerCU < b) b = s->knobs.frameBlocksPerCU;
 		s->blocksFrame = b * s->numCUs;
 	}
 	const int blocks = std::max(s->blocksFrame, s->blocksPass1 > s->blocksSsaa ? s->blocksPass1 : s->blocksSsaa);
@@ -253,6 +293,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 	HIPCHK(hipGetDeviceProperties(&prop, device));
 
 	rtx_scene* s = new rtx_scene;
+	readKnobs(s->knobs);
 	s->tileQueues.reserve(16);
 	gUploadedBytes = 0;
 	s->device = device;
@@ -286,7 +327,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		}
 		// the tree with every other level skipped (rtxd::WideNode), when every box lies inside its parent's
 		std::vector<WideNode> wide;
-		const bool pruneWanted = !getenv("RTX_NO_PRUNE");      // experiment knob (read once, here)
+		const bool pruneWanted = s->knobs.prune;
 		std::vector<PruneBlock> prune;
 		float vmaxMesh = 0;
 		std::vector<std::array<uint32_t, 4>> slotNode;      // binary node behind every wide-node slot
@@ -451,8 +492,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 				const double l2 = std::sqrt((double)b.e2x * b.e2x + (double)c.e2y * c.e2y + (double)c.e2z * c.e2z);
 				if (std::isfinite(l1 + l2)) { sum += l1 + l2; cnt += 2; }
 			}
-			float factor = 3.0f;
-			if (const char* e = getenv("RTX_FAT_FACTOR")) factor = strtof(e, nullptr);       // tuning knob; 0 = never split
+			const float factor = s->knobs.fatFactor;
 			dm.fatRadius = cnt && factor > 0 ? (float)(sum / (double)cnt) * factor : INFINITY;
 			double rad = 0;
 			for (int c = 0; c < 3; c++) {
@@ -575,6 +615,10 @@ void meshTileRect(const rtx_scene* s, uint32_t tilesX, uint32_t tilesYFull, uint
 	}
 }
 
+// A strip entry is 0x10000000 | strip << 16 | y: it needs y < 2^15, strip < 2^12, and plain entries (ty << 16 | tx) that never
+// set bit 28, i.e. tile rows below 4096.  Larger frames are listed as tiles only and the kernels are told so (Params::stripBit).
+bool stripsFit(const View& v) { return v.height <= 32768u && v.width <= 262144u; }
+
 // The eight per-XCD queues of one pass-1 launch.  Only tiles with a row this launch renders are listed.
 // strips (the three-launch path): a tile row of which this launch renders a single pixel row -- the halo row of a band
 // that belongs to another device -- is listed as 64 x 1 pixel strips (0x10000000 | strip << 16 | y) instead of 8 x 8
@@ -583,7 +627,7 @@ void meshTileRect(const rtx_scene* s, uint32_t tilesX, uint32_t tilesYFull, uint
 int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t tilesX, uint32_t tileRow0, uint32_t tilesY, rtx_scene::TileQueues** out, bool strips = false)
 {
 	const Params& p = s->params;
-	if (p.view.height > 32768u || p.view.width > 262144u) strips = false;
+	if (!stripsFit(p.view)) strips = false;
 	std::vector<uint32_t> key = { rowBegin, lastRow, tilesX, p.bandH, p.nParts, p.part, p.halo, p.view.width, p.view.height, strips ? 1u : 0u };
 	for (int i = 0; i < 16; i++) { uint32_t w; memcpy(&w, &p.view.camM[i], 4); key.push_back(w); }
 	for (int i = 0; i < 3; i++) { uint32_t w; memcpy(&w, &p.view.camPos[i], 4); key.push_back(w); }
@@ -597,7 +641,7 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 	rtx_scene::TileQueues* e = &s->tileQueues[0];
 	for (auto& q : s->tileQueues) { if (!q.list) { e = &q; break; } if (q.lastUse < e->lastUse) e = &q; }
 	e->costValid = false; e->key.clear();
-	e->frameMs[0] = e->frameMs[1] = -1.f; e->frameSamples[0] = e->frameSamples[1] = 0; e->framesSeen = 0; e->generation++;
+	e->frameMs[0] = e->frameMs[1] = -1.f; e->frameSamples[0] = e->frameSamples[1] = 0; e->framesSeen = 0; e->generation++; e->fusedGaveUp = false;
 	const uint32_t H = p.view.height;
 	auto rowOwnedH = [&](uint32_t y) { return p.bandH == 0 || (y / p.bandH) % p.nParts == p.part; };
 	auto rowRenderedH = [&](uint32_t y) {
@@ -679,23 +723,23 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	p.nTiles = p.tilesX * tilesY;
 	p.tilesY = tilesY;
 #if RTX_DBG
-	if (const char* e = getenv("RTX_DBG_TILE")) { unsigned tx = 0, ty = 0; if (sscanf(e, "%u,%u", &tx, &ty) == 2) p.pad3 = ((ty << 16) | tx) + 1; }
+	p.pad3 = s->knobs.dbgTile;
 #endif
 	p.workCounter = s->work + 128;            // eight per-XCD queue heads, 64 bytes apart
 	if (p.view.width > 0x7fff8u || p.view.height > 0x7fff8u) return fail(RTX_ERR_ARG, "frame too large");
 	rtx_scene::TileQueues* tq = nullptr;
 	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY, &tq, true))) return rc;
 	p.tileList = tq->list;
+	p.stripBit = stripsFit(p.view) ? 0x10000000u : 0u;
 	if (tq->costValid) {
 		// the previous launch rendered exactly these tiles from this view: start with the ones that were expensive
-		uint32_t stripLimit = 100000u;
-		if (const char* e = getenv("RTX_STRIP_LIMIT")) stripLimit = (uint32_t)strtoul(e, nullptr, 10);      // experiment knob (100 MHz ticks)
+		const uint32_t stripLimit = s->knobs.stripLimit;
 		// (a strip of a halo row that took more than 1 ms is listed as its tiles again: rtxTileOrderKernel)
 		const unsigned pieces = tq->listed > 16384u ? 32u : 1u;      // (short queues: one block each, one launch)
 		if (pieces > 1) hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
-		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit);
+		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit, (uint32_t*)nullptr, p.stripBit);
 		hipLaunchKernelGGL(rtxTileOrderKernel<true>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
-		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit, s->work + 128);      // (also zeroes the queue heads)
+		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit, s->work + 128, p.stripBit);      // (also zeroes the queue heads)
 		p.tileList = tq->list + tq->cap;
 	}
 	else HIPCHK(hipMemsetAsync(s->work + 128, 0, 128 * sizeof(uint32_t), st));
@@ -731,8 +775,8 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	// the mask of the rows is defined everywhere: 0 where no tile computes it (rows of other parts, the last row / column)
 	const size_t maskBytes = (size_t)(rowEnd - rowBegin) * W;
 	const bool maskInClear = maskBytes <= (4u << 20);      // (a small frame: cleared by rtxFrameClearKernel below)
-	if (!maskInClear) HIPCHK(hipMemsetAsync(mask_dev + (size_t)rowBegin * W, 0, maskBytes, st));
 	const uint32_t lastRow = (rowEnd < H - 1 ? rowEnd : H - 1);   // exclusive; row H-1 is never rendered
+	if (!maskInClear || lastRow <= rowBegin) HIPCHK(hipMemsetAsync(mask_dev + (size_t)rowBegin * W, 0, maskBytes, st));
 	if (lastRow <= rowBegin) return RTX_OK;
 	const uint32_t tilesY = (lastRow + 7) / 8 - p.tileRow0;
 	p.nTiles = p.tilesX * tilesY;
@@ -753,9 +797,9 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	}
 	// 64 queues; in all up to 4 items per tile (16 flagged pixels each) plus the budget of extra items for tiles that get
 	// 4-pixel items.  The items are dealt round the queues, so each holds about 1/64 of them: twice that, and some.
-	const size_t perQueue = 2 * ((4 * tiles + kSsaaSpreadSlots / 16) / 64) + 256;
+	const size_t perQueue = s->knobs.frameQueueCap ? s->knobs.frameQueueCap : 2 * ((4 * tiles + kSsaaSpreadSlots / 16) / 64) + 256;
 	if (tiles >= (1u << 24)) return fail(RTX_ERR_ARG, "frame too large for rtx_render_frame");
-	if (64 * perQueue > s->queueCap) {
+	if (64 * perQueue != s->queueCap) {
 		HIPCHK(hipDeviceSynchronize());
 		if (s->ssaaQueue) HIPCHK(hipFree(s->ssaaQueue));
 		s->ssaaQueue = nullptr; s->queueCap = 0;
@@ -791,9 +835,8 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	p.ssaaQueue = s->ssaaQueue; p.frameCtl = s->frameCtl;
 	p.listedTiles = tq->listed; p.epoch = s->epoch; p.queueCap = (uint32_t)perQueue; p.veryBudget = kSsaaSpreadSlots / 16;
 	p.countExpect = tq->countExpect;
-	p.heavyTicks = 25000u;
-	if (const char* e = getenv("RTX_SSAA_HEAVY_TICKS")) p.heavyTicks = (uint32_t)strtoul(e, nullptr, 10);       // test knobs
-	if (const char* e = getenv("RTX_SSAA_SPREAD_SLOTS")) p.veryBudget = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), kSsaaSpreadSlots) / 16;
+	p.heavyTicks = s->knobs.heavyTicks;
+	p.veryBudget = s->knobs.spreadSlots / 16;
 	{
 		const size_t most = std::max<size_t>(4 * tiles, maskInClear ? maskBytes : 0);
 		hipLaunchKernelGGL(rtxFrameClearKernel, dim3((unsigned)std::min<size_t>((most + 255) / 256, 2048)), dim3(256), 0, st, s->work, s->tileDeps, 4 * tiles,
@@ -806,8 +849,7 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	if (ordered) {
 		// the previous launch rendered exactly these tiles from this view: start with the ones that were expensive
 		hipLaunchKernelGGL(rtxTileClassKernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, s->tileCost, p.tilesXFull, p.tilesYFull, s->tileClass, (unsigned long long*)(s->work + 16));
-		uint32_t splitPercent = 100, splitFloor = 2000u;            // floor: 20 us (100 MHz)
-		if (const char* e = getenv("RTX_SPLIT_PERCENT")) splitPercent = (uint32_t)strtoul(e, nullptr, 10);       // experiment knob; 0 = never
+		const uint32_t splitPercent = s->knobs.splitPercent, splitFloor = 2000u;            // floor: 20 us (100 MHz)
 		const unsigned pieces = tq->listed > 16384u ? 32u : 1u;      // (short queues: one block each, one launch)
 		if (pieces > 1) hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)s->tileClass,
 		                   (const unsigned long long*)(s->work + 16), (uint32_t)s->blocksFrame * 4u, splitPercent, splitFloor, s->work + 18);
@@ -825,6 +867,20 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	HIPCHK(hipGetLastError());
 	if ((rc = stamp(s, 4, st))) return rc;
 	return RTX_OK;
+}
+
+// The frame in three launches.  The mask of the rows is defined everywhere, as in the single launch: rtx_sobel leaves the rows
+// of other parts alone, so under row ownership they are zeroed first.
+static int renderFrameSplit(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, uint8_t* mask_dev, void* stream)
+{
+	const uint32_t W = s->params.view.width, H = s->params.view.height;
+	if (rowEnd > H) rowEnd = H;
+	if (rowBegin >= rowEnd) return RTX_OK;
+	if (s->params.bandH) HIPCHK(hipMemsetAsync(mask_dev + (size_t)rowBegin * W, 0, (size_t)(rowEnd - rowBegin) * W, (hipStream_t)stream));
+	int rc = rtx_render_pass1(s, rowBegin, rowEnd, fb_dev, stream);
+	if (!rc) rc = rtx_sobel(s, fb_dev, rowBegin, rowEnd, mask_dev, stream);
+	if (!rc) rc = rtx_render_ssaa(s, mask_dev, rowBegin, rowEnd, fb_dev, stream);
+	return rc;
 }
 
 // One launch or three?  The single launch overlaps the stages and splits the slowest tiles -- it wins when the frame is
@@ -866,11 +922,10 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	}
 	(void)hipGetLastError();
 	int mode;
-	static const int envForced = [] { const char* e = getenv("RTX_FRAME_MODE"); return !e ? -1 : (!strcmp(e, "split") ? 0 : (!strcmp(e, "fused") ? 1 : -1)); }();
-	const int forced = s->frameModeForced >= 0 ? s->frameModeForced : envForced;
+	const int forced = s->frameModeForced >= 0 ? s->frameModeForced : s->knobs.frameMode;
 	const bool warm = tq && tq->costValid;
 	if (forced >= 0) mode = forced;
-	else if (!tq) mode = 0;
+	else if (!tq || tq->fusedGaveUp) mode = 0;
 	else if (!warm) mode = tq->listed <= 65536u ? 1 : 0;       // no costs yet (nothing can be split or ordered): by size
 	// not measured twice each yet: in turn
 	else if (tq->frameSamples[0] < 2 || tq->frameSamples[1] < 2) mode = (int)(tq->framesSeen & 1u);
@@ -889,13 +944,13 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 		HIPCHK(hipEventRecord(pr->a, st));
 	}
 	if ((rc = stamp(s, 3, st))) return rc;
-	if (mode == 1) rc = renderFrameFused(s, rowBegin, rowEnd, fb_dev, mask_dev, stream, warm);
-	else {
-		rc = rtx_render_pass1(s, rowBegin, rowEnd, fb_dev, stream);
-		if (!rc) rc = rtx_sobel(s, fb_dev, rowBegin, rowEnd, mask_dev, stream);
-		if (!rc) rc = rtx_render_ssaa(s, mask_dev, rowBegin, rowEnd, fb_dev, stream);
+	if (mode == 1) {
+		rc = renderFrameFused(s, rowBegin, rowEnd, fb_dev, mask_dev, stream, warm);
+		// what rtx_frame_status needs to render the frame again should the single launch have given up
+		s->lastFused = { true, rowBegin, rowEnd, fb_dev, mask_dev, stream, tq ? (size_t)(tq - s->tileQueues.data()) : ~(size_t)0, tq ? tq->generation : 0u };
 	}
-	if (rc) return rc;
+	else rc = renderFrameSplit(s, rowBegin, rowEnd, fb_dev, mask_dev, stream);
+	if (rc) { if (s->evUsed[3] & 1) s->evUsed[3]--; return rc; }      // (the open event pair is dropped with the frame)
 	if ((rc = stamp(s, 3, st))) return rc;
 	if (pr) {
 		HIPCHK(hipEventRecord(pr->b, st));
@@ -906,6 +961,22 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	if (tq) tq->costValid = true;      // (either way the tile costs of this view are now known)
 	s->lastFrameMode = mode;
 	s->lastFrameQueue = tq ? (size_t)(tq - s->tileQueues.data()) : ~(size_t)0;
+	return RTX_OK;
+}
+
+int rtx_set_knob(rtx_scene* s, const char* name, double value)
+{
+	if (!s || !name) return fail(RTX_ERR_ARG, "scene/name is NULL");
+	Knobs& k = s->knobs;
+	const std::string n = name;
+	if (n == "strip_limit") k.stripLimit = (uint32_t)value;
+	else if (n == "ssaa_heavy_ticks") k.heavyTicks = (uint32_t)value;
+	else if (n == "ssaa_spread_slots") k.spreadSlots = (uint32_t)std::min(value, (double)kSsaaSpreadSlots);
+	else if (n == "split_percent") k.splitPercent = (uint32_t)value;
+	else if (n == "ssaa_local_below") k.localBelow = (long long)value;
+	else if (n == "frame_queue_cap") k.frameQueueCap = (uint32_t)value;
+	else if (n == "debug_items") k.debugItems = value != 0;
+	else return fail(RTX_ERR_ARG, "unknown knob: " + n);
 	return RTX_OK;
 }
 
@@ -951,7 +1022,20 @@ int rtx_frame_status(rtx_scene* s, uint32_t* status)
 	if (earlier) HIPCHK(hipMemset(s->work + 24, 0, sizeof(uint32_t)));
 	if (!err) err = earlier;
 	*status = err;
-	if (err) return fail(RTX_ERR_DEVICE, "rtx_render_frame: the frame kernel gave up (1: queue entry never written, 2: work never completed, 3: SSAA queue overflow)");
+	if (!err) return RTX_OK;
+	// The single launch gave up (1: queue entry never written, 2: work never completed, 3: SSAA queue overflow): its frame is
+	// incomplete.  The reference's Scene::render cannot deliver a partial frame (scene.cpp:595-606), so the frame is rendered
+	// again here, in three launches, into the same buffers, and the view stays with three launches.  status = the error | 0x100.
+	HIPCHK(hipMemset((uint32_t*)s->frameCtl + FC_ERROR, 0, sizeof(uint32_t)));
+	const rtx_scene::LastFused lf = s->lastFused;
+	s->lastFused.valid = false;
+	if (lf.queue < s->tileQueues.size() && s->tileQueues[lf.queue].generation == lf.generation) s->tileQueues[lf.queue].fusedGaveUp = true;
+	if (!lf.valid) return fail(RTX_ERR_DEVICE, "rtx_render_frame: the frame kernel gave up and the frame is not known any more");
+	int rc = renderFrameSplit(s, lf.rowBegin, lf.rowEnd, lf.fb, lf.mask, lf.stream);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize((hipStream_t)lf.stream));
+	s->framesRecovered++;
+	*status = err | 0x100u;
 	return RTX_OK;
 }
 
@@ -984,6 +1068,7 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	hipStream_t st = (hipStream_t)stream;
 	// (work[1], the queue head, and work[10], the slot budget used, are zeroed by rtxSsaaScatterKernel; [8], [9]: the layout
 	// decision and its count, see below)
+	if ((uint32_t)s->tileCap < s->params.tilesXFull * ((H + 7) / 8) || W > 0xffffu || H > 0xffffu) return fail(RTX_ERR_ARG, "frame too large for the SSAA pixel list");
 	if ((rc = stamp(s, 2, st))) return rc;
 	Params p = s->params;
 	p.fb = fb_dev;
@@ -996,15 +1081,13 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	p.ssaaPixels = s->ssaaPixels;
 	if (p.nTiles == 0 || p.view.width > 0xffffu || p.view.height > 0xffffu) return fail(RTX_ERR_ARG, "frame too large for the SSAA pixel list");
 	// flagged pixels -> one packed list; tiles on which pass 1 spent more than 0.25 ms go first (wall clock = 100 MHz)
-	uint32_t heavyTicks = 25000u, spreadSlots = kSsaaSpreadSlots;
+	const uint32_t heavyTicks = s->knobs.heavyTicks, spreadSlots = s->knobs.spreadSlots;
 	const uint32_t scanN = 2 * p.nTiles + 1;
-	if (const char* e = getenv("RTX_SSAA_HEAVY_TICKS")) heavyTicks = (uint32_t)strtoul(e, nullptr, 10);       // test knobs
-	if (const char* e = getenv("RTX_SSAA_SPREAD_SLOTS")) spreadSlots = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), kSsaaSpreadSlots);
 	// tile-local waves (see rtxSsaaCountKernel) below eight full rounds of waves' worth of flagged pixels -- measured:
 	// 250k scene 4096^2 (88 k flagged) 1.00 against 1.54 ms packed, 8192^2 (350 k) 1.29 against 1.75; the glass-and-
 	// mirror scene at 1080p (746 k flagged, no slow tiles) 0.82 against 0.68 packed
 	uint32_t localBelow = (uint32_t)s->blocksSsaa * 4u * 16u * 8u;      // (about 650 000 flagged pixels)
-	if (const char* e = getenv("RTX_SSAA_LOCAL_BELOW")) localBelow = (uint32_t)strtoul(e, nullptr, 10);   // test knob: 0 = always packed
+	if (s->knobs.localBelow >= 0) localBelow = (uint32_t)std::min<long long>(s->knobs.localBelow, 0xffffffffll);   // test knob: 0 = always packed
 	uint32_t* mode = s->work + 8;             // [0] local mode, [1] flagged pixels, [2] extra slots handed to 4-pixel tiles
 	uint32_t launches = 0;
 	// The layout (tile-local or packed) follows from the number of flagged pixels: a count, a scan and a copy before the
@@ -1088,10 +1171,10 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	unsigned long long c[16];
 	HIPCHK(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
 	out->rays = c[0]; out->box_tests = c[1]; out->tri_tests = c[2]; out->moot_rays = c[15];
-	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] slowest work item %.3f ms, sum of items %.3f ms (100 MHz wall clock)\n", c[3] * 1e-5, c[4] * 1e-5);
-	if (getenv("RTX_DEBUG_ITEMS")) fprintf(stderr, "[rtx] wave-level: node visits %llu, reached leaves %llu, filter passes (64 references) %llu, of which rejected whole by stage 1 %llu, by stage 2 %llu; survivors tested exactly %llu\n", c[5], c[10], c[12], c[13], c[7], c[6]);
+	if (s->knobs.debugItems) fprintf(stderr, "[rtx] slowest work item %.3f ms, sum of items %.3f ms (100 MHz wall clock)\n", c[3] * 1e-5, c[4] * 1e-5);
+	if (s->knobs.debugItems) fprintf(stderr, "[rtx] wave-level: node visits %llu, reached leaves %llu, filter passes (64 references) %llu, of which rejected whole by stage 1 %llu, by stage 2 %llu; survivors tested exactly %llu\n", c[5], c[10], c[12], c[13], c[7], c[6]);
 #if RTX_DBG
-	if (getenv("RTX_DEBUG_ITEMS")) {
+	if (s->knobs.debugItems) {
 		std::vector<unsigned long long> w(3 * 16384);
 		HIPCHK(hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(gDbgWave), w.size() * 8));
 		unsigned long long t0 = ~0ull, t1 = 0; double busy = 0; int n = 0;
@@ -1106,7 +1189,7 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	}
 #endif
 #if RTX_DBG
-	if (getenv("RTX_DEBUG_ITEMS")) {
+	if (s->knobs.debugItems) {
 		unsigned long long h[64];
 		HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(gDbgHist), sizeof(h)));
 		{ unsigned long long z[8] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gDbgHist), z, sizeof(z), 8 * sizeof(unsigned long long))); }
@@ -1120,7 +1203,7 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	}
 #endif
 #if RTX_DBG >= 2
-	if (getenv("RTX_DEBUG_ITEMS")) {
+	if (s->knobs.debugItems) {
 		unsigned long long h[64];
 		HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(gDbgHist), sizeof(h)));
 		{ unsigned long long z[64] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gDbgHist), z, sizeof(z))); }

@@ -164,7 +164,7 @@ struct Params {
 	const uint32_t* countExpect;    // [k], k < 64: listed tiles with index % 64 == k; [64]: how many of those are not zero
 	const uint32_t* splitLimits;    // [0], [1]: pass-1 cost (ticks) above which a tile is rendered / re-sampled in 4, in 16 parts (rtxTileOrderKernel)
 	uint8_t* maskOut;               // Sobel mask written by the frame kernel
-	uint32_t listedTiles, epoch, queueCap, veryBudget, tilesYFull, heavyTicks, padF0, padF1;
+	uint32_t listedTiles, epoch, queueCap, veryBudget, tilesYFull, heavyTicks, stripBit, padF1;      // stripBit: pass 1, 0x10000000 when the tile list may hold 64 x 1 strips
 };
 
 constexpr int kFrameFields = 14;

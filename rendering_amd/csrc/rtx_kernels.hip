@@ -1599,7 +1599,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 #endif
 			// a tile (ty << 16 | tx), or a 64 x 1 strip of a halo row (0x10000000 | strip << 16 | y: rtx_api.hip, buildTileList),
 			// which is accounted to the first of the eight tiles it runs through
-			const bool strip = (tile & 0x10000000u) != 0;
+			const bool strip = (tile & P.stripBit) != 0;      // (stripBit = 0 when the list holds no strips: tile rows from 4096 on use bit 28 themselves)
 			const uint32_t tx = strip ? ((tile >> 16) & 0xfffu) * 8 : tile & 0xffffu, ty = strip ? (tile & 0x7fffu) >> 3 : tile >> 16;
 			const uint32_t x = strip ? tx * 8 + lane : tx * 8 + (lane & 7), y = strip ? tile & 0x7fffu : ty * 8 + (lane >> 3);
 			// x1/y1 are clamped to W-1/H-1: the last column and row are never rendered (scene.cpp:369-372)
@@ -1808,7 +1808,8 @@ __global__ void __launch_bounds__(256) rtxTileOrderKernel(uint32_t* __restrict__
                                                            uint32_t tilesXFull, uint32_t* __restrict__ out, const uint8_t* __restrict__ klassIn = nullptr,
                                                            const unsigned long long* __restrict__ costSum = nullptr, uint32_t nWaves = 1,
                                                            uint32_t splitPercent = 0, uint32_t splitFloor = 0, uint32_t* __restrict__ thresholds = nullptr,
-                                                           uint32_t tilesX = 0, uint32_t stripLimit = 0xffffffffu, uint32_t* __restrict__ heads = nullptr)
+                                                           uint32_t tilesX = 0, uint32_t stripLimit = 0xffffffffu, uint32_t* __restrict__ heads = nullptr,
+                                                           uint32_t stripBit = 0)      // 0x10000000 when the list may hold strips (buildTileList), else 0
 {
 	// (the eight queue heads of the launch that follows, 64 bytes apart: saves a memset per frame)
 	if (PLACE && heads && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 128) heads[threadIdx.x] = 0;
@@ -1832,19 +1833,19 @@ __global__ void __launch_bounds__(256) rtxTileOrderKernel(uint32_t* __restrict__
 	if (thresholds && q == 0 && blockIdx.x == 0 && threadIdx.x == 0) { thresholds[0] = split4; thresholds[1] = split16; }
 	__syncthreads();
 	auto entry = [&](uint32_t tile) {      // (a strip: the first tile it runs through)
-		return (tile & 0x10000000u) ? ((tile & 0x7fffu) >> 3) * tilesXFull + ((tile >> 16) & 0xfffu) * 8 : (tile >> 16) * tilesXFull + (tile & 0xffffu);
+		return (tile & stripBit) ? ((tile & 0x7fffu) >> 3) * tilesXFull + ((tile >> 16) & 0xfffu) * 8 : (tile >> 16) * tilesXFull + (tile & 0xffffu);
 	};
 	auto klass = [&](uint32_t tile) {
 		if (klassIn) return (uint32_t)klassIn[entry(tile)];
 		uint32_t c = cost[entry(tile)];
-		if (tile & 0x10000000u) c = c > 0x1fffffffu ? 0xffffffffu : c * 8;      // (a strip's time is spread over eight entries)
+		if (tile & stripBit) c = c > 0x1fffffffu ? 0xffffffffu : c * 8;      // (a strip's time is spread over eight entries)
 		return c ? 31u - (uint32_t)__builtin_clz(c) : 0u;
 	};
 	// A strip that was slow (it runs through dense geometry: its wide bundle is halved again and again, and ONE wave does
 	// all of it) goes back to being up to eight tiles for eight waves.  Its cost is spread over the entries of those tiles
 	// (rtxPass1Kernel), so the sum is the strip's time in either form.
 	auto parts = [&](uint32_t tile) {
-		if (tile & 0x10000000u) {
+		if (tile & stripBit) {
 			const uint32_t tx0 = ((tile >> 16) & 0xfffu) * 8, n = tilesX - tx0 < 8u ? tilesX - tx0 : 8u;
 			unsigned long long sum = 0;
 			for (uint32_t e = 0; e < n; ++e) sum += cost[entry(tile) + e];
@@ -1897,7 +1898,7 @@ __global__ void __launch_bounds__(256) rtxTileOrderKernel(uint32_t* __restrict__
 		const uint32_t tile = list[base + i], np = parts(tile);
 		const uint32_t at = obase + atomicAdd(&cursor[klass(tile)], np);
 		if (np == 1) out[at] = tile;
-		else if (tile & 0x10000000u) for (uint32_t e = 0; e < np; ++e) out[at + e] = ((tile & 0x7fffu) >> 3) << 16 | (((tile >> 16) & 0xfffu) * 8 + e);
+		else if (tile & stripBit) for (uint32_t e = 0; e < np; ++e) out[at + e] = ((tile & 0x7fffu) >> 3) << 16 | (((tile >> 16) & 0xfffu) * 8 + e);
 		else if (np == 4) for (uint32_t e = 0; e < 4; ++e) out[at + e] = tile | 0x8000u | e << 13;
 		else for (uint32_t e = 0; e < 16; ++e) out[at + e] = tile | 0x80008000u | (e & 3u) << 13 | (e >> 2) << 29;
 	}
@@ -2193,6 +2194,8 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 		bool late = false;
 		do {                              // the tail is advanced before the entry is written
 			e = __hip_atomic_load(entry, RTX_AGENT);
+			// (an entry that is never written: its producer found the queue full and set the error word -- nobody waits 10 s for that)
+			if ((uint32_t)(e >> 32) != P.epoch && __hip_atomic_load(ctl + FC_ERROR, RTX_AGENT) != 0) return -1;
 			late = (uint32_t)(e >> 32) != P.epoch && expired();
 		} while ((uint32_t)(e >> 32) != P.epoch && !late);
 		if (late) { if (lane == 0) atomicExch(ctl + FC_ERROR, 1u); return -1; }

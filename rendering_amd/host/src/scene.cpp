@@ -640,8 +640,10 @@ void Scene::render()
 		Timer tp("Render scene + MSAA");
 		gpuCheck(rtx_counters_enable(g, 0), "rtx_counters_enable");
 		gpuCheck(rtx_render_frame(g, 0, (uint32_t)options.height, d.fb, d.mask, nullptr), "rtx_render_frame");
+		// the host's synchronisation point: a single launch that gave up has been rendered again in three (include/rtx.h)
 		uint32_t status = 0;
 		gpuCheck(rtx_frame_status(g, &status), "rtx_frame_status");
+		if (status && options::enableOutput) std::cout << "frame rendered again in three launches (single launch status " << (status & 0xffu) << ")\n";
 	}
 	else {
 		{
@@ -667,6 +669,8 @@ void Scene::render()
 			saveImageBGR(bgr.data(), options);
 		}
 	}
+	// launchWorkers / launchSSAA (the reference's entry points) render ALL rows: the sharding is this call's own business
+	if (sharded) gpuCheck(rtx_set_row_ownership(g, 0u, 1u, 0u, 1), "rtx_set_row_ownership");
 	if (statisticsOn()) {
 		rtx_counters c{};
 		if (rtx_counters_read(gpu(), &c) == RTX_OK) {

@@ -73,7 +73,7 @@ def test_frame_everything_split(ra, torch_cuda, monkeypatch):
     for it in range(3):
         fb, mask = frame(torch, g, FUSED)
         assert same(torch, ref_fb, fb) and torch.equal(ref_mask, mask)
-    monkeypatch.setenv("RTX_SPLIT_PERCENT", "0")      # and never
+    g.set_knob("split_percent", 0)      # and never
     fb, mask = frame(torch, g, FUSED)
     assert same(torch, ref_fb, fb) and torch.equal(ref_mask, mask)
 
@@ -162,7 +162,7 @@ def test_halo_strips_and_their_expansion(ra, torch_cuda, monkeypatch):
     full, full_mask = stages(torch, g)
     for limit in (None, "0"):
         if limit is not None:
-            monkeypatch.setenv("RTX_STRIP_LIMIT", limit)
+            g.set_knob("strip_limit", int(limit))
         for parts in (2, 3):
             acc = torch.zeros_like(full)
             for part in range(parts):
