@@ -620,6 +620,12 @@ __shared__ float pruneUni[4][16];
 #ifndef RTX_PRUNE
 #define RTX_PRUNE 1
 #endif
+#ifndef RTX_PRUNE_ROOT
+#define RTX_PRUNE_ROOT 0      // 1: the prune records of the root's slots are evaluated too
+#endif
+#ifndef RTX_PRUNE_RCP
+#define RTX_PRUNE_RCP 1       // the range of 1 / dir from the bundle's direction box (six v_rcp_f32) instead of three wave-wide min / max reductions
+#endif
 // 36 u / 1e-8 (u = 2^-24) = 214.6: see pruneSlots
 constexpr float kPruneC = 216.0f;
 // the reference's box test in its min / max form (exact when no NaN can arise, see meshWalk) against a box in SGPRs
@@ -739,13 +745,29 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 	if (WIDE && RTX_PRUNE) {
 		pruneRecs = (const RTX_AS1 char*)(uintptr_t)uni((const PruneBlock*)sloadp(&M->prune));
 		if (pruneRecs != nullptr) {
-			// range of 1 / dir over the rays of this walk (finite: WIDE implies REGULAR), and of their origins (the bundle's box)
+			// Range of 1 / dir over the rays of this walk, from the bundle's direction box (every ray's direction lies in dc +- rd):
+			// 1 / x is monotone on either side of 0, so every lane's RN(1 / d) lies between the reciprocals of the box's ends --
+			// v_rcp_f32 (1 ulp) widened by 2^-21 covers its own error, the rounding of the ends and the lane's own rounding.
+			// An axis whose box touches 0 is not usable (flag), one with an end beyond 2^-100 neither (the reciprocal may be inf).
+#if RTX_PRUNE_RCP
+			const float dlx = B.dcx - B.rdx, dhx = B.dcx + B.rdx, dly = B.dcy - B.rdy, dhy = B.dcy + B.rdy, dlz = B.dcz - B.rdz, dhz = B.dcz + B.rdz;
+			const float wide = 1.0f + 0x1p-21f, narrow = 1.0f - 0x1p-21f;
+			// (1 / x falls on either side of 0: the smaller reciprocal belongs to the upper end of the box, whatever the sign)
+			float lx = __builtin_amdgcn_rcpf(dhx), hx = __builtin_amdgcn_rcpf(dlx);
+			float ly = __builtin_amdgcn_rcpf(dhy), hy = __builtin_amdgcn_rcpf(dly), lz = __builtin_amdgcn_rcpf(dhz), hz = __builtin_amdgcn_rcpf(dlz);
+			lx *= lx > 0 ? narrow : wide; hx *= hx > 0 ? wide : narrow;
+			ly *= ly > 0 ? narrow : wide; hy *= hy > 0 ? wide : narrow;
+			lz *= lz > 0 ? narrow : wide; hz *= hz > 0 ? wide : narrow;
+			const bool usx = (dlx > 0x1p-100f || dhx < -0x1p-100f), usy = (dly > 0x1p-100f || dhy < -0x1p-100f), usz = (dlz > 0x1p-100f || dhz < -0x1p-100f);
+#else
 			const float inf = __builtin_inff();
 			float hx = consider ? ix : -inf, lx = consider ? ix : inf, hy = consider ? iy : -inf, ly = consider ? iy : inf, hz = consider ? iz : -inf, lz = consider ? iz : inf;
 			waveMaxMin(hx, lx); waveMaxMin(hy, ly); waveMaxMin(hz, lz);
+			const bool usx = true, usy = true, usz = true;
+#endif
 			if (laneNow() == 0) {
 				const bool nx = hx < 0, ny = hy < 0, nz = hz < 0;
-				const bool okx = lx > 0 || nx, oky = ly > 0 || ny, okz = lz > 0 || nz;
+				const bool okx = usx && (lx > 0 || nx), oky = usy && (ly > 0 || ny), okz = usz && (lz > 0 || nz);
 				f4v a, b, c, e;
 				a.x = nx ? -hx : lx; a.y = nx ? -lx : hx; a.z = ny ? -hy : ly; a.w = ny ? -ly : hy;
 				b.x = nz ? -hz : lz; b.y = nz ? -lz : hz;
@@ -810,7 +832,8 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				const u32x16 wa = sload16(w), wb = sload16((const char*)w + 64);
 				// Which slots can contribute at all: lane k & 3 looks at slot k & 3 (bits 0..3 of the ballot are used).
 				uint32_t aliveM = 0xfu;
-				if (RTX_PRUNE && pruneRecs != nullptr) {
+				// (not at the root: the four slots two levels down are as good as never pruned -- 7 of 259 in tools/research/pruned_walk_sim.py)
+				if (RTX_PRUNE && pruneRecs != nullptr && (RTX_PRUNE_ROOT || link != 1)) {
 					// lanes 0..3: the slots' boxes (PruneRec), lanes 4..7: their planes (PlaneRec); both tests run on every lane's record
 					const RTX_AS1 f4v* pr = (const RTX_AS1 f4v*)(pruneRecs + ((((uint32_t)(link - 1) << 3) | (lane & 7u)) << 5));
 					const f4v r0 = pr[0], r1 = pr[1];
@@ -1445,9 +1468,29 @@ __device__ __forceinline__ void primaryRay(const Params& P, float x, float y, V3
 constexpr int kParkFields = RTX_PARK_MORE ? 26 : 21;
 __shared__ float parkedState[kParkFields][256];
 
-template <bool STATS, bool MESH = true, bool FEWRAYS = false>
-__device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 d, uint32_t gl, Counts& cnt)
+// The kernel's argument block, read afresh from the kernarg segment.  Every ray kernel takes `const Params P` as its only
+// argument, so the segment starts with it.  The empty asm makes the pointer opaque: fields read through it are loaded where
+// they are used (s_load from the kernarg segment: scalar memory, no VALU slot) instead of being kept in SGPRs across the
+// walk -- where the register allocator parks them in lanes of a VGPR (v_writelane / v_readlane: ~100 VALU instructions per
+// trace round of a kernel that is bound by VALU issue).
+#ifndef RTX_KARGS
+#define RTX_KARGS 1
+#endif
+__device__ __forceinline__ const Params& freshParams(const Params& P)
 {
+#if RTX_KARGS
+	uint64_t p = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(p));
+	return *(const Params*)(const RTX_AS4 Params*)p;      // (the loads are still selected as s_load: the address space is inferred back)
+#else
+	return P;
+#endif
+}
+
+template <bool STATS, bool MESH = true, bool FEWRAYS = false>
+__device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3 d, uint32_t gl, Counts& cnt)
+{
+	const Params& P = freshParams(P0);
 	Lane s;
 	s.state = valid ? ST_NEWRAY : ST_DONE;
 	s.sp = 0; s.ro = o; s.rd = d; s.col = mk(0, 0, 0);
@@ -1488,7 +1531,7 @@ __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 
 			}
 			asm volatile("" ::: "memory");
 		}
-		traceWave<STATS, MESH, FEWRAYS>(P, qactive, qshadow, qo, qd, qtmax, h, cnt);
+		traceWave<STATS, MESH, FEWRAYS>(freshParams(P0), qactive, qshadow, qo, qd, qtmax, h, cnt);
 		if (MESH && RTX_PARK) {
 			asm volatile("" ::: "memory");
 			const uint32_t t = threadIdx.x;
@@ -1508,8 +1551,9 @@ __device__ __forceinline__ V3 castRayWave(const Params& P, bool valid, V3 o, V3 
 		const unsigned long long dbgT1 = __builtin_readcyclecounter();
 #endif
 		if (s.state != ST_DONE) {
-			consume(P, s, h);
-			advance(P, s, gl);
+			const Params& Pa = freshParams(P0);
+			consume(Pa, s, h);
+			advance(Pa, s, gl);
 		}
 #if RTX_DBG
 		dbgRounds++; dbgTrace += dbgT1 - dbgT0; dbgState += __builtin_readcyclecounter() - dbgT1;

@@ -55,7 +55,17 @@ def make_scene(seed, w, h):
     return s + "[end]\n"
 
 
-@pytest.mark.parametrize("seed", list(range(16)))
+def fuzz_seeds():
+    """16 seeds by default; RTX_FUZZ_SEEDS=first:last (exclusive) runs any other range (tools/fuzz_many.py runs long ranges
+    with larger scenes and keeps the evidence: profiles/r03_fuzz.txt)."""
+    e = os.environ.get("RTX_FUZZ_SEEDS")
+    if e:
+        a, b = e.split(":")
+        return list(range(int(a), int(b)))
+    return list(range(16))
+
+
+@pytest.mark.parametrize("seed", fuzz_seeds())
 def test_random_scene_bit_exact(ra, oracle, tmp_path, seed):
     from tests.util_rays import probe_rays
     w, h = 96 + 8 * (seed % 3), 72 + 4 * (seed % 5)

@@ -55,4 +55,6 @@ for seed in range(first, first + n):
         if frames: print("   rtx_render_frame differs in %d of 6 frames" % frames)
         print("MISMATCH seed", seed, "pass-1 pixels", int((bits(ref1) != bits(got1)).any(-1).sum()), "ssaa pixels", int((bits(ref2) != bits(got2)).any(-1).sum()))
     o.close(); g.close()
-print("seeds %d..%d: %d mismatching scenes" % (first, first + n - 1, bad))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from srchash import source_hash
+print("seeds %d..%d: %d mismatching scenes; sources %s" % (first, first + n - 1, bad, source_hash()))

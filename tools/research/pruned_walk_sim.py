@@ -49,6 +49,11 @@ def main():
             qlo[i] = np.minimum(qlo[l], qlo[r_]); qhi[i] = np.maximum(qhi[l], qhi[r_])
             wlo[i] = min(wlo[l], wlo[r_]); whi[i] = max(whi[l], whi[r_])
             tlo[i] = np.minimum(tlo[l], tlo[r_]); thi[i] = np.maximum(thi[l], thi[r_])
+    depth = np.zeros(nN, int)
+    for i in range(nN):
+        if not is_leaf[i]:
+            depth[i + 1] = depth[i] + 1; depth[skip[i + 1]] = depth[i] + 1
+    hist_visit = np.zeros(40, int); hist_prune = np.zeros(40, int)
     scale, aspect, M, pos = g.camera()
     M = M.reshape(4, 4)
     rng = np.random.default_rng(1)
@@ -151,7 +156,11 @@ def main():
                 nodes += 1
                 if not p.any():
                     continue
+                if mo == "unc_plane":
+                    hist_visit[depth[i]] += 1
                 if mo in ("plane", "both", "bothc", "bothc_ord", "unc_plane", "mix_plane") and plane_dead(o[open_], d[open_], best[open_].max(), i):
+                    if mo == "unc_plane":
+                        hist_prune[depth[i]] += 1
                     continue
                 if mo in ("tbox", "both") and np.isfinite(tlo[i]).all():
                     if not seg_box(o64[open_], inv[open_], best[open_], tlo[i], thi[i], float(os.environ.get('MARGIN','1e-3'))).any():
@@ -165,6 +174,8 @@ def main():
                     if mo.startswith("mix"):
                         rho = np.minimum(rho, cert_rho_bundle(o[open_], d[open_], i))
                     if not seg_box_rho(o64[open_], inv[open_], np.full(int(open_.sum()), best[open_].max()), tlo[i], thi[i], rho).any():
+                        if mo == "unc_plane":
+                            hist_prune[depth[i]] += 1
                         continue
                 if is_leaf[i]:
                     if lcnt[i] == 0:
@@ -229,6 +240,7 @@ def main():
                 so = (P + n * f32(1e-4)).astype(f32)
                 trace(so[facing], dl[facing], dist[facing], True)
         print("tile (%d,%d) r=%.0f hit %d: " % (tx, ty, rad, hit.sum()) + " | ".join("%s n%d l%d p%d" % (mo, tot[mo]["nodes"] - before[mo]["nodes"], tot[mo]["leaves"] - before[mo]["leaves"], tot[mo]["passes"] - before[mo]["passes"]) for mo in modes))
+    print("unc_plane: by binary depth: tested / pruned:", [(int(a), int(b)) for a, b in zip(hist_visit, hist_prune)][:30])
     n = ntr[0]
     print("traces", n, "mismatching lanes vs today:", mism[0])
     for mo in modes:
