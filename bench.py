@@ -354,7 +354,10 @@ def main():
     avg_ms = ms4 / max(n4, 1) if one_launch else ms1 / max(n1, 1)
     # cold frame: a freshly created scene in the warm process -- its first pass 1 has no tile costs of a previous launch to
     # order its queues by (the reference's use case is one frame per process)
-    cold_ms = None
+    # The GPU has been idle while the host loaded that scene, and its clocks need a few milliseconds to come back: a second
+    # fresh scene is timed (HIP events) directly behind three frames of the warm one -- what the first frame costs in software
+    # (no measured tile costs: the estimate of rtx_scene_create orders and splits it; tools/cold_probe.py).
+    cold_ms = cold_busy_ms = None
     if world == 1:
         scene2 = RA.Scene(args.scene, W, H, device=local)
         scene2.gpu()
@@ -364,6 +367,20 @@ def main():
         torch.cuda.synchronize()
         cold_ms = (time.perf_counter() - tc) * 1e3
         scene2.close()
+        scene3 = RA.Scene(args.scene, W, H, device=local)
+        scene3.gpu()
+        torch.cuda.synchronize()
+        fb3 = torch.zeros_like(fb); mask3 = torch.zeros_like(mask)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            step()
+        e0.record()
+        parallel.shard_frame(scene3, fb3, mask3, 1, 0, ssaa=ssaa, clear=False)
+        e1.record()
+        torch.cuda.synchronize()
+        cold_busy_ms = e0.elapsed_time(e1)
+        scene3.close()
+        del fb3, mask3
     # The SURVEY 8d byte model (32 B per box test + 40 B per triangle test counted under REFERENCE traversal semantics
     # + 12 B per rendered pixel) is kept as a description of the reference's work -- the kernel shares every fetch among
     # 64 rays and rejects whole groups of triangles without touching them per ray, so it is not what bounds the kernel.
@@ -408,6 +425,7 @@ def main():
                    "pass1_ms": round(ms1 / n1, 3) if n1 else None, "ssaa_ms": round(ms2 / n2, 3) if n2 else None,
                    "frame_kernel_ms": round(ms4 / n4, 3) if n4 else None,
                    "cold_frame_ms": None if cold_ms is None else round(cold_ms, 3),
+                   "cold_frame_gpu_busy_before_ms": None if cold_busy_ms is None else round(cold_busy_ms, 3),
                    "pass1_rays_rank0": int(c1[0]), "ssaa_rays_rank0": int(c2[0]), "ssaa_pixels_rank0": int(mask.sum()),
                    "ssaa_box_tests": int(c2[1]), "ssaa_tri_tests": int(c2[2])},
         "roofline": roof,

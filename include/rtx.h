@@ -162,6 +162,11 @@ int rtx_render_frame(rtx_scene* scene, uint32_t row_begin, uint32_t row_end, flo
 int rtx_frame_status(rtx_scene* scene, uint32_t* status);
 int rtx_frame_mode(rtx_scene* scene, int* mode, float* split_ms, float* fused_ms);
 int rtx_set_frame_mode(rtx_scene* scene, int mode); /* -1 measure and choose (default), 0 always three launches, 1 always one */
+/* First-frame cost estimate (rtx_scene_create / rtx_scene_set_view project every leaf box of the meshes through the camera;
+ * the reference renders one frame per process, main.cpp:15, so there is no previous frame to learn the tile costs from):
+ * per cell of 2 x 2 tiles (16 x 16 pixels) the references and the leaves whose boxes cover it, interleaved (refs, leaves),
+ * grid_w x grid_h cells.  out == NULL: only the dimensions.  Diagnostic (tools/cost_fit.py); no pixel depends on the estimate. */
+int rtx_cost_grid_read(rtx_scene* scene, uint32_t* out, size_t n, uint32_t* grid_w, uint32_t* grid_h);
 /* Experiment / test knobs of a live scene.  Their environment variables (RTX_STRIP_LIMIT, RTX_SSAA_HEAVY_TICKS,
  * RTX_SSAA_SPREAD_SLOTS, RTX_SPLIT_PERCENT, RTX_SSAA_LOCAL_BELOW, RTX_FRAME_QUEUE_CAP, RTX_DEBUG_ITEMS, ...) are read
  * once, by rtx_scene_create; names here: strip_limit, ssaa_heavy_ticks, ssaa_spread_slots, split_percent,

@@ -34,7 +34,7 @@ _host = None
 # every entry point declared in include/rtx.h
 RTX_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_set_view", "rtx_scene_bytes",
-    "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_render_frame", "rtx_frame_status", "rtx_frame_mode", "rtx_set_frame_mode", "rtx_set_knob", "rtx_quantize_bgr8", "rtx_render_frame_host",
+    "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_render_frame", "rtx_frame_status", "rtx_frame_mode", "rtx_set_frame_mode", "rtx_set_knob", "rtx_cost_grid_read", "rtx_quantize_bgr8", "rtx_render_frame_host",
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
     "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
     "rtx_bvh_build", "rtx_bvh_info", "rtx_bvh_read", "rtx_bvh_destroy",
@@ -68,6 +68,7 @@ def load():
     rtx.rtx_frame_status.argtypes = [vp, C.POINTER(C.c_uint32)]
     rtx.rtx_set_frame_mode.argtypes = [vp, C.c_int]
     rtx.rtx_set_knob.argtypes = [vp, C.c_char_p, C.c_double]
+    rtx.rtx_cost_grid_read.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     rtx.rtx_frame_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     rtx.rtx_quantize_bgr8.argtypes = [vp, vp, vp, vp]
     rtx.rtx_render_frame_host.argtypes = [vp, i32, vp]
@@ -360,6 +361,14 @@ class Scene:
     def set_knob(self, name, value):
         """Experiment / test knob of this scene (include/rtx.h, rtx_set_knob); no knob changes a pixel."""
         _check(self.rtx.rtx_set_knob(self.gpu(), name.encode(), float(value)), "rtx_set_knob")
+
+    def cost_grid(self):
+        """First-frame cost estimate of the current view: (refs, leaves) per cell of 2 x 2 tiles, arrays grid_h x grid_w."""
+        gw, gh = C.c_uint32(0), C.c_uint32(0)
+        _check(self.rtx.rtx_cost_grid_read(self.gpu(), None, 0, C.byref(gw), C.byref(gh)), "rtx_cost_grid_read")
+        g = np.zeros((gh.value, gw.value, 2), np.uint32)
+        _check(self.rtx.rtx_cost_grid_read(self.gpu(), _np_ptr(g), g.size, C.byref(gw), C.byref(gh)), "rtx_cost_grid_read")
+        return g[..., 0], g[..., 1]
 
     def frame_status(self):
         """The host's synchronisation point for render_frame: 0, or error | 0x100 when the single launch gave up and the

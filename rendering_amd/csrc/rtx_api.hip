@@ -75,6 +75,8 @@ void makeRef(const rtx_mesh& m, uint32_t ref, RefA& a, RefB& b, RefC& c)
 struct Knobs {
 	int pass1BlocksPerCU = 0, ssaaBlocksPerCU = 0, frameBlocksPerCU = 0;   // RTX_*_BLOCKS_PER_CU: 0 = what the occupancy allows
 	bool prune = true;                   // RTX_NO_PRUNE: no prune records (rtxd::PruneBlock)
+	bool estimate = true;                // RTX_NO_COST_ESTIMATE: no first-frame cost estimate
+	float costPerRef = 6.0f, costPerLeaf = 150.0f, costBase = 1500.0f;   // estimate = base + perRef refs + perLeaf leaves (100 MHz ticks per tile; tools/cost_fit.py)
 	float fatFactor = 3.0f;              // RTX_FAT_FACTOR: bundle width, in mean triangle edges, above which a bundle is split; 0 = never
 	uint32_t stripLimit = 100000u;       // RTX_STRIP_LIMIT: a halo strip slower than this (100 MHz ticks) is listed as tiles again
 	uint32_t heavyTicks = 25000u;        // RTX_SSAA_HEAVY_TICKS: tiles above go first in the SSAA list
@@ -113,7 +115,7 @@ struct rtx_scene {
 	std::vector<float> meshBounds;        // 6 floats per mesh: the root box
 	struct TileQueues {
 		std::vector<uint32_t> key;        // what the list was built for (view, row range, row ownership)
-		uint32_t* list = nullptr; size_t cap = 0;   // [0, cap): queues in geometric order, [cap, 2 cap): ordered by cost
+		uint32_t* list = nullptr; size_t cap = 0;   // the queues in geometric order (ordered by cost: rtx_scene::orderedList)
 		uint8_t* need = nullptr; size_t needCap = 0; uint32_t listed = 0;
 		uint32_t* countExpect = nullptr; bool needValid = false;          // listed tiles by index % 64 (the frame kernel's completion counters)   // rtx_render_frame: listed tiles in each tile's 3x3 neighbourhood
 		bool costValid = false;           // tileCost holds the costs of a launch with this key
@@ -128,6 +130,13 @@ struct rtx_scene {
 	struct LastFused { bool valid = false; uint32_t rowBegin = 0, rowEnd = 0; float* fb = nullptr; uint8_t* mask = nullptr; void* stream = nullptr; size_t queue = ~(size_t)0; uint32_t generation = 0; };
 	LastFused lastFused;
 	uint32_t framesRecovered = 0;
+	// first-frame cost estimate (estimateCosts): the leaf arrays of the meshes, the cell grid, whether tileCost holds usable
+	// numbers (estimated or measured) for EVERY tile of the current view
+	struct MeshLeaves { const float* boxes; uint32_t n; };      // 8 floats per non-empty leaf: true box lo, hi, reference count, -
+	std::vector<MeshLeaves> meshLeaves;
+	uint32_t* costGrid = nullptr; size_t costGridCap = 0;
+	uint32_t* orderedList = nullptr; size_t orderedCap = 0;      // the tile list of the next launch in the order of rtxTileOrderKernel
+	bool costsUsable = false;
 	// rtx_render_frame: event pairs around the last few frames, read back (without waiting) by later calls
 	struct FrameProbe { hipEvent_t a = nullptr, b = nullptr; int mode = -1; size_t queue = 0; uint32_t generation = 0; bool pending = false; };
 	FrameProbe probes[8];
@@ -153,6 +162,8 @@ void readKnobs(Knobs& k)
 	auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? strtoll(e, nullptr, 10) : dflt; };
 	k.pass1BlocksPerCU = (int)num("RTX_PASS1_BLOCKS_PER_CU", 0); k.ssaaBlocksPerCU = (int)num("RTX_SSAA_BLOCKS_PER_CU", 0); k.frameBlocksPerCU = (int)num("RTX_FRAME_BLOCKS_PER_CU", 0);
 	k.prune = !getenv("RTX_NO_PRUNE");
+	k.estimate = !getenv("RTX_NO_COST_ESTIMATE");
+	if (const char* e = getenv("RTX_COST_COEFFS")) sscanf(e, "%f,%f,%f", &k.costPerRef, &k.costPerLeaf, &k.costBase);
 	if (const char* e = getenv("RTX_FAT_FACTOR")) k.fatFactor = strtof(e, nullptr);
 	k.stripLimit = (uint32_t)num("RTX_STRIP_LIMIT", k.stripLimit);
 	k.heavyTicks = (uint32_t)num("RTX_SSAA_HEAVY_TICKS", k.heavyTicks);
@@ -246,6 +257,36 @@ int ensureWork(rtx_scene* s)
 	s->params.totalLanes = totalLanes;
 	s->params.workCounter = s->work;
 	s->params.counters = s->counters;
+	return RTX_OK;
+}
+
+int prepareView(rtx_scene* s);
+
+// First-frame cost estimate of the current view into tileCost (rtx_kernels.hip, rtxCostSplatKernel).  Part of loading the
+// scene / setting the view, like the upload: the reference's "Render scene" timer starts after its loader too.
+int estimateCosts(rtx_scene* s)
+{
+	s->costsUsable = false;
+	if (!s->knobs.estimate || s->meshLeaves.empty() || !s->tileCost) return RTX_OK;
+	const View& v = s->params.view;
+	const uint32_t txFull = (v.width + 7) / 8, tyFull = (v.height + 7) / 8;
+	const uint32_t gridW = (txFull + 1) / 2, gridH = (tyFull + 1) / 2;
+	const size_t cells = (size_t)gridW * gridH;
+	if (cells > s->costGridCap) {
+		if (s->costGrid) HIPCHK(hipFree(s->costGrid));
+		s->costGrid = nullptr; s->costGridCap = 0;
+		HIPCHK(hipMalloc((void**)&s->costGrid, 2 * cells * sizeof(uint32_t)));
+		s->costGridCap = cells;
+	}
+	HIPCHK(hipMemsetAsync(s->costGrid, 0, 2 * cells * sizeof(uint32_t), nullptr));
+	for (const auto& m : s->meshLeaves)
+		if (m.n) hipLaunchKernelGGL(rtxCostSplatKernel, dim3((m.n + 255) / 256), dim3(256), 0, nullptr, m.boxes, m.n, v, gridW, gridH, s->costGrid);
+	const uint32_t tiles = txFull * tyFull;
+	hipLaunchKernelGGL(rtxCostFillKernel, dim3((tiles + 255) / 256), dim3(256), 0, nullptr, (const uint32_t*)s->costGrid, gridW, txFull, tyFull, s->tileCost,
+	                   s->knobs.costPerRef, s->knobs.costPerLeaf, s->knobs.costBase);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipDeviceSynchronize());
+	s->costsUsable = true;
 	return RTX_OK;
 }
 
@@ -467,6 +508,23 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		memset(&dm, 0, sizeof(dm));
 		int rc;
 		if ((rc = upload(s->owned, nodes.data(), nodes.size(), &dm.nodes))) return bail(rc);
+		{
+			// for the first-frame cost estimate: the TRUE box of every non-empty leaf's triangles and its reference count
+			std::vector<float> lb;
+			for (uint32_t i = 0; i < m.n_nodes; i++) {
+				if (m.leaf_count[i] <= 0) continue;
+				float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+				for (uint32_t r = (uint32_t)m.leaf_begin[i]; r < (uint32_t)(m.leaf_begin[i] + m.leaf_count[i]); r++) {
+					const float* p = m.tri_pos + (size_t)m.refs[r] * 9;
+					for (int v = 0; v < 9; v++) { lo[v % 3] = std::min(lo[v % 3], p[v]); hi[v % 3] = std::max(hi[v % 3], p[v]); }
+				}
+				if (!(std::isfinite(lo[0] + lo[1] + lo[2] + hi[0] + hi[1] + hi[2]))) continue;
+				lb.insert(lb.end(), { lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], (float)m.leaf_count[i], 0.0f });
+			}
+			const float* dev = nullptr;
+			if ((rc = upload(s->owned, lb.data(), lb.size(), &dev))) return bail(rc);
+			s->meshLeaves.push_back({ dev, (uint32_t)(lb.size() / 8) });
+		}
 		if ((rc = upload(s->owned, wide.data(), wide.size(), &dm.wide))) return bail(rc);
 		dm.nWide = (uint32_t)wide.size();
 		if ((rc = upload(s->owned, prune.data(), prune.size(), &dm.prune))) return bail(rc);
@@ -549,6 +607,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 	}
 	if ((rc = setView(s, &desc->view))) return bail(rc);
 	if ((rc = ensureWork(s))) return bail(rc);
+	if ((rc = prepareView(s))) return bail(rc);
 	s->sceneBytes = gUploadedBytes;
 	*out = s;
 	return RTX_OK;
@@ -568,6 +627,8 @@ void rtx_scene_destroy(rtx_scene* s)
 	if (s->tileClass) (void)hipFree(s->tileClass);
 	for (auto& pr : s->probes) { if (pr.a) (void)hipEventDestroy(pr.a); if (pr.b) (void)hipEventDestroy(pr.b); }
 	if (s->ssaaQueue) (void)hipFree(s->ssaaQueue);
+	if (s->costGrid) (void)hipFree(s->costGrid);
+	if (s->orderedList) (void)hipFree(s->orderedList);
 	if (s->frameCtl) (void)hipFree(s->frameCtl);
 	if (s->ssaaPixels) (void)hipFree(s->ssaaPixels);
 	if (s->work) {
@@ -583,7 +644,8 @@ int rtx_scene_set_view(rtx_scene* s, const rtx_view* v)
 	int rc = setView(s, v);
 	if (rc) return rc;
 	s->viewSerial++;
-	return ensureWork(s);
+	if ((rc = ensureWork(s))) return rc;
+	return prepareView(s);
 }
 
 namespace {
@@ -689,8 +751,16 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 	if (list.size() > e->cap) {
 		if (e->list) HIPCHK(hipFree(e->list));
 		e->list = nullptr; e->cap = 0;
-		HIPCHK(hipMalloc((void**)&e->list, 17 * list.size() * sizeof(uint32_t)));      // + the ordered copy, where every tile may be listed in sixteen parts
+		HIPCHK(hipMalloc((void**)&e->list, list.size() * sizeof(uint32_t)));
 		e->cap = list.size();
+	}
+	// the ordered copy, where every tile may be listed in sixteen parts: ONE buffer per scene, shared by the cached lists (the
+	// launch that consumes it follows the ordering kernels on the same stream)
+	if (16 * list.size() > s->orderedCap) {
+		if (s->orderedList) HIPCHK(hipFree(s->orderedList));
+		s->orderedList = nullptr; s->orderedCap = 0;
+		HIPCHK(hipMalloc((void**)&s->orderedList, 16 * list.size() * sizeof(uint32_t)));
+		s->orderedCap = 16 * list.size();
 	}
 	HIPCHK(hipMemcpy(e->list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	e->listed = (uint32_t)(list.size() - 16);
@@ -698,6 +768,58 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 	e->key = key;
 	e->lastUse = ++s->tileUse;
 	*out = e;
+	return RTX_OK;
+}
+
+// Buffers of the single-launch frame (renderFrameFused): dependency counters, flags, the 64 SSAA item queues, the control block.
+int ensureFrameBuffers(rtx_scene* s, size_t tiles, size_t* perQueueOut)
+{
+	if (tiles > s->depCap) {
+		HIPCHK(hipDeviceSynchronize());
+		if (s->tileDeps) { HIPCHK(hipFree(s->tileDeps)); HIPCHK(hipFree(s->tileFlags)); HIPCHK(hipFree(s->tileClass)); }
+		s->tileDeps = nullptr; s->tileFlags = nullptr; s->tileClass = nullptr; s->depCap = 0;
+		HIPCHK(hipMalloc((void**)&s->tileClass, tiles));
+		HIPCHK(hipMalloc((void**)&s->tileDeps, 4 * tiles * sizeof(uint32_t)));      // pass-1 count, Sobel count, quarter costs, quarter count
+		HIPCHK(hipMalloc((void**)&s->tileFlags, tiles * sizeof(unsigned long long)));
+		s->depCap = tiles;
+	}
+	// 64 queues; in all up to 4 items per tile (16 flagged pixels each) plus the budget of extra items for tiles that get
+	// 4-pixel items.  The items are dealt round the queues, so each holds about 1/64 of them: twice that, and some.
+	const size_t perQueue = s->knobs.frameQueueCap ? s->knobs.frameQueueCap : 2 * ((4 * tiles + kSsaaSpreadSlots / 16) / 64) + 256;
+	if (tiles >= (1u << 24)) return fail(RTX_ERR_ARG, "frame too large for rtx_render_frame");
+	if (64 * perQueue != s->queueCap) {
+		HIPCHK(hipDeviceSynchronize());
+		if (s->ssaaQueue) HIPCHK(hipFree(s->ssaaQueue));
+		s->ssaaQueue = nullptr; s->queueCap = 0;
+		HIPCHK(hipMalloc((void**)&s->ssaaQueue, 64 * perQueue * sizeof(unsigned long long)));
+		HIPCHK(hipMemset(s->ssaaQueue, 0, 64 * perQueue * sizeof(unsigned long long)));
+		s->queueCap = 64 * perQueue;
+	}
+	if (!s->frameCtl) {
+		HIPCHK(hipMalloc((void**)&s->frameCtl, kFrameCtlBytes));
+		HIPCHK(hipMemset(s->frameCtl, 0, kFrameCtlBytes));      // (rtxFrameClearKernel keeps an error word it finds)
+	}
+	*perQueueOut = perQueue;
+	return RTX_OK;
+}
+
+// Everything a first frame would otherwise do on the host before its first launch, done when the scene is created / the view
+// set (scene loading: outside the reference's "Render scene" timer as well): the cost estimate, the tile lists of the whole
+// frame for either way of rendering it, the buffers of the single launch.
+int prepareView(rtx_scene* s)
+{
+	int rc = estimateCosts(s);
+	if (rc) return rc;
+	const View& v = s->params.view;
+	if (v.width > 0xffffu || v.height > 0xffffu || s->params.bandH) return RTX_OK;
+	const uint32_t tilesX = (v.width - 1 + 7) / 8, lastRow = v.height - 1;
+	if (lastRow == 0) return RTX_OK;
+	rtx_scene::TileQueues* tq = nullptr;
+	if ((rc = buildTileList(s, 0, lastRow, tilesX, 0, (lastRow + 7) / 8, &tq, true))) return rc;
+	if ((rc = buildTileList(s, 0, lastRow, tilesX, 0, (lastRow + 7) / 8, &tq, false))) return rc;
+	const size_t tiles = (size_t)((v.width + 7) / 8) * ((v.height + 7) / 8);
+	size_t perQueue = 0;
+	if (tiles < (1u << 24) && (rc = ensureFrameBuffers(s, tiles, &perQueue))) return rc;
 	return RTX_OK;
 }
 
@@ -731,16 +853,16 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY, &tq, true))) return rc;
 	p.tileList = tq->list;
 	p.stripBit = stripsFit(p.view) ? 0x10000000u : 0u;
-	if (tq->costValid) {
-		// the previous launch rendered exactly these tiles from this view: start with the ones that were expensive
+	if (tq->costValid || s->costsUsable) {
+		// the previous launch rendered exactly these tiles from this view (or their costs are estimated: estimateCosts): start with the expensive ones
 		const uint32_t stripLimit = s->knobs.stripLimit;
 		// (a strip of a halo row that took more than 1 ms is listed as its tiles again: rtxTileOrderKernel)
 		const unsigned pieces = tq->listed > 16384u ? 32u : 1u;      // (short queues: one block each, one launch)
-		if (pieces > 1) hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
+		if (pieces > 1) hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, s->orderedList, (const uint8_t*)nullptr,
 		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit, (uint32_t*)nullptr, p.stripBit);
-		hipLaunchKernelGGL(rtxTileOrderKernel<true>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)nullptr,
+		hipLaunchKernelGGL(rtxTileOrderKernel<true>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, s->orderedList, (const uint8_t*)nullptr,
 		                   (const unsigned long long*)nullptr, 1u, 0u, 0u, (uint32_t*)nullptr, p.tilesX, stripLimit, s->work + 128, p.stripBit);      // (also zeroes the queue heads)
-		p.tileList = tq->list + tq->cap;
+		p.tileList = s->orderedList;
 	}
 	else HIPCHK(hipMemsetAsync(s->work + 128, 0, 128 * sizeof(uint32_t), st));
 	tq->costValid = true;
@@ -786,31 +908,8 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	rtx_scene::TileQueues* tq = nullptr;
 	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY, &tq))) return rc;
 	const size_t tiles = (size_t)p.tilesXFull * p.tilesYFull;
-	if (tiles > s->depCap) {
-		HIPCHK(hipDeviceSynchronize());
-		if (s->tileDeps) { HIPCHK(hipFree(s->tileDeps)); HIPCHK(hipFree(s->tileFlags)); HIPCHK(hipFree(s->tileClass)); }
-		s->tileDeps = nullptr; s->tileFlags = nullptr; s->tileClass = nullptr; s->depCap = 0;
-		HIPCHK(hipMalloc((void**)&s->tileClass, tiles));
-		HIPCHK(hipMalloc((void**)&s->tileDeps, 4 * tiles * sizeof(uint32_t)));      // pass-1 count, Sobel count, quarter costs, quarter count
-		HIPCHK(hipMalloc((void**)&s->tileFlags, tiles * sizeof(unsigned long long)));
-		s->depCap = tiles;
-	}
-	// 64 queues; in all up to 4 items per tile (16 flagged pixels each) plus the budget of extra items for tiles that get
-	// 4-pixel items.  The items are dealt round the queues, so each holds about 1/64 of them: twice that, and some.
-	const size_t perQueue = s->knobs.frameQueueCap ? s->knobs.frameQueueCap : 2 * ((4 * tiles + kSsaaSpreadSlots / 16) / 64) + 256;
-	if (tiles >= (1u << 24)) return fail(RTX_ERR_ARG, "frame too large for rtx_render_frame");
-	if (64 * perQueue != s->queueCap) {
-		HIPCHK(hipDeviceSynchronize());
-		if (s->ssaaQueue) HIPCHK(hipFree(s->ssaaQueue));
-		s->ssaaQueue = nullptr; s->queueCap = 0;
-		HIPCHK(hipMalloc((void**)&s->ssaaQueue, 64 * perQueue * sizeof(unsigned long long)));
-		HIPCHK(hipMemset(s->ssaaQueue, 0, 64 * perQueue * sizeof(unsigned long long)));
-		s->queueCap = 64 * perQueue;
-	}
-	if (!s->frameCtl) {
-		HIPCHK(hipMalloc((void**)&s->frameCtl, kFrameCtlBytes));
-		HIPCHK(hipMemset(s->frameCtl, 0, kFrameCtlBytes));      // (rtxFrameClearKernel keeps an error word it finds)
-	}
+	size_t perQueue = 0;
+	if ((rc = ensureFrameBuffers(s, tiles, &perQueue))) return rc;
 	if (!tq->needValid) {
 		// once per tile list, on the device: the listed tiles around every tile and the expected values of the completion counters
 		if (tiles > tq->needCap) {
@@ -844,18 +943,18 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	}
 	p.tileList = tq->list;
 	p.splitLimits = s->work + 18;
-	const bool ordered = tq->costValid || costsKnown;      // (the costs of this view may come from frames rendered in three launches)
+	const bool ordered = tq->costValid || costsKnown || s->costsUsable;      // (the costs of this view may come from frames rendered in three launches)
 	if (!ordered) HIPCHK(hipMemsetAsync(s->work + 18, 0xff, 2 * sizeof(uint32_t), st));      // no costs yet: nothing is split
 	if (ordered) {
 		// the previous launch rendered exactly these tiles from this view: start with the ones that were expensive
 		hipLaunchKernelGGL(rtxTileClassKernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, s->tileCost, p.tilesXFull, p.tilesYFull, s->tileClass, (unsigned long long*)(s->work + 16));
 		const uint32_t splitPercent = s->knobs.splitPercent, splitFloor = 2000u;            // floor: 20 us (100 MHz)
 		const unsigned pieces = tq->listed > 16384u ? 32u : 1u;      // (short queues: one block each, one launch)
-		if (pieces > 1) hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)s->tileClass,
+		if (pieces > 1) hipLaunchKernelGGL(rtxTileOrderKernel<false>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, s->orderedList, (const uint8_t*)s->tileClass,
 		                   (const unsigned long long*)(s->work + 16), (uint32_t)s->blocksFrame * 4u, splitPercent, splitFloor, s->work + 18);
-		hipLaunchKernelGGL(rtxTileOrderKernel<true>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, tq->list + tq->cap, (const uint8_t*)s->tileClass,
+		hipLaunchKernelGGL(rtxTileOrderKernel<true>, dim3(pieces, 8), dim3(256), 0, st, s->orderWork, tq->list, s->tileCost, s->params.tilesXFull, s->orderedList, (const uint8_t*)s->tileClass,
 		                   (const unsigned long long*)(s->work + 16), (uint32_t)s->blocksFrame * 4u, splitPercent, splitFloor, s->work + 18);
-		p.tileList = tq->list + tq->cap;
+		p.tileList = s->orderedList;
 	}
 	tq->costValid = true;
 	uint32_t blocks = (uint32_t)s->blocksFrame;
@@ -1265,6 +1364,20 @@ int rtx_tile_cost_read(rtx_scene* s, uint32_t* out, size_t n)
 	if (!s->tileCost || s->tileCap < tiles) return fail(RTX_ERR_ARG, "no pass 1 has run at this size");
 	HIPCHK(hipDeviceSynchronize());
 	HIPCHK(hipMemcpy(out, s->tileCost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	return RTX_OK;
+}
+
+int rtx_cost_grid_read(rtx_scene* s, uint32_t* out, size_t n, uint32_t* grid_w, uint32_t* grid_h)
+{
+	if (!s || !grid_w || !grid_h) return fail(RTX_ERR_ARG, "scene/grid_w/grid_h is NULL");
+	const View& v = s->params.view;
+	*grid_w = ((v.width + 7) / 8 + 1) / 2; *grid_h = ((v.height + 7) / 8 + 1) / 2;
+	if (!out) return RTX_OK;
+	if (!s->costsUsable || !s->costGrid) return fail(RTX_ERR_ARG, "no cost estimate for this view");
+	const size_t cells = (size_t)*grid_w * *grid_h;
+	HIPCHK(hipSetDevice(s->device));
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(out, s->costGrid, std::min(n, 2 * cells) * sizeof(uint32_t), hipMemcpyDeviceToHost));
 	return RTX_OK;
 }
 

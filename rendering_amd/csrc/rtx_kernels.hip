@@ -1816,6 +1816,53 @@ __global__ void __launch_bounds__(256) rtxFrameClearKernel(uint32_t* __restrict_
 	for (size_t i = t; i < maskBytes; i += stride) mask[i] = 0;
 }
 
+// First-frame cost estimate (the reference renders ONE frame per process, main.cpp:15): what a tile will cost is not known
+// before it has been rendered once, so the first frame could neither start with its slow tiles nor split them.  A tile's
+// cost is mostly the leaves its rays' lines run through and the references in them (objects.cpp:587-631): every leaf's box
+// is projected through the camera and its reference count added to the cells (2 x 2 tiles) its bounding rectangle touches
+// (the TRUE box of the leaf's triangles: the cells of the reference's builder are several times larger).
+// rtxCostFillKernel turns cells into ticks per tile (coefficients fitted to measured tile costs: tools/cost_fit.py).
+// The estimate only orders and splits work; no pixel depends on it.  Measured costs replace it tile by tile.
+__global__ void __launch_bounds__(256) rtxCostSplatKernel(const float* __restrict__ boxes, uint32_t nLeaves, const View view, uint32_t gridW, uint32_t gridH,
+                                                          uint32_t* __restrict__ grid)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nLeaves) return;
+	const float* b = boxes + (size_t)i * 8;      // true box of the leaf's triangles (lo, hi), reference count
+	const uint32_t n = (uint32_t)b[6];
+	const float* M = view.camM;
+	float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f;
+	for (int c = 0; c < 8; ++c) {
+		const float px = b[(c & 1) ? 3 : 0] - view.camPos[0], py = b[(c & 2) ? 4 : 1] - view.camPos[1], pz = b[(c & 4) ? 5 : 2] - view.camPos[2];
+		// camera space: the inverse of primaryRay()'s rotation (orthonormal rMatrix, scene.cpp:22-49)
+		const float sx = px * M[0] + py * M[1] + pz * M[2], sy = px * M[4] + py * M[5] + pz * M[6], sz = px * M[8] + py * M[9] + pz * M[10];
+		if (!(sz < -1e-4f)) return;                        // reaches behind the camera: no estimate from this leaf
+		const float xp = sx / -sz, yp = sy / -sz;
+		const float fx = (xp / (view.scale * view.aspect) + 1.0f) * 0.5f * (float)view.width - 1.0f, fy = (-yp / view.scale + 1.0f) * 0.5f * (float)view.height - 1.0f;
+		x0 = fminf(x0, fx); x1 = fmaxf(x1, fx); y0 = fminf(y0, fy); y1 = fmaxf(y1, fy);
+	}
+	if (!(x1 >= 0.0f && y1 >= 0.0f && x0 < (float)view.width && y0 < (float)view.height)) return;
+	const int cx0 = max(0, (int)floorf(x0 / 16.0f)), cx1 = min((int)gridW - 1, (int)floorf(x1 / 16.0f));
+	const int cy0 = max(0, (int)floorf(y0 / 16.0f)), cy1 = min((int)gridH - 1, (int)floorf(y1 / 16.0f));
+	if ((long long)(cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 4096) return;      // (a leaf that fills the screen says nothing about where the work is)
+	for (int cy = cy0; cy <= cy1; ++cy)
+		for (int cx = cx0; cx <= cx1; ++cx) {
+			atomicAdd(grid + 2 * ((size_t)cy * gridW + cx), n);
+			atomicAdd(grid + 2 * ((size_t)cy * gridW + cx) + 1, 1u);
+		}
+}
+
+__global__ void __launch_bounds__(256) rtxCostFillKernel(const uint32_t* __restrict__ grid, uint32_t gridW, uint32_t tilesXFull, uint32_t tilesYFull,
+                                                         uint32_t* __restrict__ tileCost, float perRef, float perLeaf, float base)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= tilesXFull * tilesYFull) return;
+	const uint32_t ty = t / tilesXFull, tx = t - ty * tilesXFull;
+	const size_t cell = (size_t)(ty / 2) * gridW + tx / 2;
+	const float refs = (float)grid[2 * cell], leaves = (float)grid[2 * cell + 1];
+	tileCost[t] = leaves > 0 ? (uint32_t)fminf(base + perRef * refs + perLeaf * leaves, 4.0e9f) : 0u;
+}
+
 // klass != null (rtx_render_frame): the class of a tile is the highest one within two tiles of it (rtxTileClassKernel) --
 // the SSAA items of a slow tile can only be queued once the 5 x 5 tiles around it have been rendered.
 __global__ void __launch_bounds__(256) rtxTileClassKernel(const uint32_t* __restrict__ cost, uint32_t tilesXFull, uint32_t tilesYFull,
