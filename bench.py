@@ -7,8 +7,9 @@ framebuffer resident in HBM.  A ray = one Render::trace invocation (stats::raysC
 reflect/refract and SSAA rays; rays/frame is counted once by the instrumented kernel variant (deterministic).
 Of these, `moot_shadow_rays` are shadow rays whose answer cannot influence the pixel (Diffuse surface turned away from
 the light: vis * max(0, N.-L) is +0 either way); the timed kernels do not walk them, the frame is bit-identical.
-N > 1: rows are dealt to the ranks in 64-row bands, every frame ends with an RCCL gather to rank 0 (strong
-scaling of the same frame).  Prints ONE JSON line on rank 0.
+N > 1: rows are dealt to the ranks in bands of 64 to 256 rows (rendering_amd/parallel.py band_height), every frame ends
+with an RCCL gather to rank 0 (rtx_gather; strong scaling of the same frame), and after the timed region the gathered
+image is compared with the frame rank 0 renders alone (--no-verify skips that).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import subprocess
@@ -125,8 +126,8 @@ def cpu_baseline_port(scene_path, width, height, gpu_scene, target_s=15.0):
 # not observable with the counters at hand), falling back to 4 cycles per instruction when no stamped ISA summary exists.
 SIMDS, CLOCK_GHZ = 1024, 2.4
 VALU_PEAK_GINSTR = SIMDS * CLOCK_GHZ / 4
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pass1_pmc.json")
-ISA_JSON = os.path.join(ROOT, "profiles", "r02_pass1_isa.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pass1_pmc.json")
+ISA_JSON = os.path.join(ROOT, "profiles", "r03_pass1_isa.json")
 
 
 def stamped(path):
@@ -143,7 +144,7 @@ def stamped(path):
 
 def pmc_roofline(avg_ms, scene_bytes, fb_bytes, kernel="rtxPass1Kernel<false, true>", workload="headline"):
     """Hardware-counter side of the roofline of the dominant kernel (rtxPass1Kernel where the frame is three launches,
-    rtxFrameKernel where it is one): VALU wave-instructions and HBM-side bytes per launch from profiles/r02_pass1_pmc.json
+    rtxFrameKernel where it is one): VALU wave-instructions and HBM-side bytes per launch from profiles/r03_pass1_pmc.json
     (tools/pmc_pass1.sh: separate rocprofv3 --pmc passes of this command), over the launch duration measured live in THIS run."""
     d, why = stamped(PMC_JSON)
     if d is None:
@@ -199,7 +200,9 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ssaa", action="store_true")
-    ap.add_argument("--verify", action="store_true", help="N > 1: rank 0 also renders the whole frame alone and compares the gathered image with it")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=True,
+                    help="N > 1 (default): after the timed region rank 0 also renders the whole frame alone and compares the gathered image with it")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
     args = ap.parse_args()
     cscene, cw, ch = CONFIGS[args.config]
     custom = bool(args.scene or args.width or args.height or args.no_ssaa)
@@ -404,6 +407,11 @@ def main():
             roof["achieved"] = round(pm["valu_ginstr_s"], 1)
             roof["frac"] = round(min(pm["valu_ginstr_s"] / roof["peak"], 1.0), 4)
             roof["frac_unclamped"] = round(pm["valu_ginstr_s"] / roof["peak"], 4)
+            # against the guide's fp32 issue peak (MI355X_MICROARCH.md: a wave64 v_fma_f32 issues in 2 cycles on a SIMD-32:
+            # 1024 SIMDs x 2.4 GHz / 2): what fraction of that peak's instruction slots carry an instruction of this kernel --
+            # `frac` above divides by a peak weighted with the kernel's own (static) instruction mix and measured issue costs
+            roof["fp32_issue_peak"] = SIMDS * CLOCK_GHZ / 2
+            roof["frac_vs_fp32_issue_peak"] = round(pm["valu_ginstr_s"] / (SIMDS * CLOCK_GHZ / 2), 4)
             roof["traffic"] = pm["hbm"]["fetch_bytes"] + pm["hbm"]["write_bytes"]
         roof["counters"] = pm
     out = {

@@ -6,8 +6,9 @@
 // is copied: this file only calls its public API (scene.h:31-100, objects.h:69-164).
 //
 // Used by tools/make_golden.py to (a) validate oracle/rt_oracle.cpp bit-for-bit and (b) emit the
-// committed golden vectors under tests/golden/.  /root/reference does not exist on the GPU box, so
-// nothing in the GPU tests, smoke() or bench.py touches this library.
+// committed golden vectors under tests/golden/.  /root/reference does not exist on the GPU box: the GPU tests and
+// smoke() never touch this library; the built oracle/_ref/ travels there for ONE purpose -- bench.py's cpu_baseline leg
+// times it (kind "reference") beside the oracle port, as the measured CPU baseline.  Never on the product path.
 #include "scene.h"
 #include "stats.h"
 #include "options.h"

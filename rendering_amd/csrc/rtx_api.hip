@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <dlfcn.h>
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -22,6 +23,31 @@ using namespace rtxd;
 namespace {
 
 thread_local std::string gErr;
+
+// roctx ranges around the stages of a frame (the reference's Timer names), so that a rocprofv3 --marker-trace
+// of any caller is self-describing.  The marker library is only looked for under a profiler (ROCP_TOOL_LIBRARIES is set by
+// rocprofv3) or when RTX_ROCTX is set; without it the ranges cost one predictable branch.
+struct RoctxApi { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+const RoctxApi& roctx()
+{
+	static const RoctxApi api = [] {
+		RoctxApi a;
+		if (!getenv("ROCP_TOOL_LIBRARIES") && !getenv("RTX_ROCTX")) return a;
+		void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) return a;
+		a.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+		a.pop = (int (*)())dlsym(h, "roctxRangePop");
+		if (!a.push || !a.pop) a = RoctxApi();
+		return a;
+	}();
+	return api;
+}
+struct RoctxRange {
+	bool on;
+	explicit RoctxRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+	~RoctxRange() { if (on) roctx().pop(); }
+};
 
 int scanExclusive(uint32_t* data, uint32_t n, uint32_t* tmp, hipStream_t st, uint32_t& launches);   // rtx_bvh.hip
 
@@ -76,7 +102,7 @@ struct Knobs {
 	int pass1BlocksPerCU = 0, ssaaBlocksPerCU = 0, frameBlocksPerCU = 0;   // RTX_*_BLOCKS_PER_CU: 0 = what the occupancy allows
 	bool prune = true;                   // RTX_NO_PRUNE: no prune records (rtxd::PruneBlock)
 	bool estimate = true;                // RTX_NO_COST_ESTIMATE: no first-frame cost estimate
-	float costPerRef = 6.0f, costPerLeaf = 150.0f, costBase = 1500.0f;   // estimate = base + perRef refs + perLeaf leaves (100 MHz ticks per tile; tools/cost_fit.py)
+	float costPerRef = 2.5f, costPerLeaf = 110.0f, costBase = 8000.0f;   // estimate = base + perRef refs + perLeaf leaves (100 MHz ticks per tile; tools/cost_fit.py)
 	float fatFactor = 3.0f;              // RTX_FAT_FACTOR: bundle width, in mean triangle edges, above which a bundle is split; 0 = never
 	uint32_t stripLimit = 100000u;       // RTX_STRIP_LIMIT: a halo strip slower than this (100 MHz ticks) is listed as tiles again
 	uint32_t heavyTicks = 25000u;        // RTX_SSAA_HEAVY_TICKS: tiles above go first in the SSAA list
@@ -576,6 +602,20 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		d.ior = o.ior; d.ambient = o.ambient; d.diffuse = o.diffuse; d.specular = o.specular; d.nSpecular = o.n_specular;
 		d.r2 = o.radius2; d.mesh = o.mesh;
 	}
+	{
+		// spheres take part in the first-frame cost estimate like leaves: a mirror or a glass ball is where the deep recursions start
+		std::vector<float> sb;
+		for (uint32_t i = 0; i < desc->n_objects; i++) {
+			const rtx_object& o = desc->objects[i];
+			if (o.type != RTX_OBJ_SPHERE || !(o.radius2 > 0) || !std::isfinite(o.radius2)) continue;
+			const float r = std::sqrt(o.radius2), w = (o.material == 1 || o.material == 2) ? 4000.0f : 300.0f;
+			sb.insert(sb.end(), { o.pos[0] - r, o.pos[1] - r, o.pos[2] - r, o.pos[0] + r, o.pos[1] + r, o.pos[2] + r, w, 0.0f });
+		}
+		const float* dev = nullptr;
+		int rc0;
+		if ((rc0 = upload(s->owned, sb.data(), sb.size(), &dev))) return bail(rc0);
+		if (!sb.empty()) s->meshLeaves.push_back({ dev, (uint32_t)(sb.size() / 8) });
+	}
 	std::vector<Light> lights(desc->n_lights);
 	for (uint32_t i = 0; i < desc->n_lights; i++) {
 		const rtx_light& l = desc->lights[i];
@@ -827,6 +867,7 @@ int prepareView(rtx_scene* s)
 
 int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, void* stream)
 {
+	RoctxRange range("Render scene (rtx_render_pass1)");
 	if (!s || !fb_dev) return fail(RTX_ERR_ARG, "scene/fb is NULL");
 	const uint32_t W = s->params.view.width, H = s->params.view.height;
 	if (rowEnd > H) rowEnd = H;
@@ -881,6 +922,7 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 // The frame in one launch (rtxFrameKernel).
 static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, uint8_t* mask_dev, void* stream, bool costsKnown)
 {
+	RoctxRange range("one launch (rtxFrameKernel)");
 	const uint32_t W = s->params.view.width, H = s->params.view.height;
 	if (rowEnd > H) rowEnd = H;
 	if (rowBegin >= rowEnd) return RTX_OK;
@@ -990,6 +1032,7 @@ static int renderFrameSplit(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 // tried again every 64 frames.  The pixels are the same either way.
 int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, uint8_t* mask_dev, void* stream)
 {
+	RoctxRange range("Render scene + MSAA (rtx_render_frame)");
 	if (!s || !fb_dev || !mask_dev) return fail(RTX_ERR_ARG, "scene/fb/mask is NULL");
 	if (s->stats) return fail(RTX_ERR_UNSUPPORTED, "rtx_render_frame has no instrumented variant: use rtx_render_pass1 / rtx_sobel / rtx_render_ssaa for statistics");
 	const uint32_t W = s->params.view.width, H = s->params.view.height;
@@ -1025,7 +1068,9 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	const bool warm = tq && tq->costValid;
 	if (forced >= 0) mode = forced;
 	else if (!tq || tq->fusedGaveUp) mode = 0;
-	else if (!warm) mode = tq->listed <= 65536u ? 1 : 0;       // no costs yet (nothing can be split or ordered): by size
+	// no measured costs yet: by size -- the single launch where the frame is bounded by its slowest tiles; without meshes (cheap,
+	// even tiles: cfg3 at 1080p 2.0 ms in one launch, 1.1 in three) only for small frames
+	else if (!warm) mode = tq->listed <= (s->analytic ? 8192u : 65536u) ? 1 : 0;
 	// not measured twice each yet: in turn
 	else if (tq->frameSamples[0] < 2 || tq->frameSamples[1] < 2) mode = (int)(tq->framesSeen & 1u);
 	else {
@@ -1140,6 +1185,7 @@ int rtx_frame_status(rtx_scene* s, uint32_t* status)
 
 int rtx_sobel(rtx_scene* s, const float* fb_dev, uint32_t rowBegin, uint32_t rowEnd, uint8_t* mask_dev, void* stream)
 {
+	RoctxRange range("Sobel filter (rtx_sobel)");
 	if (!s || !fb_dev || !mask_dev) return fail(RTX_ERR_ARG, "scene/fb/mask is NULL");
 	const uint32_t W = s->params.view.width, H = s->params.view.height;
 	if (rowEnd > H) rowEnd = H;
@@ -1158,6 +1204,7 @@ int rtx_sobel(rtx_scene* s, const float* fb_dev, uint32_t rowBegin, uint32_t row
 
 int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, void* stream)
 {
+	RoctxRange range("MSAA (rtx_render_ssaa)");
 	if (!s || !fb_dev || !mask_dev) return fail(RTX_ERR_ARG, "scene/fb/mask is NULL");
 	const uint32_t W = s->params.view.width, H = s->params.view.height;
 	if (rowEnd > H) rowEnd = H;

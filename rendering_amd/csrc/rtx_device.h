@@ -39,7 +39,7 @@ static_assert(sizeof(WideNode) == 128, "wide node = two s_load_dwordx16");
 // reference against the wave's whole ray BUNDLE (box of origins x box of directions) with division-free tests on the
 // Moller-Trumbore numerators and rigorous rounding-error margins; a reference survives unless the reference renderer
 // is CERTAIN to reject it for every ray of the bundle.  Then the lanes act as 64 RAYS again and run the reference's
-// exact arithmetic on the few survivors (operands broadcast with v_readlane), in the reference's order.
+// exact arithmetic on the few survivors (operands broadcast through the LDS crossbar, ds_bpermute), in the reference's order.
 struct RefA { float v0x, v0y, v0z; uint32_t tri; };
 struct RefB { float e1x, e1y, e1z, e2x; };
 struct RefC { float e2y, e2z; };

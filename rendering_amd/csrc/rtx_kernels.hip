@@ -3,14 +3,18 @@
 // src/objects.cpp:59-175,534-631,766-824, src/lights.cpp:18-63).  Citations are file:line into the reference.
 //
 // Execution model:
-//   * persistent waves pull work items (8x8 pixel tiles, or 16 SSAA pixels x 4 samples) from an atomic queue;
-//   * the 64 lanes of a wave are 64 rays; every Render::trace of the wave is ONE cooperative walk of the
-//     pre-order node array: node boxes and leaf triangles are fetched with scalar loads (s_load_dwordx8/x16)
-//     into SGPRs, each lane runs the reference's slab test / Moller-Trumbore on its own ray;
-//   * the walk is stackless: a lane that fails a box stores the node's skip index in `resume` and sleeps
-//     until the wave's node cursor reaches it; the wave skips a subtree when the ballot of passing lanes is
-//     empty.  This visits, for every lane, exactly the nodes the reference's recursion visits, in the same
-//     order, so "strict <, first hit wins" is reproduced without a stack (objects.cpp:587-631);
+//   * persistent waves pull work items (8x8 pixel tiles, or 16 / 4 / 1 SSAA pixels x 4 samples) from atomic queues;
+//   * the 64 lanes of a wave are 64 rays = one BUNDLE; every Render::trace of the wave is ONE cooperative walk
+//     (meshWalk): the reference's tree two levels per fetch (rtxd::WideNode, scalar loads, a wave-level stack in LDS),
+//     every lane testing the slot boxes on its own ray with the reference's arithmetic; slots whose triangles no ray of
+//     the bundle can hit are dropped beforehand (rtxd::PruneBlock: pruneAlive / planeAlive, lanes acting as slots);
+//   * the references of the reached leaves are streamed 64 at a time with the lanes acting as TRIANGLES: the bundle
+//     filter (bundleRejects1/2) keeps what some ray might hit, the survivors are tested exactly (the reference's
+//     Moller-Trumbore, operation by operation) with the lanes acting as rays again, in the reference's order --
+//     "strict <, first hit wins" (objects.cpp:587-631);
+//   * trees that do not allow the wide walk (boxes not nested, culling off, a zero direction component, the
+//     instrumented variant) take the stackless binary walk: a lane that fails a box sleeps until the wave's cursor
+//     reaches the node's skip index;
 //   * castRay's recursion is an explicit per-lane frame stack in HBM ([slot][field][lane], coalesced) so the
 //     nested colour expressions keep the reference's association order (scene.cpp:858-940).
 //
@@ -520,7 +524,7 @@ __device__ __forceinline__ bool bundleRejects2(const Bundle& B, const RefA& ra, 
 }
 
 // The reference's test (objects.cpp:59-95) of the rays in exec against ONE triangle whose record is wave-uniform (read
-// from the surviving lane with v_readlane): the reference's own arithmetic, operation by operation.
+// from the surviving lane through the LDS crossbar, ds_bpermute): the reference's own arithmetic, operation by operation.
 template <bool CULL, bool STATS>
 __device__ __forceinline__ void triTestOne(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
                                            uint32_t tri, const V3& o, const V3& d, float& bt, float& bu, float& bv, uint32_t& btri)
