@@ -397,6 +397,9 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		const bool pruneWanted = s->knobs.prune;
 		std::vector<PruneBlock> prune;
 		float vmaxMesh = 0;
+		PruneRec rootRec;
+		memset(&rootRec, 0, sizeof(rootRec));
+		rootRec.h[0] = rootRec.h[1] = rootRec.h[2] = INFINITY; rootRec.P = INFINITY;
 		std::vector<std::array<uint32_t, 4>> slotNode;      // binary node behind every wide-node slot
 		constexpr uint32_t kNoNode = 0xffffffffu;
 		if (boxesRegular && m.n_nodes > 0) {
@@ -486,6 +489,22 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 						a.wlo = std::min(a.wlo, w); a.whi = std::max(a.whi, w);
 					}
 				}
+				auto makeRec = [&](const Agg& a, PruneRec& pr) {
+					memset(&pr, 0, sizeof(pr));
+					pr.h[0] = pr.h[1] = pr.h[2] = -1e30f;      // empty: nothing can meet it
+					if (!(a.lo[0] <= a.hi[0])) return;         // no triangles
+					bool finite = std::isfinite(a.ps);
+					for (int c = 0; c < 3; c++) finite = finite && std::isfinite(a.lo[c]) && std::isfinite(a.hi[c]);
+					if (!finite) { pr.h[0] = pr.h[1] = pr.h[2] = INFINITY; pr.P = INFINITY; return; }      // never pruned
+					for (int c = 0; c < 3; c++) {
+						const double mid = 0.5 * (a.lo[c] + a.hi[c]), big = std::max(std::fabs(a.lo[c]), std::fabs(a.hi[c]));
+						pr.c[c] = (float)mid;
+						// [c - h, c + h] really contains [lo, hi] (c is rounded, h rounded up)
+						pr.h[c] = (float)((0.5 * (a.hi[c] - a.lo[c]) + std::fabs((double)pr.c[c] - mid)) * (1.0 + 0x1p-20) + 0x1p-24 * big + 1e-37);
+					}
+					pr.P = (float)(a.ps * (1.0 + 0x1p-20) + 1e-37);
+				};
+				makeRec(agg[0], rootRec);
 				prune.resize(wide.size());
 				for (int c = 0; c < 3; c++) vmaxMesh = std::max(vmaxMesh, (float)std::max(std::fabs(agg[0].lo[c]), std::fabs(agg[0].hi[c])));
 				for (size_t wi = 0; wi < wide.size(); wi++)
@@ -498,17 +517,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 						const uint32_t nd = slotNode[wi][k];
 						if (nd == kNoNode) continue;
 						const Agg& a = agg[nd];
-						if (!(a.lo[0] <= a.hi[0])) continue;       // no triangles below this slot
-						bool finite = std::isfinite(a.ps);
-						for (int c = 0; c < 3; c++) finite = finite && std::isfinite(a.lo[c]) && std::isfinite(a.hi[c]);
-						if (!finite) { pr.h[0] = pr.h[1] = pr.h[2] = INFINITY; pr.P = INFINITY; continue; }      // never pruned
-						for (int c = 0; c < 3; c++) {
-							const double mid = 0.5 * (a.lo[c] + a.hi[c]), big = std::max(std::fabs(a.lo[c]), std::fabs(a.hi[c]));
-							pr.c[c] = (float)mid;
-							// [c - h, c + h] really contains [lo, hi] (c is rounded, h rounded up)
-							pr.h[c] = (float)((0.5 * (a.hi[c] - a.lo[c]) + std::fabs((double)pr.c[c] - mid)) * (1.0 + 0x1p-20) + 0x1p-24 * big + 1e-37);
-						}
-						pr.P = (float)(a.ps * (1.0 + 0x1p-20) + 1e-37);
+						makeRec(a, pr);
+						if (!(a.lo[0] <= a.hi[0]) || !std::isfinite(pr.P)) continue;
 						if (a.planes && a.wlo <= a.whi && std::isfinite(a.wlo) && std::isfinite(a.whi)) {
 							for (int c = 0; c < 3; c++) {
 								const double mid = 0.5 * (a.qlo[c] + a.qhi[c]);
@@ -555,7 +565,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		dm.nWide = (uint32_t)wide.size();
 		if ((rc = upload(s->owned, prune.data(), prune.size(), &dm.prune))) return bail(rc);
 		dm.vmax = vmaxMesh;
-		if (!(vmaxMesh < 0x1p40f)) dm.prune = nullptr;      // (huge or non-finite coordinates: nothing is pruned)
+		dm.rootRec = rootRec;
+		if (!(vmaxMesh < 0x1p40f)) { dm.prune = nullptr; dm.rootRec.h[0] = dm.rootRec.h[1] = dm.rootRec.h[2] = INFINITY; }      // (huge or non-finite coordinates: nothing is pruned)
 		if ((rc = upload(s->owned, refA.data(), refA.size(), &dm.refA))) return bail(rc);
 		if ((rc = upload(s->owned, refB.data(), refB.size(), &dm.refB))) return bail(rc);
 		if ((rc = upload(s->owned, refC.data(), refC.size(), &dm.refC))) return bail(rc);
@@ -601,6 +612,13 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		memcpy(d.pos, o.pos, 12); memcpy(d.color, o.color, 12); memcpy(d.normal, o.normal, 12);
 		d.ior = o.ior; d.ambient = o.ambient; d.diffuse = o.diffuse; d.specular = o.specular; d.nSpecular = o.n_specular;
 		d.r2 = o.radius2; d.mesh = o.mesh;
+		if (o.type == RTX_OBJ_MESH) {
+			const Mesh& dm = meshes[o.mesh];
+			const rtx_mesh& hm = desc->meshes[o.mesh];
+			for (int c = 0; c < 3; c++) { d.rootBox[2 * c] = hm.n_nodes ? hm.node_bounds[c] : 0.0f; d.rootBox[2 * c + 1] = hm.n_nodes ? hm.node_bounds[3 + c] : 0.0f; }
+			d.fatRadius = dm.fatRadius; memcpy(d.centre, dm.centre, 12); d.radius = dm.radius;
+			d.meshFlags = (hm.n_nodes ? 1u : 0u) | (dm.boxesRegular ? 2u : 0u) | (dm.nWide ? 4u : 0u);
+		}
 	}
 	{
 		// spheres take part in the first-frame cost estimate like leaves: a mirror or a glass ball is where the deep recursions start

@@ -82,6 +82,7 @@ struct Mesh {
 	uint32_t nWide, padw;
 	const PruneBlock* prune;   // one per wide node, or null
 	float vmax, padv;          // largest |vertex coordinate| of the mesh
+	PruneRec rootRec;          // the PruneRec of the whole mesh (h = +inf: none): a ray whose segment misses it takes no part in the walk
 	// bundle splitting (rtx_kernels.hip, traceWave): a wave's rays are walked as ONE bundle unless the bundle is wider than
 	// fatRadius at this mesh (a few mean triangle edges); centre / radius = bounding sphere of the root box
 	float fatRadius, centre[3], radius;
@@ -96,10 +97,16 @@ struct Object {
 	int32_t mesh;
 	float color[3];
 	float ior, ambient, diffuse, specular, nSpecular;
-	uint32_t pad[14];
+	// Meshes: what Render::trace needs before it decides to walk (a copy of the Mesh's fields: the second s_load_dwordx16 of the
+	// record instead of a chain of dependent loads -- object -> mesh -> node array -> root node)
+	float rootBox[6];          // lo.x hi.x | lo.y hi.y | lo.z hi.z of node 0
+	float fatRadius, centre[3], radius;
+	uint32_t meshFlags;        // bit 0: the mesh has nodes, 1: boxesRegular, 2: the wide walk is available
+	uint32_t pad[2];
 };
 static_assert(sizeof(Object) == 128, "object record = two 64-byte lines");
 
+// 64 bytes: one s_load_dwordx16 when the lanes of a wave are at the same light (the usual case).
 struct Light {
 	int32_t type;
 	float color[3];
@@ -108,7 +115,9 @@ struct Light {
 	float pos[3];
 	uint32_t nPoints;
 	const float* points;
+	uint32_t pad[2];
 };
+static_assert(sizeof(Light) == 64, "light record = one 64-byte line");
 
 struct View {
 	uint32_t width, height;

@@ -606,7 +606,7 @@ __device__ __forceinline__ void triTestLane(const RefA& ra, const RefB& rb, cons
 #define RTX_MAX_SPLITS 4          // halvings of a wide bundle
 #endif
 #ifndef RTX_LEAF_BATCH
-#define RTX_LEAF_BATCH 8
+#define RTX_LEAF_BATCH 4
 #endif
 // one reached leaf: first reference, number of references, the lanes (rays) that passed its box, start in the batch's stream
 struct LeafEntry { uint32_t start, count, first, pad0, maskLo, maskHi, pad1, pad2; };      // (what the assignment of a pass needs arrives with one 16-byte read)
@@ -623,6 +623,9 @@ __shared__ WideItem wideStack[4][64];
 __shared__ float pruneUni[4][16];
 #ifndef RTX_PRUNE
 #define RTX_PRUNE 1
+#endif
+#ifndef RTX_PRUNE_RAYS
+#define RTX_PRUNE_RAYS 0      // per ray: the segment against the mesh's own PruneRec before the walk (measured: -1 %, the walk's first visit does it as well)
 #endif
 #ifndef RTX_PRUNE_ROOT
 #define RTX_PRUNE_ROOT 0      // 1: the prune records of the root's slots are evaluated too
@@ -1121,24 +1124,25 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 		if (ballot(consider) == 0) continue;
 		if (MESH && type == 3) {
 			const Mesh* M = uni(P.meshes + (int)rec[9]);
+			const u32x16 rec2 = sload16((const char*)ob + 64);      // specular, nSpecular, rootBox[6], fatRadius, centre[3], radius, meshFlags
 			// The rays are walked as one bundle (meshWalk) -- unless the bundle is too wide at this mesh for the bundle
 			// filter to reject much (rays of a silhouette tile that hit different objects, a grazing strip of shadow-ray
 			// origins, coarse frames): then the lanes on one side of the middle of the widest axis go first, the others
 			// later, halving until the bundle is narrow.  Which lanes walk together changes the amount of work only.
-			const float fat = sloadf(&M->fatRadius), mrad = sloadf(&M->radius);
-			const float mcx = sloadf(&M->centre[0]), mcy = sloadf(&M->centre[1]), mcz = sloadf(&M->centre[2]);
+			const float fat = F(rec2[8]), mrad = F(rec2[12]);
+			const float mcx = F(rec2[9]), mcy = F(rec2[10]), mcz = F(rec2[11]);
+			const uint32_t mflags = rec2[13];
 			// Rays that fail the root box (objects.cpp:590) take no further part: the bundles are formed by the others.
 			bool pending = consider;
 			// the min / max form of the box test (meshWalk<.., REGULAR>) is exact when no NaN can arise: regular boxes, finite
 			// origins and finite 1 / dir for every ray of the wave
-			const bool regular = uni(sload1(&M->boxesRegular)) != 0 &&
+			const bool regular = (mflags & 2u) != 0 &&
 			                     ballot(consider && !(fabsf(ix) < __builtin_inff() && fabsf(iy) < __builtin_inff() && fabsf(iz) < __builtin_inff() &&
 			                                          fabsf(o.x) < 0x1p100f && fabsf(o.y) < 0x1p100f && fabsf(o.z) < 0x1p100f)) == 0;
-			const bool wideOk = RTX_WIDE && uni(sload1(&M->nWide)) != 0;
-			if (uni(sload1(&M->nNodes)) != 0) {
-				const u32x8 rn = sload8(uni((const Node*)sloadp(&M->nodes)));
-				const float xlo = (F(rn[0]) - o.x) * ix, xhi = (F(rn[1]) - o.x) * ix, ylo = (F(rn[2]) - o.y) * iy, yhi = (F(rn[3]) - o.y) * iy;
-				const float zlo = (F(rn[4]) - o.z) * iz, zhi = (F(rn[5]) - o.z) * iz;
+			const bool wideOk = RTX_WIDE && (mflags & 4u) != 0;
+			if ((mflags & 1u) != 0) {
+				const float xlo = (F(rec2[2]) - o.x) * ix, xhi = (F(rec2[3]) - o.x) * ix, ylo = (F(rec2[4]) - o.y) * iy, yhi = (F(rec2[5]) - o.y) * iy;
+				const float zlo = (F(rec2[6]) - o.z) * iz, zhi = (F(rec2[7]) - o.z) * iz;
 				float tmin = sx ? xhi : xlo, tmx = sx ? xlo : xhi;
 				const float tymin = sy ? yhi : ylo, tymax = sy ? ylo : yhi;
 				bool fail = (tmin > tymax) || (tymin > tmx);
@@ -1148,6 +1152,29 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 				fail = fail || (tmin > tzmax) || (tzmin > tmx);
 				if (STATS) cnt.box += __popcll(ballot(consider && fail));       // (their root-box test is still a test of the reference)
 				pending = consider && !fail;
+#if RTX_PRUNE && RTX_PRUNE_RAYS
+				// A ray whose SEGMENT [0, limit] stays clear of the mesh's true box (inflated by how far the reference's accepted hit
+				// can lie from its triangle: pruneAlive, here per ray with the ray's own dmax / ainf) cannot be given a hit by this
+				// mesh: it takes no part in the walk.  Most shadow rays that start on the floor in front of the mesh end here --
+				// their LINE meets the root box, which is all the reference's test asks (objects.cpp:534-570).
+				if (!STATS && cull) {
+					const u32x8 rr = sload8(&M->rootRec);      // c.xyz, P, h.xyz, -
+					const float ainf = fmaxf(fmaxf(fabsf(o.x - F(rr[0])) + F(rr[4]), fabsf(o.y - F(rr[1])) + F(rr[5])), fabsf(o.z - F(rr[2])) + F(rr[6]));
+					const float dmx = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), omx = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+					const float rho = __builtin_fmaf(kPruneC * dmx * ainf, F(rr[3]), 0x1p-17f * (ainf + omx)) * (1.0f + 0x1p-20f) + 1e-30f;
+					const float hx = F(rr[4]) + rho, hy = F(rr[5]) + rho, hz = F(rr[6]) + rho;
+					const float ax = ((F(rr[0]) - hx) - o.x) * ix, bx = ((F(rr[0]) + hx) - o.x) * ix;
+					const float ay = ((F(rr[1]) - hy) - o.y) * iy, by = ((F(rr[1]) + hy) - o.y) * iy;
+					const float az = ((F(rr[2]) - hz) - o.z) * iz, bz = ((F(rr[2]) + hz) - o.z) * iz;
+					// (fminf / fmaxf drop a NaN operand -- 0 * inf on an axis the ray does not move along: that axis does not constrain)
+					const float ent = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), ext = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+					// (only rays with three finite 1 / dir: with a zero component an origin exactly on a face of the inflated box would
+					// make 0 * inf of one face and +-inf of the other, and the dropped NaN would leave the wrong one)
+					const bool tameRay = omx < 0x1p40f && dmx < 0x1p20f && fabsf(ix) < __builtin_inff() && fabsf(iy) < __builtin_inff() && fabsf(iz) < __builtin_inff();
+					const bool clear = ent > ext || ext < 0.0f || ent > h.t * (1.0f + 0x1p-18f);
+					pending = pending && !(clear && tameRay);
+				}
+#endif
 			}
 			while (ballot(pending) != 0) {
 				bool cl = pending;
@@ -1229,35 +1256,36 @@ __device__ __forceinline__ float& frameAt(const Params& P, uint32_t gl, int slot
 	return P.frames[((size_t)slot * kFrameFields + field) * P.totalLanes + gl];
 }
 
-__device__ __forceinline__ void shadePrimary(const Params& P, Lane& s, const Hit& h)
+// One object's part of shadePrimary: the object's record `a` / `b` (its two 64-byte halves) is wave-uniform.
+__device__ __forceinline__ void shadeObject(const Params& P, Lane& s, const Hit& h, const u32x16& a, const u32x16& b)
 {
-	// scene.cpp:763-775 + Object::getSurfaceData overrides
-	const Object* ob = P.objects + h.obj;
-	s.obj = h.obj;
-	s.mat = ob->material;
-	s.objColor = mk(ob->color[0], ob->color[1], ob->color[2]);
-	s.specCoef = ob->specular;
-	s.nSpec = ob->nSpecular;
-	s.P = s.ro + s.rd * h.t;
-	const int type = ob->type;
-	if (type == 1) s.N = normalized(s.P - mk(ob->pos[0], ob->pos[1], ob->pos[2]));          // objects.cpp:788-796
-	else if (type == 2) s.N = mk(ob->normal[0], ob->normal[1], ob->normal[2]);             // objects.cpp:816-824
+	s.mat = (int)a[1];
+	s.objColor = mk(F(a[10]), F(a[11]), F(a[12]));
+	s.specCoef = F(b[0]);
+	s.nSpec = F(b[1]);
+	const int type = (int)a[0];
+	if (type == 1) s.N = normalized(s.P - mk(F(a[2]), F(a[3]), F(a[4])));          // objects.cpp:788-796
+	else if (type == 2) s.N = mk(F(a[6]), F(a[7]), F(a[8]));                       // objects.cpp:816-824
 	else {
 		// Mesh::getSurfaceData, objects.cpp:121-151
-		const Mesh* M = P.meshes + ob->mesh;
-		const GlobalFloats uvp = inGlobal(M->uv) + (size_t)h.tri * 6;
-		const GlobalFloats np = inGlobal(M->nrm) + (size_t)h.tri * 9;
+		const Mesh* M = uni(P.meshes + (int)a[9]);
+		const GlobalFloats uvp = inGlobal((const float*)sloadp(&M->uv)) + (size_t)h.tri * 6;
+		const GlobalFloats np = inGlobal((const float*)sloadp(&M->nrm)) + (size_t)h.tri * 9;
+		const float* normalMap = (const float*)sloadp(&M->normal);
+		const float* diffuseMap = (const float*)sloadp(&M->diffuse);
+		const float* specularMap = (const float*)sloadp(&M->specular);
 		const float u = h.u, v = h.v;
 		const float w = 1 - u - v;
 		const float texx = uvp[2] * u + uvp[4] * v + uvp[0] * w;
 		const float texy = uvp[3] * u + uvp[5] * v + uvp[1] * w;
 		V3 n = (load3(np + 3) * u + load3(np + 6) * v + load3(np) * (1 - u - v)) / 3;
 		n = normalized(n);
-		if (M->normal) {
-			const GlobalFloats tbp = inGlobal(M->tb) + (size_t)h.tri * 6;
-			const int x = texel((int)M->nW, texx), y = texel((int)M->nH, texy);
+		if (normalMap) {
+			const GlobalFloats tbp = inGlobal((const float*)sloadp(&M->tb)) + (size_t)h.tri * 6;
+			const uint32_t nW = sload1(&M->nW), nH = sload1(&M->nH);
+			const int x = texel((int)nW, texx), y = texel((int)nH, texy);
 			// normalise(texel as loaded): the reference's in-place re-normalisation race is resolved this way
-			const V3 tn = normalized(load3(inGlobal(M->normal) + ((size_t)y * M->nW + x) * 3));
+			const V3 tn = normalized(load3(inGlobal(normalMap) + ((size_t)y * nW + x) * 3));
 			V3 r;
 			r.x = tn.x * tbp[0] + tn.y * tbp[3] + tn.z * n.x + 0.0f;
 			r.y = tn.x * tbp[1] + tn.y * tbp[4] + tn.z * n.y + 0.0f;
@@ -1265,14 +1293,37 @@ __device__ __forceinline__ void shadePrimary(const Params& P, Lane& s, const Hit
 			n = normalized(r);
 		}
 		s.N = n;
-		if (M->diffuse)                                     // Mesh::getDiffuseColor, objects.cpp:153-163
-			s.objColor = load3(inGlobal(M->diffuse) + ((size_t)texel((int)M->dH, texy) * M->dW + texel((int)M->dW, texx)) * 3);
-		if (M->specular)                                    // Mesh::getSpecularValue, objects.cpp:165-175
-			s.specCoef = inGlobal(M->specular)[(size_t)texel((int)M->sH, texy) * M->sW + texel((int)M->sW, texx)];
+		if (diffuseMap) {                                   // Mesh::getDiffuseColor, objects.cpp:153-163
+			const uint32_t dW = sload1(&M->dW), dH = sload1(&M->dH);
+			s.objColor = load3(inGlobal(diffuseMap) + ((size_t)texel((int)dH, texy) * dW + texel((int)dW, texx)) * 3);
+		}
+		if (specularMap) {                                  // Mesh::getSpecularValue, objects.cpp:165-175
+			const uint32_t sW = sload1(&M->sW), sH = sload1(&M->sH);
+			s.specCoef = inGlobal(specularMap)[(size_t)texel((int)sH, texy) * sW + texel((int)sW, texx)];
+		}
+	}
+}
+
+__device__ __forceinline__ void shadePrimary(const Params& P, Lane& s, const Hit& h)
+{
+	// scene.cpp:763-775 + Object::getSurfaceData overrides.  The lanes that are here hit one object, sometimes two: the object's
+	// record (and a mesh's array pointers) come through the scalar unit, once per distinct object (instead of a chain of
+	// dependent per-lane loads: object -> mesh -> arrays).
+	s.obj = h.obj;
+	s.P = s.ro + s.rd * h.t;
+	for (uint64_t rem = ballot(true); rem != 0;) {
+		const int o0 = __builtin_amdgcn_readlane(h.obj, __builtin_ctzll(rem));
+		const Object* ob = uni(P.objects + o0);
+		const u32x16 a = sload16(ob), b = sload16((const char*)ob + 64);
+		const bool mine = h.obj == o0;
+		if (mine) shadeObject(P, s, h, a, b);
+		rem &= ~ballot(mine);
 	}
 	s.diff = mk(0, 0, 0); s.spec = mk(0, 0, 0);
 	s.li = 0; s.si = 0; s.dsum = 0; s.ssum = 0;
 }
+
+struct LightRec { int type; V3 color; float intensity; V3 dir, pos; uint32_t nPoints; const float* points; };
 
 // Runs the lane's castRay state machine until it needs a Render::trace (returns true) or is finished.
 __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
@@ -1290,26 +1341,41 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 		if (s.state == ST_NEXT_LIGHT) {
 			RTX_T0
 			if (s.li >= P.nLights) { s.state = ST_LIGHTS_DONE; continue; }
-			const Light* l = P.lights + s.li;
+			// The light's record: the lanes that are here are nearly always at the same light -- then it comes through the scalar
+			// unit in one load (the per-lane form is a chain of dependent vector loads: type, then the fields of that type).
+			LightRec lr;
+			const uint32_t li0 = __builtin_amdgcn_readfirstlane(s.li);
+			if (ballot(s.li != li0) == 0) {
+				const u32x16 w = sload16(P.lights + li0);
+				lr.type = (int)w[0]; lr.color = mk(F(w[1]), F(w[2]), F(w[3])); lr.intensity = F(w[4]);
+				lr.dir = mk(F(w[5]), F(w[6]), F(w[7])); lr.pos = mk(F(w[8]), F(w[9]), F(w[10])); lr.nPoints = w[11];
+				lr.points = (const float*)(((uint64_t)w[13] << 32) | w[12]);
+			}
+			else {
+				const Light* lp = P.lights + s.li;
+				lr.type = lp->type; lr.color = mk(lp->color[0], lp->color[1], lp->color[2]); lr.intensity = lp->intensity;
+				lr.dir = mk(lp->dir[0], lp->dir[1], lp->dir[2]); lr.pos = mk(lp->pos[0], lp->pos[1], lp->pos[2]); lr.nPoints = lp->nPoints; lr.points = lp->points;
+			}
+			const LightRec* l = &lr;
 			const int lt = l->type;
 			float dist;
 			if (lt == 1) {                 // DistantLight::illuminate, lights.cpp:18-23
-				s.L = mk(l->dir[0], l->dir[1], l->dir[2]);
-				s.I = mk(l->color[0], l->color[1], l->color[2]) * l->intensity;
+				s.L = l->dir;
+				s.I = l->color * l->intensity;
 				dist = kFltMax;
 			}
 			else if (lt == 2) {            // PointLight::illuminate, lights.cpp:32-38
-				const V3 lp = mk(l->pos[0], l->pos[1], l->pos[2]);
+				const V3 lp = l->pos;
 				V3 L = s.P - lp;
-				s.I = mk(l->color[0], l->color[1], l->color[2]) * attenuation(l->intensity, len2(L));
+				s.I = l->color * attenuation(l->intensity, len2(L));
 				s.L = normalized(L);
 				dist = length(s.P - lp);
 			}
 			else {                         // area light sample loop, scene.cpp:790-806 etc.
 				const uint32_t np = l->nPoints;
 				if (s.si == 0) {
-					const V3 lp = mk(l->pos[0], l->pos[1], l->pos[2]);
-					s.I = mk(l->color[0], l->color[1], l->color[2]) * attenuation(l->intensity, len2(s.P - lp));
+					const V3 lp = l->pos;
+					s.I = l->color * attenuation(l->intensity, len2(s.P - lp));
 					s.dsum = 0; s.ssum = 0;
 				}
 				if (s.si >= np) {
@@ -1415,7 +1481,8 @@ __device__ __forceinline__ void consume(const Params& P, Lane& s, const Hit& h)
 	if (s.state == ST_WAIT_SHADOW) {
 		RTX_T0
 		const float vis = (h.obj < 0) ? 1.0f : 0.0f;       // bool vis = !trace(...)
-		const bool area = P.lights[s.li].type == 3;
+		const uint32_t li0 = __builtin_amdgcn_readfirstlane(s.li);
+		const bool area = ballot(s.li != li0) == 0 ? (int)sload1(&P.lights[li0].type) == 3 : P.lights[s.li].type == 3;
 		const V3 nL = -s.L;
 		if (s.mat == 0) {
 			const float c = vis * fmaxRef(0.f, dot(s.N, nL));
