@@ -618,6 +618,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			for (int c = 0; c < 3; c++) { d.rootBox[2 * c] = hm.n_nodes ? hm.node_bounds[c] : 0.0f; d.rootBox[2 * c + 1] = hm.n_nodes ? hm.node_bounds[3 + c] : 0.0f; }
 			d.fatRadius = dm.fatRadius; memcpy(d.centre, dm.centre, 12); d.radius = dm.radius;
 			d.meshFlags = (hm.n_nodes ? 1u : 0u) | (dm.boxesRegular ? 2u : 0u) | (dm.nWide ? 4u : 0u);
+			d.nodes = dm.nodes; d.refA = dm.refA; d.refB = dm.refB; d.refC = dm.refC; d.wide = dm.wide; d.prune = dm.prune;
+			d.nNodes = dm.nNodes; d.vmax = dm.vmax;
 		}
 	}
 	{

@@ -88,7 +88,7 @@ struct Mesh {
 	float fatRadius, centre[3], radius;
 };
 
-// 128 bytes; everything Render::trace needs (the first ten dwords) arrives with ONE s_load_dwordx16.
+// 192 bytes = three s_load_dwordx16 issued together; everything Render::trace needs of a sphere or a plane is in the first.
 struct Object {
 	int32_t type, material;
 	float pos[3];
@@ -103,8 +103,11 @@ struct Object {
 	float fatRadius, centre[3], radius;
 	uint32_t meshFlags;        // bit 0: the mesh has nodes, 1: boxesRegular, 2: the wide walk is available
 	uint32_t pad[2];
+	// third line (meshes): what the walk itself needs
+	const Node* nodes; const RefA* refA; const RefB* refB; const RefC* refC; const struct WideNode* wide; const struct PruneBlock* prune;
+	uint32_t nNodes; float vmax; uint32_t pad3[2];
 };
-static_assert(sizeof(Object) == 128, "object record = two 64-byte lines");
+static_assert(sizeof(Object) == 192, "object record = three 64-byte lines");
 
 // 64 bytes: one s_load_dwordx16 when the lanes of a wave are at the same light (the usual case).
 struct Light {

@@ -721,15 +721,17 @@ __device__ __forceinline__ bool planeAlive(const f4v& r0, const f4v& r1, const B
 }
 
 template <bool STATS, bool CULL, bool REGULAR, bool WIDE = false, bool FEWRAYS = false>
-__device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
+__device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
                                          float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
                                          float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
 {
-	const Node* nodes = uni((const Node*)sloadp(&M->nodes));
-	const RTX_AS1 char* refA = (const RTX_AS1 char*)(uintptr_t)uni((const RefA*)sloadp(&M->refA));
-	const RTX_AS1 char* refB = (const RTX_AS1 char*)(uintptr_t)uni((const RefB*)sloadp(&M->refB));
-	const RTX_AS1 char* refC = (const RTX_AS1 char*)(uintptr_t)uni((const RefC*)sloadp(&M->refC));
-	const uint32_t nN = uni(sload1(&M->nNodes));
+	// mp = the third line of the object's record (rtxd::Object): nodes, refA, refB, refC, wide, prune, nNodes, vmax
+#define RTX_MP(k) (((uint64_t)mp[2 * (k) + 1] << 32) | mp[2 * (k)])
+	const Node* nodes = (const Node*)RTX_MP(0);
+	const RTX_AS1 char* refA = (const RTX_AS1 char*)(uintptr_t)RTX_MP(1);
+	const RTX_AS1 char* refB = (const RTX_AS1 char*)(uintptr_t)RTX_MP(2);
+	const RTX_AS1 char* refC = (const RTX_AS1 char*)(uintptr_t)RTX_MP(3);
+	const uint32_t nN = mp[12];
 	bt = kFltMax; bu = 0; bv = 0; btri = 0;
 	if (nN == 0) return;
 	// the largest limit of any ray of the wave: a triangle whose t is certainly not below it cannot be recorded by any
@@ -745,12 +747,13 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 	// fetch per two levels.  The items carry the rays that passed their own box, so nothing per lane has to remember where
 	// it is in the tree; `resume` only marks the rays that are done.
 	WideItem* stack = wideStack[threadIdx.x >> 6];
-	const WideNode* wideNodes = WIDE ? uni((const WideNode*)sloadp(&M->wide)) : nullptr;
+	const WideNode* wideNodes = WIDE ? (const WideNode*)RTX_MP(4) : nullptr;
 	uint32_t sp = 0;
 	const RTX_AS1 char* pruneRecs = nullptr;
 	float* pu = pruneUni[threadIdx.x >> 6];
 	if (WIDE && RTX_PRUNE) {
-		pruneRecs = (const RTX_AS1 char*)(uintptr_t)uni((const PruneBlock*)sloadp(&M->prune));
+		pruneRecs = (const RTX_AS1 char*)(uintptr_t)RTX_MP(5);
+#undef RTX_MP
 		if (pruneRecs != nullptr) {
 			// Range of 1 / dir over the rays of this walk, from the bundle's direction box (every ray's direction lies in dc +- rd):
 			// 1 / x is monotone on either side of 0, so every lane's RN(1 / d) lies between the reciprocals of the box's ends --
@@ -784,7 +787,7 @@ __device__ __forceinline__ void meshWalk(const Mesh* M, const Bundle& B, bool co
 				e.x = B.kd * (kPruneC / kFilterK);      // 216 dmax (kd = K dmax, rounded up)
 				e.y = fmaxf(fmaxf(fabsf(B.ocx) + B.rox, fabsf(B.ocy) + B.roy), fabsf(B.ocz) + B.roz);
 				e.z = __uint_as_float((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u) | (okx ? 8u : 0u) | (oky ? 16u : 0u) | (okz ? 32u : 0u));
-				e.w = kFilterK * (e.y + sloadf(&M->vmax)) * (1.0f + 0x1p-20f) + 1e-30f;      // K (|orig| + |vertex|): see planeAlive
+				e.w = kFilterK * (e.y + F(mp[13])) * (1.0f + 0x1p-20f) + 1e-30f;      // K (|orig| + |vertex|): see planeAlive
 				*(f4v*)(pu + 0) = a; *(f4v*)(pu + 4) = b; *(f4v*)(pu + 8) = c; *(f4v*)(pu + 12) = e;
 			}
 			if (!B.sane) pruneRecs = nullptr;      // NaN / inf / huge coordinates somewhere in the bundle: nothing is pruned
@@ -1125,6 +1128,7 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 		if (MESH && type == 3) {
 			const Mesh* M = uni(P.meshes + (int)rec[9]);
 			const u32x16 rec2 = sload16((const char*)ob + 64);      // specular, nSpecular, rootBox[6], fatRadius, centre[3], radius, meshFlags
+			const u32x16 rec3 = sload16((const char*)ob + 128);     // nodes, refA, refB, refC, wide, prune, nNodes, vmax
 			// The rays are walked as one bundle (meshWalk) -- unless the bundle is too wide at this mesh for the bundle
 			// filter to reject much (rays of a silhouette tile that hit different objects, a grazing strip of shadow-ray
 			// origins, coarse frames): then the lanes on one side of the middle of the widest axis go first, the others
@@ -1192,10 +1196,10 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 					B = makeBundle(cl, o, d);
 				}
 				float bt, bu, bv; uint32_t btri;
-				if (!STATS && cull && regular && wideOk) meshWalk<STATS, true, true, true, FEWRAYS>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
-				else if (cull && regular) meshWalk<STATS, true, true, false, FEWRAYS>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
-				else if (cull) meshWalk<STATS, true, false, false, FEWRAYS>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
-				else meshWalk<STATS, false, false, false, FEWRAYS>(M, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				if (!STATS && cull && regular && wideOk) meshWalk<STATS, true, true, true, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				else if (cull && regular) meshWalk<STATS, true, true, false, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				else if (cull) meshWalk<STATS, true, false, false, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				else meshWalk<STATS, false, false, false, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				if (cl && bt < kFltMax && bt < h.t) { h.obj = (int)oi; h.t = bt; h.tri = btri; h.u = bu; h.v = bv; }   // scene.cpp:740-745
 				pending = pending && !cl;
 			}
