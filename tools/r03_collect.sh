@@ -1,0 +1,28 @@
+#!/bin/bash
+# GPU box: the round's profiles for the CURRENT sources -- PMC counters (tools/pmc_pass1.sh), bench lines plain and under
+# rocprofv3 --kernel-trace --stats (headline + cfg2), all BASELINE configs, RTX_DBG wave-level counts with and without the
+# prune records, shard emulation.  Results under gpurun_out/r03/ (copied to profiles/ by tools/r03_copy.sh).
+cd ${GRAFT_REPO_ROOT:-.}
+O=gpurun_out/r03; mkdir -p $O
+bash tools/pmc_pass1.sh r03 > $O/pmc.log 2>&1
+python bench.py > $O/bench_default.log 2>&1; grep '^{' $O/bench_default.log > $O/r03_bench_default.json
+python bench.py --config cfg2 --no-cpu-baseline 2>&1 | grep '^{' > $O/r03_bench_cfg2.json
+bash tools/profile.sh r03 --steps 5 --warmup 1 > $O/profile_headline.log 2>&1
+cp $(find gpurun_out/prof_r03 -name '*kernel_stats.csv' | head -1) $O/r03_kernel_stats.csv; cp gpurun_out/prof_r03/bench.json $O/r03_bench_under_rocprof.json
+bash tools/profile.sh r03cfg2 --config cfg2 --steps 5 --warmup 1 > $O/profile_cfg2.log 2>&1
+cp $(find gpurun_out/prof_r03cfg2 -name '*kernel_stats.csv' | head -1) $O/r03_kernel_stats_cfg2.csv; cp gpurun_out/prof_r03cfg2/bench.json $O/r03_bench_cfg2_under_rocprof.json
+: > $O/r03_configs.txt
+for c in cfg1 cfg2 cfg3 cfg4 cfg5; do
+  python bench.py --no-cpu-baseline --config $c 2>/dev/null | grep '^{' | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); c=d['config']
+print('$c', c['workload'], '|', d['value'], 'Mrays/s', d['ms_per_step'], 'ms/frame |', c['frame'], '| pass1', c['pass1_ms'], 'ssaa', c['ssaa_ms'], 'frame kernel', c['frame_kernel_ms'], '| first frame', c['cold_frame_ms'], 'ms, directly behind warm frames', c.get('cold_frame_gpu_busy_before_ms'), '| rays', c['rays_per_frame'])" >> $O/r03_configs.txt
+done
+(python tools/shard_time.py 2 4 8; python tools/shard_time.py 2 4 8 --size 8192) 2>&1 | grep -v amdgpu > $O/r03_shard_emulation.txt
+bash tools/r03_dbg.sh > $O/r03_dbg_counts.txt 2>&1
+python tools/cold_probe.py 2>&1 | grep pass1 > $O/r03_cold_probe.txt
+python tools/overhead_probe.py 2>&1 | grep -E "pass1|rays" > $O/r03_overhead_probe.txt
+python tools/cost_fit.py 2>&1 | grep -E "scene|together" > $O/r03_cost_fit.txt
+python -c "
+import json
+for f in ('r03_bench_default','r03_bench_cfg2'):
+    b=json.load(open('$O/%s.json'%f)); r=b['roofline']; print(f, b['value'], b['ms_per_step'], r.get('peak'), r.get('achieved'), r.get('frac'), r.get('frac_vs_fp32_issue_peak'))"
