@@ -246,6 +246,10 @@ int rtx_comm_unique_id(void* id128);
 int rtx_comm_create(const void* id128, int n_ranks, int rank, int device, rtx_comm** out);
 int rtx_comm_info(const rtx_comm* comm, int* n_ranks, int* rank);
 void rtx_comm_destroy(rtx_comm* comm);
+/* Every rank reports whether its part of the frame went well (ok != 0); *all_ok = 1 iff every rank said so (a 4-byte
+ * ncclAllReduce).  Called before rtx_gather, so that a rank that failed does not leave the others waiting for its bands:
+ * when *all_ok is 0 every rank skips the gather and reports the error.  Synchronises `stream`. */
+int rtx_comm_agree(rtx_comm* comm, int ok, int* all_ok, void* stream);
 /* img_dev: an image of `height` rows of row_bytes bytes each on this rank's device -- the fp32 framebuffer
  * (row_bytes = W*12, bottom_up = 0) or the BGR8 image of rtx_quantize_bgr8 (row_bytes = W*3, bottom_up = 1: image row y
  * is stored at row H-1-y, util.cpp:50).  On return (asynchronously, on `stream`) rank `root`'s buffer holds every

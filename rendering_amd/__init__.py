@@ -38,7 +38,7 @@ RTX_SYMBOLS = [
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
     "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
     "rtx_bvh_build", "rtx_bvh_info", "rtx_bvh_read", "rtx_bvh_destroy",
-    "rtx_vec_probe", "rtx_comm_unique_id", "rtx_comm_create", "rtx_comm_info", "rtx_comm_destroy", "rtx_gather", "rtx_gather_plan",
+    "rtx_vec_probe", "rtx_comm_unique_id", "rtx_comm_create", "rtx_comm_info", "rtx_comm_destroy", "rtx_comm_agree", "rtx_gather", "rtx_gather_plan",
 ]
 
 
@@ -93,6 +93,7 @@ def load():
     rtx.rtx_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     rtx.rtx_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     rtx.rtx_comm_destroy.argtypes = [vp]
+    rtx.rtx_comm_agree.argtypes = [vp, C.c_int, C.POINTER(C.c_int), vp]
     rtx.rtx_comm_destroy.restype = None
     rtx.rtx_gather.argtypes = [vp, vp, vp, C.c_size_t, i32, i32, vp]
     rtx.rtx_gather_plan.argtypes = [u32, u32, u32, C.c_size_t, i32, u32, vp, vp, vp, C.POINTER(u32)]
@@ -212,6 +213,12 @@ class Comm:
         row_bytes = img[0].numel() * img.element_size()
         _check(self.rtx.rtx_gather(scene.gpu(), self.h, C.c_void_p(img.data_ptr()), row_bytes, int(bottom_up), root,
                                    Scene._stream_ptr(stream)), "rtx_gather")
+
+    def agree(self, ok, stream=None):
+        """rtx_comm_agree: True iff every rank passed ok=True (called before gather, so that a failed rank does not leave the others waiting)."""
+        out = C.c_int(0)
+        _check(self.rtx.rtx_comm_agree(self.h, int(bool(ok)), C.byref(out), Scene._stream_ptr(stream)), "rtx_comm_agree")
+        return bool(out.value)
 
     def close(self):
         if self.h:

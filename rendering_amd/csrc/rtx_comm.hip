@@ -17,6 +17,7 @@ struct RcclApi {
 	ncclResult_t (*groupEnd)() = nullptr;
 	ncclResult_t (*send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*allReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
 	const char* (*errorString)(ncclResult_t) = nullptr;
 };
 RcclApi gRccl;
@@ -32,7 +33,7 @@ int loadRccl()
 #define RTX_SYM(field, name) if (!(*(void**)&a.field = dlsym(lib, name))) return fail(RTX_ERR_UNSUPPORTED, "RCCL lacks " name)
 	RTX_SYM(getUniqueId, "ncclGetUniqueId"); RTX_SYM(commInitRank, "ncclCommInitRank"); RTX_SYM(commDestroy, "ncclCommDestroy");
 	RTX_SYM(groupStart, "ncclGroupStart"); RTX_SYM(groupEnd, "ncclGroupEnd"); RTX_SYM(send, "ncclSend"); RTX_SYM(recv, "ncclRecv");
-	RTX_SYM(errorString, "ncclGetErrorString");
+	RTX_SYM(errorString, "ncclGetErrorString"); RTX_SYM(allReduce, "ncclAllReduce");
 #undef RTX_SYM
 	gRccl = a;
 	return RTX_OK;
@@ -49,6 +50,7 @@ int loadRccl()
 struct rtx_comm {
 	ncclComm_t comm = nullptr;
 	int nRanks = 1, rank = 0, device = 0;
+	int* flag = nullptr;      // one device word for rtx_comm_agree
 };
 
 extern "C" {
@@ -97,6 +99,7 @@ int rtx_comm_create(const void* id128, int n_ranks, int rank, int device, rtx_co
 	c->nRanks = n_ranks; c->rank = rank; c->device = device;
 	ncclResult_t r = gRccl.commInitRank(&c->comm, n_ranks, id, rank);
 	if (r != ncclSuccess) { delete c; return fail(RTX_ERR_DEVICE, std::string("ncclCommInitRank: ") + gRccl.errorString(r)); }
+	if (hipMalloc((void**)&c->flag, sizeof(int)) != hipSuccess) { (void)gRccl.commDestroy(c->comm); delete c; return fail(RTX_ERR_DEVICE, "hipMalloc"); }
 	*out = c;
 	return RTX_OK;
 }
@@ -105,6 +108,7 @@ void rtx_comm_destroy(rtx_comm* c)
 {
 	if (!c) return;
 	if (c->comm && gRccl.commDestroy) (void)gRccl.commDestroy(c->comm);
+	if (c->flag) (void)hipFree(c->flag);
 	delete c;
 }
 
@@ -113,6 +117,26 @@ int rtx_comm_info(const rtx_comm* c, int* n_ranks, int* rank)
 	if (!c) return fail(RTX_ERR_ARG, "comm is NULL");
 	if (n_ranks) *n_ranks = c->nRanks;
 	if (rank) *rank = c->rank;
+	return RTX_OK;
+}
+
+// Do all ranks agree that things went well so far?  A rank that failed must not leave the others waiting in rtx_gather for
+// bands that will never be sent: every rank calls this with its own verdict BEFORE the gather (one 4-byte ncclAllReduce, min)
+// and all of them skip the gather and report the error when *all_ok comes back 0.  Synchronises `stream`.
+int rtx_comm_agree(rtx_comm* c, int ok, int* all_ok, void* stream)
+{
+	if (!c || !all_ok) return fail(RTX_ERR_ARG, "rtx_comm_agree: NULL argument");
+	*all_ok = ok ? 1 : 0;
+	if (c->nRanks == 1) return RTX_OK;
+	HIPCHK(hipSetDevice(c->device));
+	hipStream_t st = (hipStream_t)stream;
+	const int mine = ok ? 1 : 0;
+	HIPCHK(hipMemcpyAsync(c->flag, &mine, sizeof(int), hipMemcpyHostToDevice, st));
+	NCCLCHK(gRccl.allReduce(c->flag, c->flag, 1, ncclInt, ncclMin, c->comm, st));
+	int all = 0;
+	HIPCHK(hipMemcpyAsync(&all, c->flag, sizeof(int), hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	*all_ok = all;
 	return RTX_OK;
 }
 

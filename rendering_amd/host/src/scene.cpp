@@ -639,10 +639,18 @@ void Scene::render()
 		// launchWorkers + launchSSAA as one call: the stages overlap on the device (rtx_render_frame)
 		Timer tp("Render scene + MSAA");
 		gpuCheck(rtx_counters_enable(g, 0), "rtx_counters_enable");
-		gpuCheck(rtx_render_frame(g, 0, (uint32_t)options.height, d.fb, d.mask, nullptr), "rtx_render_frame");
+		// With other ranks waiting for this one's bands, a failure here must not simply exit: every rank reports its verdict
+		// (rtx_comm_agree below) and they all leave together.
+		int rc = rtx_render_frame(g, 0, (uint32_t)options.height, d.fb, d.mask, nullptr);
 		// the host's synchronisation point: a single launch that gave up has been rendered again in three (include/rtx.h)
 		uint32_t status = 0;
-		gpuCheck(rtx_frame_status(g, &status), "rtx_frame_status");
+		if (rc == RTX_OK) rc = rtx_frame_status(g, &status);
+		if (sharded) {
+			int allOk = 0;
+			gpuCheck(rtx_comm_agree(comm_, rc == RTX_OK, &allOk, nullptr), "rtx_comm_agree");
+			if (!allOk) { std::cout << "rank " << rank_ << ": " << (rc == RTX_OK ? "another rank failed to render its rows" : rtx_last_error()) << '\n'; LOG_ERROR(); }
+		}
+		else gpuCheck(rc, "rtx_render_frame");
 		if (status && options::enableOutput) std::cout << "frame rendered again in three launches (single launch status " << (status & 0xffu) << ")\n";
 	}
 	else {

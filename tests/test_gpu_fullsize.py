@@ -256,6 +256,7 @@ def test_comm_single_rank_and_gather_noop(ra, torch_cuda):
     c.gather(g, img, bottom_up=True)
     torch.cuda.synchronize()
     assert torch.equal(before, img)
+    assert c.agree(True) is True and c.agree(False) is False      # rtx_comm_agree: one rank agrees with itself
     c.close()
 
 

@@ -17,6 +17,11 @@ for c in cfg1 cfg2 cfg3 cfg4 cfg5; do
 import json,sys; d=json.loads(sys.stdin.read()); c=d['config']
 print('$c', c['workload'], '|', d['value'], 'Mrays/s', d['ms_per_step'], 'ms/frame |', c['frame'], '| pass1', c['pass1_ms'], 'ssaa', c['ssaa_ms'], 'frame kernel', c['frame_kernel_ms'], '| first frame', c['cold_frame_ms'], 'ms, directly behind warm frames', c.get('cold_frame_gpu_busy_before_ms'), '| rays', c['rays_per_frame'])" >> $O/r03_configs.txt
 done
+for c in headline cfg4 cfg5; do
+  RTX_NO_PRUNE=1 python bench.py --no-cpu-baseline --config $c 2>/dev/null | grep '^{' | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); c=d['config']
+print('$c WITHOUT the prune records (RTX_NO_PRUNE=1):', d['value'], 'Mrays/s', d['ms_per_step'], 'ms/frame | pass1', c['pass1_ms'], 'ssaa', c['ssaa_ms'])" >> $O/r03_configs.txt
+done
 (python tools/shard_time.py 2 4 8; python tools/shard_time.py 2 4 8 --size 8192) 2>&1 | grep -v amdgpu > $O/r03_shard_emulation.txt
 bash tools/r03_dbg.sh > $O/r03_dbg_counts.txt 2>&1
 python tools/cold_probe.py 2>&1 | grep pass1 > $O/r03_cold_probe.txt
