@@ -445,7 +445,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 				}
 			}
 			// the walk's stack holds at most 3 entries per wide level + 4
-			if (!nested || 3 * depthMax + 4 > 60) wide.clear();
+			if (!nested || 3 * depthMax + 4 > 52) wide.clear();      // (wideStack holds 56 entries per wave)
 			if (!wide.empty() && pruneWanted) {
 				// Prune records (rtxd::PruneRec): per binary node the true box of the triangles its subtree references and the
 				// largest |e1|_1 |e2|_1 among them (bottom-up over the pre-order array), then one record per wide-node slot.

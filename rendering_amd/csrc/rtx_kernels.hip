@@ -173,6 +173,23 @@ __device__ const uint64_t kExp2Tab[32] = {
 	0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
 };
 
+// The two tables in LDS (512 bytes per block, copied by fillPowTab at the start of every ray kernel): the lookups are per lane and
+// DEPENDENT (the exp2 entry's index comes out of the logarithm) -- from global memory two round trips of a microsecond or two in
+// every Phong / mirror / glass shading step, the longest part of a trace round of a scene of spheres (RTX_DBG=3: 12 000 of a
+// round's 17 000 cycles).
+#ifndef RTX_POW_LDS
+#define RTX_POW_LDS 1
+#endif
+__shared__ unsigned long long powTab[64];      // [0, 32): kLog2Tab as bits, [32, 64): kExp2Tab
+__device__ __forceinline__ void fillPowTab()
+{
+#if RTX_POW_LDS
+	if (threadIdx.x < 32) powTab[threadIdx.x] = (unsigned long long)__double_as_longlong(kLog2Tab[threadIdx.x]);
+	else if (threadIdx.x < 64) powTab[threadIdx.x] = kExp2Tab[threadIdx.x - 32];
+	__syncthreads();
+#endif
+}
+
 __device__ __forceinline__ int powfCheckInt(uint32_t iy)
 {
 	int e = iy >> 23 & 0xff;
@@ -219,7 +236,11 @@ __device__ __noinline__ float powfRef(float x, float y)
 	uint32_t top = tmp & 0xff800000;
 	uint32_t iz = ix - top;
 	int k = (int32_t)top >> 23;
+#if RTX_POW_LDS
+	double invc = __longlong_as_double((long long)powTab[2 * i]), logc = __longlong_as_double((long long)powTab[2 * i + 1]);
+#else
 	double invc = kLog2Tab[2 * i], logc = kLog2Tab[2 * i + 1];
+#endif
 	double z = (double)__uint_as_float(iz);
 	double r = __builtin_fma(z, invc, -1.0);
 	double y0 = logc + (double)k;
@@ -240,7 +261,11 @@ __device__ __noinline__ float powfRef(float x, float y)
 	uint64_t ki = (uint64_t)__double_as_longlong(kd);
 	kd -= 0x1.8p+47;
 	double rr = ylogx - kd;
+#if RTX_POW_LDS
+	uint64_t t = powTab[32 + ki % 32];
+#else
 	uint64_t t = kExp2Tab[ki % 32];
+#endif
 	t += (ki + signBias) << (52 - 5);
 	double s = __longlong_as_double((long long)t);
 	double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
@@ -615,7 +640,7 @@ __shared__ LeafEntry leafBatch[4][RTX_LEAF_BATCH];      // per wave of a 256-thr
 // WIDE walk: pending subtrees / leaves of the wave, top of the stack = next in the reference's order.  link > 0: wide node
 // link - 1; link < 0: leaf with ~link references from `first`; mask = the rays that passed the item's own box.
 struct WideItem { int32_t link; uint32_t first, maskLo, maskHi; };
-__shared__ WideItem wideStack[4][64];
+__shared__ WideItem wideStack[4][RTX_POW_LDS ? 56 : 64];      // (3 entries per wide level + 4: rtx_scene_create checks the depth; 512 bytes went to powTab)
 // WIDE walk with prune records (rtxd::PruneRec): what the slot test needs from the wave's bundle, per wave, written once per
 // walk: [0..5] the range of 1 / dir over the rays per axis (lo, hi; mirrored so that it is positive), [6..11] the range of
 // the origins per axis in the same mirrored coordinates (lo, hi), [12] 216 dmax, [13] the largest |origin| coordinate,
@@ -1253,6 +1278,7 @@ struct Lane {
 	// pending trace request
 	float qtmax;                  // (origin / direction of the pending request are derived from the state: see castRayWave)
 	bool qmoot;                   // the pending shadow ray cannot influence the pixel (see advance)
+	bool qarea;                   // the pending shadow ray goes to a sample point of an area light (consume: no second look at the light's record)
 };
 
 __device__ __forceinline__ float& frameAt(const Params& P, uint32_t gl, int slot, int field)
@@ -1401,6 +1427,7 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 			// the max is +0 (surface turned away from the light, or NaN) the product is the same +0 for either answer: the
 			// ray cannot influence the pixel ("moot"), and the product kernels do not walk it (castRayWave).
 			s.qmoot = s.mat == 0 && fmaxRef(0.f, dot(s.N, -s.L)) == 0.f;
+			s.qarea = lt == 3;
 			s.qtmax = dist;               // the ray itself: Ray{P + N*bias, -L, ShadowRay} (scene.cpp:787), built in castRayWave
 			s.state = ST_WAIT_SHADOW;
 			RTX_ACC(1)
@@ -1449,19 +1476,25 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 			RTX_T0
 			if (s.sp == 0) { s.state = ST_DONE; return; }
 			s.sp--;
-			const int kind = __float_as_int(frameAt(P, gl, s.sp, 0));
-			const V3 spec = mk(frameAt(P, gl, s.sp, 2), frameAt(P, gl, s.sp, 3), frameAt(P, gl, s.sp, 4));
+			// The whole frame is requested at once (14 coalesced loads, one round trip) instead of the kind first and then the fields of
+			// that kind: a deep reflect / refract tree is a chain of these, and a small frame lasts as long as its deepest pixel.
+			float fr[kFrameFields];
+			for (int k = 0; k < kFrameFields; ++k) fr[k] = frameAt(P, gl, s.sp, k);
+			asm volatile("" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]), "+v"(fr[4]), "+v"(fr[5]), "+v"(fr[6]));
+			asm volatile("" : "+v"(fr[7]), "+v"(fr[8]), "+v"(fr[9]), "+v"(fr[10]), "+v"(fr[11]), "+v"(fr[12]), "+v"(fr[13]));
+			const int kind = __float_as_int(fr[0]);
+			const V3 spec = mk(fr[2], fr[3], fr[4]);
 			if (kind == FR_REFL) { s.col = s.col * 0.8f + spec; RTX_ACC(4) continue; }                      // scene.cpp:858, 890
-			const float kr = frameAt(P, gl, s.sp, 1);
+			const float kr = fr[1];
 			if (kind == FR_TRANS1) {                                                             // scene.cpp:896-902
 				const V3 acc = mk(0, 0, 0) + s.col * (1 - kr);
 				frameAt(P, gl, s.sp, 0) = __int_as_float(FR_TRANS2);
 				frameAt(P, gl, s.sp, 5) = acc.x; frameAt(P, gl, s.sp, 6) = acc.y; frameAt(P, gl, s.sp, 7) = acc.z;
-				s.ro = mk(frameAt(P, gl, s.sp, 8), frameAt(P, gl, s.sp, 9), frameAt(P, gl, s.sp, 10));
-				s.rd = mk(frameAt(P, gl, s.sp, 11), frameAt(P, gl, s.sp, 12), frameAt(P, gl, s.sp, 13));
+				s.ro = mk(fr[8], fr[9], fr[10]);
+				s.rd = mk(fr[11], fr[12], fr[13]);
 				s.sp++; s.state = ST_NEWRAY; RTX_ACC(5) continue;
 			}
-			V3 acc = mk(frameAt(P, gl, s.sp, 5), frameAt(P, gl, s.sp, 6), frameAt(P, gl, s.sp, 7));
+			V3 acc = mk(fr[5], fr[6], fr[7]);
 			acc = acc + s.col * kr;                                                              // scene.cpp:908
 			s.col = acc + spec * kr;                                                             // scene.cpp:940
 			RTX_ACC(6)
@@ -1485,8 +1518,7 @@ __device__ __forceinline__ void consume(const Params& P, Lane& s, const Hit& h)
 	if (s.state == ST_WAIT_SHADOW) {
 		RTX_T0
 		const float vis = (h.obj < 0) ? 1.0f : 0.0f;       // bool vis = !trace(...)
-		const uint32_t li0 = __builtin_amdgcn_readfirstlane(s.li);
-		const bool area = ballot(s.li != li0) == 0 ? (int)sload1(&P.lights[li0].type) == 3 : P.lights[s.li].type == 3;
+		const bool area = s.qarea;
 		const V3 nL = -s.L;
 		if (s.mat == 0) {
 			const float c = vis * fmaxRef(0.f, dot(s.N, nL));
@@ -1572,7 +1604,7 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 	s.obj = 0; s.mat = 0; s.li = 0; s.si = 0;
 	s.P = s.N = s.objColor = s.diff = s.spec = s.L = s.I = mk(0, 0, 0);
 	s.specCoef = s.nSpec = s.dsum = s.ssum = 0;
-	s.qtmax = kFltMax; s.qmoot = false;
+	s.qtmax = kFltMax; s.qmoot = false; s.qarea = false;
 	advance(P, s, gl);
 #if RTX_DBG
 	unsigned long long dbgRounds = 0, dbgTrace = 0, dbgState = 0;
@@ -1691,6 +1723,7 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 template <bool STATS, bool MESH = true>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rtxPass1Kernel(const Params P)
 {
+	fillPowTab();
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
@@ -1775,6 +1808,7 @@ __device__ __forceinline__ uint32_t nthSetBit(uint64_t m, uint32_t n)   // posit
 template <bool STATS, bool MESH = true>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTIC) rtxSsaaKernel(const Params P)
 {
+	fillPowTab();
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
@@ -2147,6 +2181,7 @@ __global__ void __launch_bounds__(256) rtxSsaaScatterKernel(const Params P, cons
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) rtxProbeKernel(const Params P)
 {
+	fillPowTab();
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t nWork = (P.nProbe + 63) / 64;
@@ -2321,6 +2356,7 @@ enum : uint32_t {
 template <bool MESH>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYTIC) rtxFrameKernel(const Params P)
 {
+	fillPowTab();
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
@@ -2604,6 +2640,7 @@ __global__ void __launch_bounds__(256) rtxQuantizeKernel(const float* __restrict
 // Device-math self-check (rtx_math_probe)
 __global__ void rtxMathProbeKernel(int op, uint32_t n, const float* x, const float* y, float* out)
 {
+	fillPowTab();
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	float r = 0;
