@@ -142,7 +142,7 @@ def stamped(path):
     return d, None
 
 
-def pmc_roofline(avg_ms, scene_bytes, fb_bytes, kernel="rtxPass1Kernel<false, true>", workload="headline"):
+def pmc_roofline(avg_ms, scene_bytes, fb_bytes, kernel="rtxPass1Kernel<false, true, true>", workload="headline"):
     """Hardware-counter side of the roofline of the dominant kernel (rtxPass1Kernel where the frame is three launches,
     rtxFrameKernel where it is one): VALU wave-instructions and HBM-side bytes per launch from profiles/r03_pass1_pmc.json
     (tools/pmc_pass1.sh: separate rocprofv3 --pmc passes of this command), over the launch duration measured live in THIS run."""
@@ -353,7 +353,7 @@ def main():
     frame_mode, split_ms, fused_ms = scene.frame_mode() if ssaa else (0, -1.0, -1.0)
     # the dominant kernel: pass 1, or the single kernel of the frame where that is what ran
     one_launch = ssaa and n4 > n1
-    dom_kernel = "rtxFrameKernel<true>" if one_launch else "rtxPass1Kernel<false, true>"
+    dom_kernel = "rtxFrameKernel<true, true>" if one_launch else "rtxPass1Kernel<false, true, true>"
     avg_ms = ms4 / max(n4, 1) if one_launch else ms1 / max(n1, 1)
     # cold frame: a freshly created scene in the warm process -- its first pass 1 has no tile costs of a previous launch to
     # order its queues by (the reference's use case is one frame per process)

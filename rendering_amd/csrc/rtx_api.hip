@@ -101,6 +101,7 @@ void makeRef(const rtx_mesh& m, uint32_t ref, RefA& a, RefB& b, RefC& c)
 struct Knobs {
 	int pass1BlocksPerCU = 0, ssaaBlocksPerCU = 0, frameBlocksPerCU = 0;   // RTX_*_BLOCKS_PER_CU: 0 = what the occupancy allows
 	bool prune = true;                   // RTX_NO_PRUNE: no prune records (rtxd::PruneBlock)
+	int pruneBoxes = -1;                 // RTX_PRUNE_BOXES=0|1: the kernels without / with the box test whatever the triangle sizes (-1: by the meshes)
 	bool estimate = true;                // RTX_NO_COST_ESTIMATE: no first-frame cost estimate
 	float costPerRef = 2.5f, costPerLeaf = 110.0f, costBase = 8000.0f;   // estimate = base + perRef refs + perLeaf leaves (100 MHz ticks per tile; tools/cost_fit.py)
 	float fatFactor = 3.0f;              // RTX_FAT_FACTOR: bundle width, in mean triangle edges, above which a bundle is split; 0 = never
@@ -124,6 +125,7 @@ struct rtx_scene {
 	Params params;                // template of the kernel argument block
 	bool stats = false;
 	bool analytic = true;         // no object is a triangle mesh: the ray kernels without the walk are launched
+	bool boxPrune = false;        // some mesh has triangles small enough for the box test of the prune records: the kernels with it are launched
 	// lazily sized work buffers
 	float* frames = nullptr; size_t framesBytes = 0, framesArea = 0;
 	uint32_t* tileCost = nullptr; uint32_t* items = nullptr; size_t tileCap = 0;   // per-tile pass-1 cost, SSAA scan array (2 tiles + 1, then scan scratch)
@@ -188,6 +190,7 @@ void readKnobs(Knobs& k)
 	auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? strtoll(e, nullptr, 10) : dflt; };
 	k.pass1BlocksPerCU = (int)num("RTX_PASS1_BLOCKS_PER_CU", 0); k.ssaaBlocksPerCU = (int)num("RTX_SSAA_BLOCKS_PER_CU", 0); k.frameBlocksPerCU = (int)num("RTX_FRAME_BLOCKS_PER_CU", 0);
 	k.prune = !getenv("RTX_NO_PRUNE");
+	k.pruneBoxes = (int)num("RTX_PRUNE_BOXES", -1);
 	k.estimate = !getenv("RTX_NO_COST_ESTIMATE");
 	if (const char* e = getenv("RTX_COST_COEFFS")) sscanf(e, "%f,%f,%f", &k.costPerRef, &k.costPerLeaf, &k.costBase);
 	if (const char* e = getenv("RTX_FAT_FACTOR")) k.fatFactor = strtof(e, nullptr);
@@ -620,6 +623,11 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			d.meshFlags = (hm.n_nodes ? 1u : 0u) | (dm.boxesRegular ? 2u : 0u) | (dm.nWide ? 4u : 0u);
 			d.nodes = dm.nodes; d.refA = dm.refA; d.refB = dm.refB; d.refC = dm.refC; d.wide = dm.wide; d.prune = dm.prune;
 			d.nNodes = dm.nNodes; d.vmax = dm.vmax;
+			// The box test inflates a slot's true box by 216 dmax |orig - v0|_inf P (pruneAlive): with the origin about a mesh size away
+			// that is 216 P mesh sizes, so only meshes of small triangles gain from it; the plane test does not depend on P.
+			d.pruneBoxes = (dm.prune && std::isfinite(dm.rootRec.P) && dm.rootRec.P < 1.0f / 216.0f) ? 1u : 0u;
+			if (d.pruneBoxes && s->knobs.pruneBoxes != 0) s->boxPrune = true;
+			if (s->knobs.pruneBoxes > 0 && dm.prune) s->boxPrune = true;
 		}
 	}
 	{
@@ -933,6 +941,7 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	if ((rc = stamp(s, 0, st))) return rc;
 	if (s->stats) hipLaunchKernelGGL(rtxPass1Kernel<true>, dim3(blocks), dim3(256), 0, st, p);
 	else if (s->analytic) hipLaunchKernelGGL((rtxPass1Kernel<false, false>), dim3(blocks), dim3(256), 0, st, p);
+	else if (!s->boxPrune) hipLaunchKernelGGL((rtxPass1Kernel<false, true, false>), dim3(blocks), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxPass1Kernel<false>, dim3(blocks), dim3(256), 0, st, p);
 	HIPCHK(hipGetLastError());
 	if ((rc = stamp(s, 0, st))) return rc;
@@ -1024,6 +1033,7 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	if (blocks > wavesNeeded) blocks = wavesNeeded ? wavesNeeded : 1;
 	if ((rc = stamp(s, 4, st))) return rc;
 	if (s->analytic) hipLaunchKernelGGL(rtxFrameKernel<false>, dim3(blocks), dim3(256), 0, st, p);
+	else if (!s->boxPrune) hipLaunchKernelGGL((rtxFrameKernel<true, false>), dim3(blocks), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxFrameKernel<true>, dim3(blocks), dim3(256), 0, st, p);
 	HIPCHK(hipGetLastError());
 	if ((rc = stamp(s, 4, st))) return rc;
@@ -1273,6 +1283,7 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	HIPCHK(hipGetLastError());
 	if (s->stats) hipLaunchKernelGGL(rtxSsaaKernel<true>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	else if (s->analytic) hipLaunchKernelGGL((rtxSsaaKernel<false, false>), dim3(s->blocksSsaa), dim3(256), 0, st, p);
+	else if (!s->boxPrune) hipLaunchKernelGGL((rtxSsaaKernel<false, true, false>), dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxSsaaKernel<false>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	HIPCHK(hipGetLastError());
 	if ((rc = stamp(s, 2, st))) return rc;

@@ -105,7 +105,9 @@ struct Object {
 	uint32_t pad[2];
 	// third line (meshes): what the walk itself needs
 	const Node* nodes; const RefA* refA; const RefB* refB; const RefC* refC; const struct WideNode* wide; const struct PruneBlock* prune;
-	uint32_t nNodes; float vmax; uint32_t pad3[2];
+	uint32_t nNodes; float vmax;
+	uint32_t pruneBoxes;       // the PruneRec test can prune for this mesh (small triangles: P well under 1 / 216, see rtx_scene_create)
+	uint32_t pad3;
 };
 static_assert(sizeof(Object) == 192, "object record = three 64-byte lines");
 

@@ -745,7 +745,7 @@ __device__ __forceinline__ bool planeAlive(const f4v& r0, const f4v& r1, const B
 	return !(dead && r1.x >= 0.0f);
 }
 
-template <bool STATS, bool CULL, bool REGULAR, bool WIDE = false, bool FEWRAYS = false>
+template <bool STATS, bool CULL, bool REGULAR, bool WIDE = false, bool FEWRAYS = false, bool BOXES = true>
 __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
                                          float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
                                          float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
@@ -872,7 +872,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 					// lanes 0..3: the slots' boxes (PruneRec), lanes 4..7: their planes (PlaneRec); both tests run on every lane's record
 					const RTX_AS1 f4v* pr = (const RTX_AS1 f4v*)(pruneRecs + ((((uint32_t)(link - 1) << 3) | (lane & 7u)) << 5));
 					const f4v r0 = pr[0], r1 = pr[1];
-					const bool aliveBox = pruneAlive(r0, r1, pu, tmaxB);
+					const bool aliveBox = !BOXES || pruneAlive(r0, r1, pu, tmaxB);      // (BOXES: see the kernels' template parameter)
 #if RTX_PRUNE_PLANES
 					const bool alivePlane = planeAlive(r0, r1, B, pu[15], tmaxB);
 					const uint32_t bal = (uint32_t)ballot((lane & 4u) ? alivePlane : aliveBox);
@@ -1130,7 +1130,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 
 // MESH = false: the variant for scenes without triangle meshes (spheres and planes only).  Without the walk the castRay
 // state machine fits the register file, and a small frame lasts as long as its slowest wave's chain of dependent rays.
-template <bool STATS, bool MESH = true, bool FEWRAYS = false>
+template <bool STATS, bool MESH = true, bool FEWRAYS = false, bool BOXES = true>
 __device__ __forceinline__ void traceWave(const Params& P, bool active, bool shadow, V3 o, V3 d, float tmax,
                                           Hit& h, Counts& cnt)
 {
@@ -1221,7 +1221,7 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 					B = makeBundle(cl, o, d);
 				}
 				float bt, bu, bv; uint32_t btri;
-				if (!STATS && cull && regular && wideOk) meshWalk<STATS, true, true, true, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				if (!STATS && cull && regular && wideOk) meshWalk<STATS, true, true, true, FEWRAYS, BOXES>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				else if (cull && regular) meshWalk<STATS, true, true, false, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				else if (cull) meshWalk<STATS, true, false, false, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				else meshWalk<STATS, false, false, false, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
@@ -1594,7 +1594,7 @@ __device__ __forceinline__ const Params& freshParams(const Params& P)
 #endif
 }
 
-template <bool STATS, bool MESH = true, bool FEWRAYS = false>
+template <bool STATS, bool MESH = true, bool FEWRAYS = false, bool BOXES = true>
 __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3 d, uint32_t gl, Counts& cnt)
 {
 	const Params& P = freshParams(P0);
@@ -1638,7 +1638,7 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 			}
 			asm volatile("" ::: "memory");
 		}
-		traceWave<STATS, MESH, FEWRAYS>(freshParams(P0), qactive, qshadow, qo, qd, qtmax, h, cnt);
+		traceWave<STATS, MESH, FEWRAYS, BOXES>(freshParams(P0), qactive, qshadow, qo, qd, qtmax, h, cnt);
 		if (MESH && RTX_PARK) {
 			asm volatile("" ::: "memory");
 			const uint32_t t = threadIdx.x;
@@ -1720,7 +1720,9 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 // ------------------------------------------------------------------------------------------------
 // Pass 1: Scene::renderWorker over 8x8 pixel tiles (scene.cpp:444-468)
 // ------------------------------------------------------------------------------------------------
-template <bool STATS, bool MESH = true>
+// BOXES = false: the variant for scenes whose meshes all have triangles too large for the box test of the prune records to prune
+// anything (rtxd::Object::pruneBoxes; cfg4): the same kernel without that test (the plane test stays).
+template <bool STATS, bool MESH = true, bool BOXES = true>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rtxPass1Kernel(const Params P)
 {
 	fillPowTab();
@@ -1765,7 +1767,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 			if (sload1(P.tileCost + ty * P.tilesXFull + tx) > RTX_PRIO_TICKS) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 #endif
 			const unsigned long long t0 = wall_clock64();
-			const V3 c = castRayWave<STATS, MESH>(P, valid, o, d, gl, cnt);
+			const V3 c = castRayWave<STATS, MESH, false, BOXES>(P, valid, o, d, gl, cnt);
 			const unsigned long long dt = wall_clock64() - t0;
 #if RTX_DBG
 			dbgEnd = t0 + dt; dbgBusy += dt;
@@ -1805,7 +1807,7 @@ __device__ __forceinline__ uint32_t nthSetBit(uint64_t m, uint32_t n)   // posit
 	return pos;
 }
 
-template <bool STATS, bool MESH = true>
+template <bool STATS, bool MESH = true, bool BOXES = true>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTIC) rtxSsaaKernel(const Params P)
 {
 	fillPowTab();
@@ -1837,7 +1839,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 		V3 o, d;
 		primaryRay(P, fx, fy, o, d);
 		const unsigned long long t0 = wall_clock64();
-		const V3 c = castRayWave<STATS, MESH, true>(P, valid, o, d, gl, cnt);      // (work items of 16, 4 or 1 pixels: see the exact tests of meshWalk)
+		const V3 c = castRayWave<STATS, MESH, true, BOXES>(P, valid, o, d, gl, cnt);      // (work items of 16, 4 or 1 pixels: see the exact tests of meshWalk)
 		if (!STATS) {
 			// what the item cost, as the time of a 16-pixel item (a 4-pixel item takes at least a quarter of it), kept per tile
 			// in the second half of tileCost: a profiling aid (rtx_tile_cost_read, tools/ssaa_items.py).  Ordering and sizing
@@ -2353,7 +2355,7 @@ enum : uint32_t {
 };
 #define RTX_FRAME_QUEUES 64u
 
-template <bool MESH>
+template <bool MESH, bool BOXES = true>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYTIC) rtxFrameKernel(const Params P)
 {
 	fillPowTab();
@@ -2522,7 +2524,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 		if (slow) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 #endif
 		const unsigned long long t0 = wall_clock64();
-		const V3 c = castRayWave<false, MESH, true>(P, valid, o, d, gl, cnt);
+		const V3 c = castRayWave<false, MESH, true, BOXES>(P, valid, o, d, gl, cnt);
 		const unsigned long long dt = wall_clock64() - t0;
 #if RTX_DBG
 		if (lane == 0 && wave < 8192 && dbgItems < 160) {
@@ -2675,3 +2677,6 @@ template __global__ void rtxPass1Kernel<false, false>(const Params);
 template __global__ void rtxSsaaKernel<false, false>(const Params);
 template __global__ void rtxFrameKernel<true>(const Params);
 template __global__ void rtxFrameKernel<false>(const Params);
+template __global__ void rtxPass1Kernel<false, true, false>(const Params);
+template __global__ void rtxSsaaKernel<false, true, false>(const Params);
+template __global__ void rtxFrameKernel<true, false>(const Params);

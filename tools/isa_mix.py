@@ -10,8 +10,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from srchash import source_hash, ROOT
 
-KERNELS = {"rtxPass1Kernel<false, true>": "_Z14rtxPass1KernelILb0ELb1EEvN4rtxd6ParamsE", "rtxFrameKernel<true>": "_Z14rtxFrameKernelILb1EEvN4rtxd6ParamsE",
-           "rtxSsaaKernel<false, true>": "_Z13rtxSsaaKernelILb0ELb1EEvN4rtxd6ParamsE"}
+KERNELS = {"rtxPass1Kernel<false, true, true>": "_Z14rtxPass1KernelILb0ELb1ELb1EEvN4rtxd6ParamsE", "rtxFrameKernel<true, true>": "_Z14rtxFrameKernelILb1ELb1EEvN4rtxd6ParamsE",
+           "rtxSsaaKernel<false, true, true>": "_Z13rtxSsaaKernelILb0ELb1ELb1EEvN4rtxd6ParamsE"}
 
 
 def klass(op, line):
@@ -105,7 +105,7 @@ def main():
     per = {name: one(path, lines, name, sym) for name, sym in KERNELS.items()}
     # top level = the pass-1 kernel (what bench.py quotes beside the headline roofline); "kernels" holds all three
     res = {"source_hash": source_hash(), "what": "static instruction counts from " + os.path.basename(path)}
-    res.update(per["rtxPass1Kernel<false, true>"])
+    res.update(per["rtxPass1Kernel<false, true, true>"])
     res["kernels"] = per
     json.dump(res, open(os.path.join(ROOT, "profiles", "%s_pass1_isa.json" % tag), "w"), indent=1)
     for name, r in per.items():

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from srchash import source_hash
 from isa_mix import klass, issue_cycles
 
-K = "_Z14rtxPass1KernelILb0ELb1EEvN4rtxd6ParamsE"
+K = "_Z14rtxPass1KernelILb0ELb1ELb1EEvN4rtxd6ParamsE"
 lines = open(os.path.join(ROOT, "build", "rtx_api-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith(K + ":"))
 loops, order, cur = {}, [], "top"
@@ -48,14 +48,14 @@ sec = dbg.split("== noprune")[0]
 m = re.search(r"node visits (\d+), reached leaves (\d+), filter passes \(64 references\) (\d+), of which rejected whole by stage 1 (\d+), by stage 2 (\d+); survivors tested exactly (\d+)", sec)
 visits, leaves, npass, rej1, rej2, exact = [int(x) for x in m.groups()]
 pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pass1_pmc.json")))
-kern = [v for n, v in pmc["workloads"]["headline"]["kernels"].items() if "Pass1Kernel<false, true>" in n][0]
+kern = [v for n, v in pmc["workloads"]["headline"]["kernels"].items() if "Pass1Kernel<false, true, true>" in n][0]
 total = kern["SQ_INSTS_VALU"]
 pv = sum(loops[k]["valu"] for k in passes) / len(passes)
 # the exact-test loop: the deepest loops nested right after each pass body
 depth = lambda k: int(k.split()[-1])
 ex = [k for k in after if depth(k) == depth(passes[0]) + 1 and loops[k]["valu"] > 40][:4]
 ev = sum(loops[k]["valu"] for k in ex) / max(len(ex), 1)
-print("sources %s, counters of sources %s; headline frame, rtxPass1Kernel<false, true>, one launch" % (source_hash(), pmc["source_hash"]))
+print("sources %s, counters of sources %s; headline frame, rtxPass1Kernel<false, true, true>, one launch" % (source_hash(), pmc["source_hash"]))
 print("SQ_INSTS_VALU (hardware)                                   %.3e wave-instructions" % total)
 rows = [("node visit (pop, WideNode + prune records, pruneAlive / planeAlive, 4 slot tests, pushes)", node, loops[node]["valu"], visits),
         ("filter pass of 64 references (assign, bundleRejects1/2, ballots; without the exact tests)", passes[0], pv, npass),

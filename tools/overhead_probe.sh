@@ -11,6 +11,6 @@ python - <<PY
 import csv, glob
 rows = [r for f in glob.glob("gpurun_out/r03/ovh/**/*counter_collection.csv", recursive=True) for r in csv.DictReader(open(f))]
 for r in rows:
-    if "Pass1Kernel<false, true>" in r["Kernel_Name"]:
+    if "Pass1Kernel<false, true, true>" in r["Kernel_Name"]:
         print(r["Dispatch_Id"], r["Counter_Name"], r["Counter_Value"])
 PY

@@ -24,7 +24,7 @@ for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
         k = row["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); disp[(k, row["Counter_Name"])].add(row["Dispatch_Id"])
 for k in agg:
-    if "Pass1Kernel<false, true>" in k or "SsaaKernel<false, true>" in k:
+    if "Pass1Kernel<false, true, true>" in k or "SsaaKernel<false, true, true>" in k:
         print(k)
         for c, v in sorted(agg[k].items()): print("   %-32s %.4g" % (c, v / max(len(disp[(k, c)]), 1)))
 PY

@@ -38,7 +38,7 @@ for cfg, mode in (("headline", "three launches"), ("cfg2", "one launch")):
             disp[(k, row["Counter_Name"])].add(row["Dispatch_Id"])
     ks = {}
     for k in agg:
-        if "Pass1Kernel<false, true>" in k or "SsaaKernel<false, true>" in k or "FrameKernel<true>" in k or "Sobel" in k:
+        if "Pass1Kernel<false, true, true>" in k or "SsaaKernel<false, true, true>" in k or "FrameKernel<true, true>" in k or "Sobel" in k:
             ks[k] = {c: v / max(len(disp[(k, c)]), 1) for c, v in agg[k].items()}
             ks[k]["dispatches"] = max(len(disp[(k, c)]) for c in agg[k])
     res["workloads"][cfg] = {"frame": mode, "kernels": ks}
