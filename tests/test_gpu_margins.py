@@ -168,3 +168,17 @@ def test_fine_meshes_where_the_box_records_prune(ra, oracle, tmp_path, name, n_t
         path.write_text(scene_text(mesh, pos=(0, 0, -3), size=(2, 2, 2), rot=(0, 0, 0), cull=cull, w=128, h=96))
         n, hits = check(ra, oracle, str(path), 128, 96, 1, 31 + cull, frames=(name != "bumpy_250k.obj" or cull == 1), n_tri=n_tri)
         assert hits > n // 50
+
+
+@pytest.mark.parametrize("name,boxes", [("bumpy_4k.obj", "1"), ("bumpy_25k.obj", "0")])
+def test_either_kernel_variant_on_either_kind_of_mesh(ra, oracle, tmp_path, monkeypatch, name, boxes):
+    """The launch picks the kernels with the box test of the prune records (BOXES) only for scenes with small triangles; the knob
+    forces the other variant: the box test on a mesh of large triangles (its margin is then larger than the mesh: it must
+    simply never prune), and a fine mesh through the kernels without it."""
+    from rendering_amd import assets
+    mesh = assets.ensure([name])[name]
+    monkeypatch.setenv("RTX_PRUNE_BOXES", boxes)
+    path = tmp_path / "variant.scene"
+    path.write_text(scene_text(mesh, pos=(0, 0, -3), size=(2, 2, 2), rot=(15, 40, 0), cull=1, w=128, h=96))
+    n, hits = check(ra, oracle, str(path), 128, 96, 1, 47, n_tri=24)
+    assert hits > n // 50
