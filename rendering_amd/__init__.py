@@ -34,7 +34,7 @@ _host = None
 # every entry point declared in include/rtx.h
 RTX_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_set_view", "rtx_scene_bytes",
-    "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_render_frame", "rtx_frame_status", "rtx_frame_mode", "rtx_set_frame_mode", "rtx_set_knob", "rtx_cost_grid_read", "rtx_quantize_bgr8", "rtx_render_frame_host",
+    "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_render_frame", "rtx_frame_status", "rtx_frame_mode", "rtx_set_frame_mode", "rtx_set_knob", "rtx_cost_grid_read", "rtx_mesh_flatten_probe", "rtx_quantize_bgr8", "rtx_render_frame_host",
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
     "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
     "rtx_bvh_build", "rtx_bvh_info", "rtx_bvh_read", "rtx_bvh_destroy",
@@ -69,6 +69,7 @@ def load():
     rtx.rtx_set_frame_mode.argtypes = [vp, C.c_int]
     rtx.rtx_set_knob.argtypes = [vp, C.c_char_p, C.c_double]
     rtx.rtx_cost_grid_read.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    rtx.rtx_mesh_flatten_probe.argtypes = [vp, C.POINTER(C.c_uint32), vp, vp, C.c_uint32, vp]
     rtx.rtx_frame_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     rtx.rtx_quantize_bgr8.argtypes = [vp, vp, vp, vp]
     rtx.rtx_render_frame_host.argtypes = [vp, i32, vp]
@@ -224,6 +225,33 @@ class Comm:
         if self.h:
             self.rtx.rtx_comm_destroy(self.h)
             self.h = C.c_void_p()
+
+
+class _RtxMesh(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_refs", C.c_uint32), ("n_tris", C.c_uint32), ("node_bounds", C.c_void_p), ("node_skip", C.c_void_p),
+                ("leaf_begin", C.c_void_p), ("leaf_count", C.c_void_p), ("refs", C.c_void_p), ("tri_pos", C.c_void_p), ("tri_nrm", C.c_void_p),
+                ("tri_uv", C.c_void_p), ("tri_tb", C.c_void_p), ("diffuse_w", C.c_uint32), ("diffuse_h", C.c_uint32), ("diffuse_map", C.c_void_p),
+                ("normal_w", C.c_uint32), ("normal_h", C.c_uint32), ("normal_map", C.c_void_p), ("specular_w", C.c_uint32), ("specular_h", C.c_uint32),
+                ("specular_map", C.c_void_p)]
+
+
+def mesh_flatten_probe(bvh):
+    """Host only: the wide nodes and prune blocks rtx_scene_create derives from a mesh (rtx_mesh_flatten_probe).  bvh = Scene.bvh(obj).
+    Returns (wide [n, 4, 8] float32 -- link / first as bit patterns in [..., 6:8] --, box records [n, 4, 8], plane records [n, 4, 8], root record [8])."""
+    rtx, _ = load()
+    bounds = np.ascontiguousarray(bvh["bounds"], np.float32); skip = np.ascontiguousarray(bvh["skip"], np.int32)
+    lb = np.ascontiguousarray(bvh["leaf_begin"], np.int32); lc = np.ascontiguousarray(bvh["leaf_count"], np.int32)
+    refs = np.ascontiguousarray(bvh["refs"], np.uint32); pos = np.ascontiguousarray(bvh["tris"][:, 0:9], np.float32)
+    m = _RtxMesh()
+    m.n_nodes, m.n_refs, m.n_tris = len(skip), len(refs), len(pos)
+    m.node_bounds, m.node_skip, m.leaf_begin, m.leaf_count = bounds.ctypes.data, skip.ctypes.data, lb.ctypes.data, lc.ctypes.data
+    m.refs, m.tri_pos = refs.ctypes.data, pos.ctypes.data
+    n = C.c_uint32(0)
+    root = np.zeros(8, np.float32)
+    _check(rtx.rtx_mesh_flatten_probe(C.byref(m), C.byref(n), None, None, 0, _np_ptr(root)), "rtx_mesh_flatten_probe")
+    wide = np.zeros((n.value, 4, 8), np.float32); prune = np.zeros((n.value, 8, 8), np.float32)
+    _check(rtx.rtx_mesh_flatten_probe(C.byref(m), C.byref(n), _np_ptr(wide), _np_ptr(prune), n.value, _np_ptr(root)), "rtx_mesh_flatten_probe")
+    return wide, prune[:, 0:4], prune[:, 4:8], root
 
 
 def math_probe(op, x, y=None, device=0):

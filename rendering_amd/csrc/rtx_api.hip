@@ -336,6 +336,187 @@ int stamp(rtx_scene* s, int which, hipStream_t st)
 
 } // namespace
 
+namespace {
+
+// The host side of a mesh's upload, free of any device call (so that it can be checked without a GPU: rtx_mesh_flatten_probe):
+// 32-byte node records, the tree with every other level skipped (when every box lies inside its parent's), and the prune
+// blocks of its slots.
+struct FlatMesh {
+	std::vector<Node> nodes;
+	std::vector<WideNode> wide;
+	std::vector<PruneBlock> prune;
+	PruneRec rootRec;
+	float vmaxMesh = 0;
+	bool boxesRegular = true;
+};
+
+int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
+{
+	if (!m.node_bounds || !m.node_skip || !m.leaf_begin || !m.leaf_count || (m.n_refs && !m.refs) || (m.n_tris && !m.tri_pos)) return fail(RTX_ERR_ARG, "mesh arrays missing");
+	for (uint32_t r = 0; r < m.n_refs; r++)
+		if (m.refs[r] >= m.n_tris) return fail(RTX_ERR_ARG, "leaf reference out of range");
+	std::vector<Node> nodes(m.n_nodes);
+	bool boxesRegular = true;
+	for (uint32_t i = 0; i < m.n_nodes; i++) {
+		Node& nd = nodes[i];
+		for (int c = 0; c < 3; c++) {
+			nd.b[2 * c] = m.node_bounds[(size_t)i * 6 + c]; nd.b[2 * c + 1] = m.node_bounds[(size_t)i * 6 + 3 + c];
+			if (!(std::fabs(nd.b[2 * c]) < 1e30f && std::fabs(nd.b[2 * c + 1]) < 1e30f && nd.b[2 * c] <= nd.b[2 * c + 1])) boxesRegular = false;
+		}
+		if (m.leaf_count[i] < 0) {
+			if (m.node_skip[i] <= (int32_t)i + 1 || m.node_skip[i] > (int32_t)m.n_nodes) return (fail(RTX_ERR_ARG, "bad skip index"));
+			nd.link = m.node_skip[i]; nd.first = 0;
+			continue;
+		}
+		const uint32_t begin = (uint32_t)m.leaf_begin[i], count = (uint32_t)m.leaf_count[i];
+		if (begin + count > m.n_refs) return (fail(RTX_ERR_ARG, "leaf range out of bounds"));
+		nd.link = ~m.leaf_count[i]; nd.first = (int32_t)begin;
+	}
+	// the tree with every other level skipped (rtxd::WideNode), when every box lies inside its parent's
+	std::vector<WideNode> wide;
+	
+	std::vector<PruneBlock> prune;
+	float vmaxMesh = 0;
+	PruneRec rootRec;
+	memset(&rootRec, 0, sizeof(rootRec));
+	rootRec.h[0] = rootRec.h[1] = rootRec.h[2] = INFINITY; rootRec.P = INFINITY;
+	std::vector<std::array<uint32_t, 4>> slotNode;      // binary node behind every wide-node slot
+	constexpr uint32_t kNoNode = 0xffffffffu;
+	if (boxesRegular && m.n_nodes > 0) {
+		bool nested = true;
+		uint32_t depthMax = 0;
+		auto isLeaf = [&](uint32_t i) { return m.leaf_count[i] >= 0; };
+		auto rightOf = [&](uint32_t i) { return isLeaf(i + 1) ? i + 2 : (uint32_t)m.node_skip[i + 1]; };     // children of inner node i: i + 1 and this
+		auto inside = [&](uint32_t c, uint32_t p) {
+			for (int k = 0; k < 3; k++)
+				if (!(nodes[c].b[2 * k] >= nodes[p].b[2 * k] && nodes[c].b[2 * k + 1] <= nodes[p].b[2 * k + 1])) return false;
+			return true;
+		};
+		// iterative pre-order construction: (binary node, index of its wide node, depth)
+		struct Item { uint32_t node, wideIndex, depth; };
+		std::vector<Item> todo;
+		wide.emplace_back(); memset(&wide[0], 0, sizeof(WideNode));
+		slotNode.push_back({ { kNoNode, kNoNode, kNoNode, kNoNode } });
+		if (isLeaf(0)) { wide[0].slot[0] = nodes[0]; slotNode[0][0] = 0; }
+		else todo.push_back({ 0u, 0u, 1u });
+		while (!todo.empty() && nested) {
+			const Item it = todo.back(); todo.pop_back();
+			depthMax = std::max(depthMax, it.depth);
+			uint32_t slots[4]; int ns = 0;
+			const uint32_t kids[2] = { it.node + 1, rightOf(it.node) };
+			for (uint32_t c : kids) {
+				if (c >= m.n_nodes || !inside(c, it.node)) { nested = false; break; }
+				if (isLeaf(c)) slots[ns++] = c;
+				else {
+					const uint32_t g[2] = { c + 1, rightOf(c) };
+					for (uint32_t gc : g) { if (gc >= m.n_nodes || !inside(gc, c)) { nested = false; break; } slots[ns++] = gc; }
+				}
+			}
+			if (!nested) break;
+			// children wide nodes are created in REVERSE so that the vector stays in pre-order when popped; indices are fixed here
+			uint32_t childWide[4] = { 0, 0, 0, 0 };
+			for (int k = 0; k < ns; k++)
+				if (!isLeaf(slots[k])) { childWide[k] = (uint32_t)wide.size(); wide.emplace_back(); memset(&wide.back(), 0, sizeof(WideNode)); slotNode.push_back({ { kNoNode, kNoNode, kNoNode, kNoNode } }); }
+			for (int k = ns - 1; k >= 0; k--) {
+				slotNode[it.wideIndex][k] = slots[k];
+				Node sl = nodes[slots[k]];
+				if (!isLeaf(slots[k])) { sl.link = (int32_t)childWide[k] + 1; sl.first = 0; todo.push_back({ slots[k], childWide[k], it.depth + 1 }); }
+				wide[it.wideIndex].slot[k] = sl;
+			}
+		}
+		// the walk's stack holds at most 3 entries per wide level + 4
+		if (!nested || 3 * depthMax + 4 > 52) wide.clear();      // (wideStack holds 56 entries per wave)
+		if (!wide.empty() && pruneWanted) {
+			// Prune records (rtxd::PruneRec): per binary node the true box of the triangles its subtree references and the
+			// largest |e1|_1 |e2|_1 among them (bottom-up over the pre-order array), then one record per wide-node slot.
+			// The triangle as the exact test sees it: v0, v0 + e1, v0 + e2 with the fp32 differences of makeRef (objects.cpp:70-71).
+			struct Agg { double lo[3], hi[3], ps, qlo[3], qhi[3], wlo, whi; bool planes; };
+			std::vector<Agg> agg(m.n_nodes);
+			for (uint32_t i = m.n_nodes; i-- > 0;) {
+				Agg& a = agg[i];
+				for (int k = 0; k < 3; k++) { a.lo[k] = a.qlo[k] = INFINITY; a.hi[k] = a.qhi[k] = -INFINITY; }
+				a.ps = 0; a.wlo = INFINITY; a.whi = -INFINITY; a.planes = true;
+				auto merge = [&](const Agg& b) {
+					for (int k = 0; k < 3; k++) {
+						a.lo[k] = std::min(a.lo[k], b.lo[k]); a.hi[k] = std::max(a.hi[k], b.hi[k]);
+						a.qlo[k] = std::min(a.qlo[k], b.qlo[k]); a.qhi[k] = std::max(a.qhi[k], b.qhi[k]);
+					}
+					a.ps = std::max(a.ps, b.ps); a.wlo = std::min(a.wlo, b.wlo); a.whi = std::max(a.whi, b.whi);
+					a.planes = a.planes && b.planes;
+				};
+				if (!isLeaf(i)) { merge(agg[i + 1]); merge(agg[rightOf(i)]); continue; }
+				const uint32_t begin = (uint32_t)m.leaf_begin[i], count = (uint32_t)m.leaf_count[i];
+				for (uint32_t r = begin; r < begin + count; r++) {
+					RefA ra; RefB rb; RefC rc;
+					makeRef(m, r, ra, rb, rc);
+					const double v0[3] = { ra.v0x, ra.v0y, ra.v0z }, e1[3] = { rb.e1x, rb.e1y, rb.e1z }, e2[3] = { rb.e2x, rc.e2y, rc.e2z };
+					double s1 = 0, s2 = 0;
+					for (int k = 0; k < 3; k++) {
+						const double x1 = v0[k] + e1[k], x2 = v0[k] + e2[k];
+						a.lo[k] = std::min(a.lo[k], std::min(v0[k], std::min(x1, x2)));
+						a.hi[k] = std::max(a.hi[k], std::max(v0[k], std::max(x1, x2)));
+						s1 += std::fabs(e1[k]); s2 += std::fabs(e2[k]);
+					}
+					a.ps = std::max(a.ps, s1 * s2);
+					// scaled plane normal q = (e2 x e1) / (s1 s2) and offset v0 . q.  A triangle with a zero edge can never be
+					// accepted (det_c = 0 exactly) and bounds nothing; one whose scale underflows spoils the slot's plane bound.
+					if (s1 == 0 || s2 == 0) continue;
+					const double sc = s1 * s2;
+					if (!(sc > 1e-30) || !std::isfinite(sc)) { a.planes = false; continue; }
+					const double mq[3] = { (e2[1] * e1[2] - e2[2] * e1[1]) / sc, (e2[2] * e1[0] - e2[0] * e1[2]) / sc, (e2[0] * e1[1] - e2[1] * e1[0]) / sc };
+					double w = 0;
+					for (int k = 0; k < 3; k++) { a.qlo[k] = std::min(a.qlo[k], mq[k]); a.qhi[k] = std::max(a.qhi[k], mq[k]); w += v0[k] * mq[k]; }
+					a.wlo = std::min(a.wlo, w); a.whi = std::max(a.whi, w);
+				}
+			}
+			auto makeRec = [&](const Agg& a, PruneRec& pr) {
+				memset(&pr, 0, sizeof(pr));
+				pr.h[0] = pr.h[1] = pr.h[2] = -1e30f;      // empty: nothing can meet it
+				if (!(a.lo[0] <= a.hi[0])) return;         // no triangles
+				bool finite = std::isfinite(a.ps);
+				for (int c = 0; c < 3; c++) finite = finite && std::isfinite(a.lo[c]) && std::isfinite(a.hi[c]);
+				if (!finite) { pr.h[0] = pr.h[1] = pr.h[2] = INFINITY; pr.P = INFINITY; return; }      // never pruned
+				for (int c = 0; c < 3; c++) {
+					const double mid = 0.5 * (a.lo[c] + a.hi[c]), big = std::max(std::fabs(a.lo[c]), std::fabs(a.hi[c]));
+					pr.c[c] = (float)mid;
+					// [c - h, c + h] really contains [lo, hi] (c is rounded, h rounded up)
+					pr.h[c] = (float)((0.5 * (a.hi[c] - a.lo[c]) + std::fabs((double)pr.c[c] - mid)) * (1.0 + 0x1p-20) + 0x1p-24 * big + 1e-37);
+				}
+				pr.P = (float)(a.ps * (1.0 + 0x1p-20) + 1e-37);
+			};
+			makeRec(agg[0], rootRec);
+			prune.resize(wide.size());
+			for (int c = 0; c < 3; c++) vmaxMesh = std::max(vmaxMesh, (float)std::max(std::fabs(agg[0].lo[c]), std::fabs(agg[0].hi[c])));
+			for (size_t wi = 0; wi < wide.size(); wi++)
+				for (int k = 0; k < 4; k++) {
+					PruneRec& pr = prune[wi].box[k];
+					PlaneRec& pl = prune[wi].plane[k];
+					memset(&pr, 0, sizeof(pr)); memset(&pl, 0, sizeof(pl));
+					pr.h[0] = pr.h[1] = pr.h[2] = -1e30f;      // empty: nothing can meet it
+					pl.qr[0] = pl.qr[1] = pl.qr[2] = -1.0f;    // no plane bound
+					const uint32_t nd = slotNode[wi][k];
+					if (nd == kNoNode) continue;
+					const Agg& a = agg[nd];
+					makeRec(a, pr);
+					if (!(a.lo[0] <= a.hi[0]) || !std::isfinite(pr.P)) continue;
+					if (a.planes && a.wlo <= a.whi && std::isfinite(a.wlo) && std::isfinite(a.whi)) {
+						for (int c = 0; c < 3; c++) {
+							const double mid = 0.5 * (a.qlo[c] + a.qhi[c]);
+							pl.qc[c] = (float)mid;
+							pl.qr[c] = (float)((0.5 * (a.qhi[c] - a.qlo[c]) + std::fabs((double)pl.qc[c] - mid)) * (1.0 + 0x1p-20) + 0x1p-24);
+						}
+						pl.wlo = (float)(a.wlo - (std::fabs(a.wlo) * 0x1p-22 + 1e-37)); pl.whi = (float)(a.whi + (std::fabs(a.whi) * 0x1p-22 + 1e-37));
+					}
+				}
+		}
+	}
+	out.nodes.swap(nodes); out.wide.swap(wide); out.prune.swap(prune);
+	out.rootRec = rootRec; out.vmaxMesh = vmaxMesh; out.boxesRegular = boxesRegular;
+	return RTX_OK;
+}
+
+} // namespace
+
 extern "C" {
 
 const char* rtx_last_error(void) { return gErr.c_str(); }
@@ -378,161 +559,17 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		if (!m.node_bounds || !m.node_skip || !m.leaf_begin || !m.leaf_count || (m.n_refs && !m.refs) || (m.n_tris && (!m.tri_pos || !m.tri_nrm || !m.tri_uv)))
 			return bail(fail(RTX_ERR_ARG, "mesh arrays missing"));
 		if (m.normal_map && !m.tri_tb) return bail(fail(RTX_ERR_ARG, "normal map without tangents"));
-		std::vector<Node> nodes(m.n_nodes);
-		bool boxesRegular = true;
-		for (uint32_t i = 0; i < m.n_nodes; i++) {
-			Node& nd = nodes[i];
-			for (int c = 0; c < 3; c++) {
-				nd.b[2 * c] = m.node_bounds[(size_t)i * 6 + c]; nd.b[2 * c + 1] = m.node_bounds[(size_t)i * 6 + 3 + c];
-				if (!(std::fabs(nd.b[2 * c]) < 1e30f && std::fabs(nd.b[2 * c + 1]) < 1e30f && nd.b[2 * c] <= nd.b[2 * c + 1])) boxesRegular = false;
-			}
-			if (m.leaf_count[i] < 0) {
-				if (m.node_skip[i] <= (int32_t)i + 1 || m.node_skip[i] > (int32_t)m.n_nodes) return bail(fail(RTX_ERR_ARG, "bad skip index"));
-				nd.link = m.node_skip[i]; nd.first = 0;
-				continue;
-			}
-			const uint32_t begin = (uint32_t)m.leaf_begin[i], count = (uint32_t)m.leaf_count[i];
-			if (begin + count > m.n_refs) return bail(fail(RTX_ERR_ARG, "leaf range out of bounds"));
-			nd.link = ~m.leaf_count[i]; nd.first = (int32_t)begin;
+		FlatMesh flat;
+		{
+			const int frc = flattenMesh(m, s->knobs.prune, flat);
+			if (frc) return bail(frc);
 		}
-		// the tree with every other level skipped (rtxd::WideNode), when every box lies inside its parent's
-		std::vector<WideNode> wide;
-		const bool pruneWanted = s->knobs.prune;
-		std::vector<PruneBlock> prune;
-		float vmaxMesh = 0;
-		PruneRec rootRec;
-		memset(&rootRec, 0, sizeof(rootRec));
-		rootRec.h[0] = rootRec.h[1] = rootRec.h[2] = INFINITY; rootRec.P = INFINITY;
-		std::vector<std::array<uint32_t, 4>> slotNode;      // binary node behind every wide-node slot
-		constexpr uint32_t kNoNode = 0xffffffffu;
-		if (boxesRegular && m.n_nodes > 0) {
-			bool nested = true;
-			uint32_t depthMax = 0;
-			auto isLeaf = [&](uint32_t i) { return m.leaf_count[i] >= 0; };
-			auto rightOf = [&](uint32_t i) { return isLeaf(i + 1) ? i + 2 : (uint32_t)m.node_skip[i + 1]; };     // children of inner node i: i + 1 and this
-			auto inside = [&](uint32_t c, uint32_t p) {
-				for (int k = 0; k < 3; k++)
-					if (!(nodes[c].b[2 * k] >= nodes[p].b[2 * k] && nodes[c].b[2 * k + 1] <= nodes[p].b[2 * k + 1])) return false;
-				return true;
-			};
-			// iterative pre-order construction: (binary node, index of its wide node, depth)
-			struct Item { uint32_t node, wideIndex, depth; };
-			std::vector<Item> todo;
-			wide.emplace_back(); memset(&wide[0], 0, sizeof(WideNode));
-			slotNode.push_back({ { kNoNode, kNoNode, kNoNode, kNoNode } });
-			if (isLeaf(0)) { wide[0].slot[0] = nodes[0]; slotNode[0][0] = 0; }
-			else todo.push_back({ 0u, 0u, 1u });
-			while (!todo.empty() && nested) {
-				const Item it = todo.back(); todo.pop_back();
-				depthMax = std::max(depthMax, it.depth);
-				uint32_t slots[4]; int ns = 0;
-				const uint32_t kids[2] = { it.node + 1, rightOf(it.node) };
-				for (uint32_t c : kids) {
-					if (c >= m.n_nodes || !inside(c, it.node)) { nested = false; break; }
-					if (isLeaf(c)) slots[ns++] = c;
-					else {
-						const uint32_t g[2] = { c + 1, rightOf(c) };
-						for (uint32_t gc : g) { if (gc >= m.n_nodes || !inside(gc, c)) { nested = false; break; } slots[ns++] = gc; }
-					}
-				}
-				if (!nested) break;
-				// children wide nodes are created in REVERSE so that the vector stays in pre-order when popped; indices are fixed here
-				uint32_t childWide[4] = { 0, 0, 0, 0 };
-				for (int k = 0; k < ns; k++)
-					if (!isLeaf(slots[k])) { childWide[k] = (uint32_t)wide.size(); wide.emplace_back(); memset(&wide.back(), 0, sizeof(WideNode)); slotNode.push_back({ { kNoNode, kNoNode, kNoNode, kNoNode } }); }
-				for (int k = ns - 1; k >= 0; k--) {
-					slotNode[it.wideIndex][k] = slots[k];
-					Node sl = nodes[slots[k]];
-					if (!isLeaf(slots[k])) { sl.link = (int32_t)childWide[k] + 1; sl.first = 0; todo.push_back({ slots[k], childWide[k], it.depth + 1 }); }
-					wide[it.wideIndex].slot[k] = sl;
-				}
-			}
-			// the walk's stack holds at most 3 entries per wide level + 4
-			if (!nested || 3 * depthMax + 4 > 52) wide.clear();      // (wideStack holds 56 entries per wave)
-			if (!wide.empty() && pruneWanted) {
-				// Prune records (rtxd::PruneRec): per binary node the true box of the triangles its subtree references and the
-				// largest |e1|_1 |e2|_1 among them (bottom-up over the pre-order array), then one record per wide-node slot.
-				// The triangle as the exact test sees it: v0, v0 + e1, v0 + e2 with the fp32 differences of makeRef (objects.cpp:70-71).
-				struct Agg { double lo[3], hi[3], ps, qlo[3], qhi[3], wlo, whi; bool planes; };
-				std::vector<Agg> agg(m.n_nodes);
-				for (uint32_t i = m.n_nodes; i-- > 0;) {
-					Agg& a = agg[i];
-					for (int k = 0; k < 3; k++) { a.lo[k] = a.qlo[k] = INFINITY; a.hi[k] = a.qhi[k] = -INFINITY; }
-					a.ps = 0; a.wlo = INFINITY; a.whi = -INFINITY; a.planes = true;
-					auto merge = [&](const Agg& b) {
-						for (int k = 0; k < 3; k++) {
-							a.lo[k] = std::min(a.lo[k], b.lo[k]); a.hi[k] = std::max(a.hi[k], b.hi[k]);
-							a.qlo[k] = std::min(a.qlo[k], b.qlo[k]); a.qhi[k] = std::max(a.qhi[k], b.qhi[k]);
-						}
-						a.ps = std::max(a.ps, b.ps); a.wlo = std::min(a.wlo, b.wlo); a.whi = std::max(a.whi, b.whi);
-						a.planes = a.planes && b.planes;
-					};
-					if (!isLeaf(i)) { merge(agg[i + 1]); merge(agg[rightOf(i)]); continue; }
-					const uint32_t begin = (uint32_t)m.leaf_begin[i], count = (uint32_t)m.leaf_count[i];
-					for (uint32_t r = begin; r < begin + count; r++) {
-						RefA ra; RefB rb; RefC rc;
-						makeRef(m, r, ra, rb, rc);
-						const double v0[3] = { ra.v0x, ra.v0y, ra.v0z }, e1[3] = { rb.e1x, rb.e1y, rb.e1z }, e2[3] = { rb.e2x, rc.e2y, rc.e2z };
-						double s1 = 0, s2 = 0;
-						for (int k = 0; k < 3; k++) {
-							const double x1 = v0[k] + e1[k], x2 = v0[k] + e2[k];
-							a.lo[k] = std::min(a.lo[k], std::min(v0[k], std::min(x1, x2)));
-							a.hi[k] = std::max(a.hi[k], std::max(v0[k], std::max(x1, x2)));
-							s1 += std::fabs(e1[k]); s2 += std::fabs(e2[k]);
-						}
-						a.ps = std::max(a.ps, s1 * s2);
-						// scaled plane normal q = (e2 x e1) / (s1 s2) and offset v0 . q.  A triangle with a zero edge can never be
-						// accepted (det_c = 0 exactly) and bounds nothing; one whose scale underflows spoils the slot's plane bound.
-						if (s1 == 0 || s2 == 0) continue;
-						const double sc = s1 * s2;
-						if (!(sc > 1e-30) || !std::isfinite(sc)) { a.planes = false; continue; }
-						const double mq[3] = { (e2[1] * e1[2] - e2[2] * e1[1]) / sc, (e2[2] * e1[0] - e2[0] * e1[2]) / sc, (e2[0] * e1[1] - e2[1] * e1[0]) / sc };
-						double w = 0;
-						for (int k = 0; k < 3; k++) { a.qlo[k] = std::min(a.qlo[k], mq[k]); a.qhi[k] = std::max(a.qhi[k], mq[k]); w += v0[k] * mq[k]; }
-						a.wlo = std::min(a.wlo, w); a.whi = std::max(a.whi, w);
-					}
-				}
-				auto makeRec = [&](const Agg& a, PruneRec& pr) {
-					memset(&pr, 0, sizeof(pr));
-					pr.h[0] = pr.h[1] = pr.h[2] = -1e30f;      // empty: nothing can meet it
-					if (!(a.lo[0] <= a.hi[0])) return;         // no triangles
-					bool finite = std::isfinite(a.ps);
-					for (int c = 0; c < 3; c++) finite = finite && std::isfinite(a.lo[c]) && std::isfinite(a.hi[c]);
-					if (!finite) { pr.h[0] = pr.h[1] = pr.h[2] = INFINITY; pr.P = INFINITY; return; }      // never pruned
-					for (int c = 0; c < 3; c++) {
-						const double mid = 0.5 * (a.lo[c] + a.hi[c]), big = std::max(std::fabs(a.lo[c]), std::fabs(a.hi[c]));
-						pr.c[c] = (float)mid;
-						// [c - h, c + h] really contains [lo, hi] (c is rounded, h rounded up)
-						pr.h[c] = (float)((0.5 * (a.hi[c] - a.lo[c]) + std::fabs((double)pr.c[c] - mid)) * (1.0 + 0x1p-20) + 0x1p-24 * big + 1e-37);
-					}
-					pr.P = (float)(a.ps * (1.0 + 0x1p-20) + 1e-37);
-				};
-				makeRec(agg[0], rootRec);
-				prune.resize(wide.size());
-				for (int c = 0; c < 3; c++) vmaxMesh = std::max(vmaxMesh, (float)std::max(std::fabs(agg[0].lo[c]), std::fabs(agg[0].hi[c])));
-				for (size_t wi = 0; wi < wide.size(); wi++)
-					for (int k = 0; k < 4; k++) {
-						PruneRec& pr = prune[wi].box[k];
-						PlaneRec& pl = prune[wi].plane[k];
-						memset(&pr, 0, sizeof(pr)); memset(&pl, 0, sizeof(pl));
-						pr.h[0] = pr.h[1] = pr.h[2] = -1e30f;      // empty: nothing can meet it
-						pl.qr[0] = pl.qr[1] = pl.qr[2] = -1.0f;    // no plane bound
-						const uint32_t nd = slotNode[wi][k];
-						if (nd == kNoNode) continue;
-						const Agg& a = agg[nd];
-						makeRec(a, pr);
-						if (!(a.lo[0] <= a.hi[0]) || !std::isfinite(pr.P)) continue;
-						if (a.planes && a.wlo <= a.whi && std::isfinite(a.wlo) && std::isfinite(a.whi)) {
-							for (int c = 0; c < 3; c++) {
-								const double mid = 0.5 * (a.qlo[c] + a.qhi[c]);
-								pl.qc[c] = (float)mid;
-								pl.qr[c] = (float)((0.5 * (a.qhi[c] - a.qlo[c]) + std::fabs((double)pl.qc[c] - mid)) * (1.0 + 0x1p-20) + 0x1p-24);
-							}
-							pl.wlo = (float)(a.wlo - (std::fabs(a.wlo) * 0x1p-22 + 1e-37)); pl.whi = (float)(a.whi + (std::fabs(a.whi) * 0x1p-22 + 1e-37));
-						}
-					}
-			}
-		}
+		std::vector<Node>& nodes = flat.nodes;
+		std::vector<WideNode>& wide = flat.wide;
+		std::vector<PruneBlock>& prune = flat.prune;
+		const PruneRec rootRec = flat.rootRec;
+		const float vmaxMesh = flat.vmaxMesh;
+		const bool boxesRegular = flat.boxesRegular;
 		// leaf references in the reference's order, three parallel arrays padded by one wave
 		std::vector<RefA> refA((size_t)m.n_refs + 64);
 		std::vector<RefB> refB((size_t)m.n_refs + 64);
@@ -1456,6 +1493,21 @@ int rtx_cost_grid_read(rtx_scene* s, uint32_t* out, size_t n, uint32_t* grid_w, 
 	HIPCHK(hipSetDevice(s->device));
 	HIPCHK(hipDeviceSynchronize());
 	HIPCHK(hipMemcpy(out, s->costGrid, std::min(n, 2 * cells) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	return RTX_OK;
+}
+
+int rtx_mesh_flatten_probe(const rtx_mesh* m, uint32_t* n_wide, void* wide_out, void* prune_out, uint32_t cap_wide, float* root_rec8)
+{
+	if (!m || !n_wide) return fail(RTX_ERR_ARG, "mesh/n_wide is NULL");
+	FlatMesh flat;
+	int rc = flattenMesh(*m, true, flat);
+	if (rc) return rc;
+	*n_wide = (uint32_t)flat.wide.size();
+	if (root_rec8) memcpy(root_rec8, &flat.rootRec, sizeof(PruneRec));
+	if (flat.prune.size() != flat.wide.size() && !flat.wide.empty()) return fail(RTX_ERR_DEVICE, "prune blocks missing");
+	const size_t n = std::min<size_t>(cap_wide, flat.wide.size());
+	if (wide_out && n) memcpy(wide_out, flat.wide.data(), n * sizeof(WideNode));
+	if (prune_out && n) memcpy(prune_out, flat.prune.data(), n * sizeof(PruneBlock));
 	return RTX_OK;
 }
 

@@ -169,3 +169,69 @@ def test_scene_flags_are_per_scene(ra):
     assert b.view_flags() == 0 and a.view_flags() == 3
     import os
     assert os.getcwd() == os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # the loader restored the cwd
+
+
+@pytest.mark.parametrize("scene,obj", [("scenes/cfg2_smooth_4k.scene", 1), ("scenes/cfg4_textured_256.scene", 0), ("scenes/coincident.scene", 1)])
+def test_prune_records_enclose_what_they_stand_for(ra, scene, obj):
+    """The prune blocks of the wide walk (rtx_mesh_flatten_probe, host only): for every slot of every wide node
+    the box record encloses all vertices of all triangles referenced below it and P bounds their |e1|_1 |e2|_1, the plane
+    record encloses their scaled normals and plane offsets; the records of a slot enclose those of the wide node below it;
+    the wide nodes hold exactly the reference's boxes (two levels apart) and reach every leaf reference once."""
+    from rendering_amd import assets
+    assets.ensure()
+    g = ra.Scene(scene, 64, 48)
+    b = g.bvh(obj)
+    wide, box, plane, root = ra.mesh_flatten_probe(b)
+    assert len(wide) > 0
+    tris = b["tris"][:, 0:9].astype(np.float64)
+    A, B, C_ = tris[:, 0:3], tris[:, 3:6], tris[:, 6:9]
+    e1 = (tris[:, 3:6].astype(np.float32) - tris[:, 0:3].astype(np.float32)).astype(np.float64)      # the fp32 differences of the exact test
+    e2 = (tris[:, 6:9].astype(np.float32) - tris[:, 0:3].astype(np.float32)).astype(np.float64)
+    s1, s2 = np.abs(e1).sum(1), np.abs(e2).sum(1)
+    link = wide[..., 6].view(np.int32); first = wide[..., 7].view(np.int32)
+    refs = b["refs"]
+    seen = np.zeros(len(refs), np.int32)
+
+    def check_slot(w, k):
+        """-> (lo, hi, P, qlo, qhi, wlo, whi) actually spanned below slot k of wide node w (None: nothing)."""
+        l = int(link[w, k])
+        if l == 0:
+            return None
+        if l < 0:
+            n, f = ~l, int(first[w, k])
+            seen[f:f + n] += 1
+            r = refs[f:f + n]
+            if n == 0:
+                return None
+            V = np.concatenate([A[r], A[r] + e1[r], A[r] + e2[r]])
+            ok = (s1[r] > 0) & (s2[r] > 0)
+            q = np.cross(e2[r], e1[r])[ok] / (s1[r] * s2[r])[ok][:, None]
+            wv = (A[r][ok] * q).sum(1)
+            span = (V.min(0), V.max(0), (s1[r] * s2[r]).max(), q.min(0) if len(q) else None, q.max(0) if len(q) else None, wv.min() if len(q) else None, wv.max() if len(q) else None)
+        else:
+            parts = [p for p in (check_slot(l - 1, kk) for kk in range(4)) if p is not None]
+            if not parts:
+                return None
+            qs = [p for p in parts if p[3] is not None]
+            span = (np.min([p[0] for p in parts], 0), np.max([p[1] for p in parts], 0), max(p[2] for p in parts),
+                    np.min([p[3] for p in qs], 0) if qs else None, np.max([p[4] for p in qs], 0) if qs else None,
+                    min(p[5] for p in qs) if qs else None, max(p[6] for p in qs) if qs else None)
+        c, P, h = box[w, k, 0:3].astype(np.float64), float(box[w, k, 3]), box[w, k, 4:7].astype(np.float64)
+        assert (c - h <= span[0]).all() and (c + h >= span[1]).all(), "box record of slot %d of wide node %d" % (k, w)
+        assert P >= span[2], "P of slot %d of wide node %d" % (k, w)
+        qc, wlo, qr, whi = plane[w, k, 0:3].astype(np.float64), float(plane[w, k, 3]), plane[w, k, 4:7].astype(np.float64), float(plane[w, k, 7])
+        if qr[0] >= 0 and span[3] is not None:
+            assert (qc - qr <= span[3]).all() and (qc + qr >= span[4]).all() and wlo <= span[5] and whi >= span[6], "plane record of slot %d of wide node %d" % (k, w)
+            assert (np.abs(qc) + qr <= 1.0 + 1e-5).all()      # |q|_inf <= 1: what planeAlive's error terms assume
+        return span
+
+    spans = [p for p in (check_slot(0, k) for k in range(4)) if p is not None]
+    assert (seen == 1).all(), "every leaf reference is reached through exactly one slot"
+    lo = np.min([p[0] for p in spans], 0); hi = np.max([p[1] for p in spans], 0)
+    assert (root[0:3] - root[4:7] <= lo).all() and (root[0:3] + root[4:7] >= hi).all() and root[3] >= max(p[2] for p in spans)
+    # the slots are the reference's own boxes: every slot box is one of the node boxes of the binary tree
+    nb = {tuple(x) for x in b["bounds"][:, [0, 3, 1, 4, 2, 5]].astype(np.float32).tolist()}
+    for w in range(len(wide)):
+        for k in range(4):
+            if link[w, k] != 0:
+                assert tuple(wide[w, k, 0:6].tolist()) in nb

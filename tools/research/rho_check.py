@@ -1,8 +1,13 @@
+"""How far from its triangle can a hit lie that the reference ACCEPTS (objects.cpp:59-95 in fp32)?  The prune records of the wide
+walk rest on the bound  |orig + t_c dir - triangle box|_inf <= 36 u dmax ainf s1 s2 / det_c  (rtx_kernels.hip,
+pruneAlive).  Random and adversarial (ray, triangle) pairs -- rays nearly in the plane of the triangle, slivers -- in the
+reference's arithmetic (numpy fp32, no FMA); reports the worst observed distance over the bound.
+python tools/research/rho_check.py [seed]      (tests/test_prune_bound_cpu.py runs a smaller sample)"""
+import sys
 import numpy as np
 f32=np.float32
-rng=np.random.default_rng(int(__import__('sys').argv[1]) if len(__import__('sys').argv)>1 else 0)
 u=2.0**-24
-def run(N, mode):
+def run(N, mode, rng, quiet=False):
     # triangles
     sc = 10.0**rng.uniform(-3,0,(N,1))
     v0 = rng.uniform(-1,1,(N,3))*10.0**rng.uniform(-1,0.5,(N,1))
@@ -49,6 +54,10 @@ def run(N, mode):
     rho_unc=35.6*u*dmax*ainf*s1*s2/1e-8
     r=out/rho
     k=np.argmax(r) if len(r) else 0
-    print(mode, "accepted %d of %d; max outside/rho = %.3f (outside %.3e rho %.3e det %.2e), max outside/rho_unc %.3f; frac with outside>0: %.3f" % (len(idx), N, r.max() if len(r) else 0, out[k] if len(r) else 0, rho[k] if len(r) else 0, det[idx][k] if len(r) else 0, (out/rho_unc).max() if len(r) else 0, (out>0).mean() if len(r) else 0))
-for mode in ['graze','sliver','generic']:
-    run(2000000, mode)
+    if not quiet: print(mode, "accepted %d of %d; max outside/rho = %.3f (outside %.3e rho %.3e det %.2e), max outside/rho_unc %.3f; frac with outside>0: %.3f" % (len(idx), N, r.max() if len(r) else 0, out[k] if len(r) else 0, rho[k] if len(r) else 0, det[idx][k] if len(r) else 0, (out/rho_unc).max() if len(r) else 0, (out>0).mean() if len(r) else 0))
+    return (float(r.max()) if len(r) else 0.0), len(idx), (float(out.max()) if len(r) else 0.0)
+
+if __name__ == "__main__":
+    rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 0)
+    for mode in ['graze','sliver','generic']:
+        run(2000000, mode, rng)
