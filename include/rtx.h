@@ -164,10 +164,15 @@ int rtx_frame_mode(rtx_scene* scene, int* mode, float* split_ms, float* fused_ms
 int rtx_set_frame_mode(rtx_scene* scene, int mode); /* -1 measure and choose (default), 0 always three launches, 1 always one */
 /* Host only (no device is touched): what rtx_scene_create derives from a mesh before uploading it -- the tree with every other
  * level skipped (n_wide records of 128 bytes: four slots of {lo.x hi.x lo.y hi.y lo.z hi.z, link, first}; 0 when the boxes are
- * not nested) and the prune blocks of its slots (n_wide records of 256 bytes: four {c[3], P, h[3], -} then four
+ * not nested) and the prune blocks of its slots (n_wide records of 256 bytes: four {c[3], P, h[3], Pgen} then four
  * {qc[3], wlo, qr[3], whi}; rtx_device.h), plus the record of the whole mesh.  For the CPU tests of their
  * invariants (tests/test_host_cpu.py); cap_wide = records the output arrays hold. */
 int rtx_mesh_flatten_probe(const rtx_mesh* mesh, uint32_t* n_wide, void* wide_out, void* prune_out, uint32_t cap_wide, float* root_rec8);
+/* Host only: the P of the source copies of the prune records (rtx_device.h PruneRec, csrc/rtx_source.hip sourceP)
+ * for n triangles given as (v0, e1, e2) = 9 floats each, the source point S3, its radius sigma and cam != 0 when the rays start
+ * at S (the camera) rather than pass through it (a point light).  The function the device kernels run, for the CPU tests of the
+ * bound (tests/test_prune_bound_cpu.py). */
+int rtx_source_p_probe(const float* tris9, uint32_t n, const double* S3, double sigma, int cam, float* out);
 /* First-frame cost estimate (rtx_scene_create / rtx_scene_set_view project every leaf box of the meshes through the camera;
  * the reference renders one frame per process, main.cpp:15, so there is no previous frame to learn the tile costs from):
  * per cell of 2 x 2 tiles (16 x 16 pixels) the references and the leaves whose boxes cover it, interleaved (refs, leaves),

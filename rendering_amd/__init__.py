@@ -34,7 +34,7 @@ _host = None
 # every entry point declared in include/rtx.h
 RTX_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_set_view", "rtx_scene_bytes",
-    "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_render_frame", "rtx_frame_status", "rtx_frame_mode", "rtx_set_frame_mode", "rtx_set_knob", "rtx_cost_grid_read", "rtx_mesh_flatten_probe", "rtx_quantize_bgr8", "rtx_render_frame_host",
+    "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_render_frame", "rtx_frame_status", "rtx_frame_mode", "rtx_set_frame_mode", "rtx_set_knob", "rtx_cost_grid_read", "rtx_mesh_flatten_probe", "rtx_source_p_probe", "rtx_quantize_bgr8", "rtx_render_frame_host",
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
     "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
     "rtx_bvh_build", "rtx_bvh_info", "rtx_bvh_read", "rtx_bvh_destroy",
@@ -70,6 +70,7 @@ def load():
     rtx.rtx_set_knob.argtypes = [vp, C.c_char_p, C.c_double]
     rtx.rtx_cost_grid_read.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     rtx.rtx_mesh_flatten_probe.argtypes = [vp, C.POINTER(C.c_uint32), vp, vp, C.c_uint32, vp]
+    rtx.rtx_source_p_probe.argtypes = [vp, u32, vp, C.c_double, i32, vp]
     rtx.rtx_frame_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     rtx.rtx_quantize_bgr8.argtypes = [vp, vp, vp, vp]
     rtx.rtx_render_frame_host.argtypes = [vp, i32, vp]
@@ -252,6 +253,17 @@ def mesh_flatten_probe(bvh):
     wide = np.zeros((n.value, 4, 8), np.float32); prune = np.zeros((n.value, 8, 8), np.float32)
     _check(rtx.rtx_mesh_flatten_probe(C.byref(m), C.byref(n), _np_ptr(wide), _np_ptr(prune), n.value, _np_ptr(root)), "rtx_mesh_flatten_probe")
     return wide, prune[:, 0:4], prune[:, 4:8], root
+
+
+def source_p_probe(v0, e1, e2, S, sigma, cam):
+    """Host only: P of the source copies of the prune records for triangles (v0, e1, e2: [n, 3] float32), source point S, radius sigma;
+    cam: the rays start at S (rtx_source_p_probe; csrc/rtx_source.hip)."""
+    rtx, _ = load()
+    t = np.ascontiguousarray(np.concatenate([v0, e1, e2], 1), np.float32)
+    S = np.ascontiguousarray(S, np.float64)
+    out = np.zeros(len(t), np.float32)
+    _check(rtx.rtx_source_p_probe(_np_ptr(t), len(t), _np_ptr(S), float(sigma), 1 if cam else 0, _np_ptr(out)), "rtx_source_p_probe")
+    return out
 
 
 def math_probe(op, x, y=None, device=0):

@@ -19,6 +19,7 @@ using namespace rtxd;
 
 // single translation unit: the kernels are compiled together with their launch code
 #include "rtx_kernels.hip"
+#include "rtx_source.hip"
 
 namespace {
 
@@ -101,6 +102,7 @@ void makeRef(const rtx_mesh& m, uint32_t ref, RefA& a, RefB& b, RefC& c)
 struct Knobs {
 	int pass1BlocksPerCU = 0, ssaaBlocksPerCU = 0, frameBlocksPerCU = 0;   // RTX_*_BLOCKS_PER_CU: 0 = what the occupancy allows
 	bool prune = true;                   // RTX_NO_PRUNE: no prune records (rtxd::PruneBlock)
+	bool sources = true;                 // RTX_NO_SRC: no source copies of the prune records (every walk uses copy 0)
 	int pruneBoxes = -1;                 // RTX_PRUNE_BOXES=0|1: the kernels without / with the box test whatever the triangle sizes (-1: by the meshes)
 	bool estimate = true;                // RTX_NO_COST_ESTIMATE: no first-frame cost estimate
 	float costPerRef = 2.5f, costPerLeaf = 110.0f, costBase = 8000.0f;   // estimate = base + perRef refs + perLeaf leaves (100 MHz ticks per tile; tools/cost_fit.py)
@@ -165,6 +167,16 @@ struct rtx_scene {
 	uint32_t* costGrid = nullptr; size_t costGridCap = 0;
 	uint32_t* orderedList = nullptr; size_t orderedCap = 0;      // the tile list of the next launch in the order of rtxTileOrderKernel
 	bool costsUsable = false;
+	// source copies of the prune records (rtxd::PruneRec, rtx_source.hip): per mesh the copies' base, the reference arrays and the
+	// slots' reference ranges; the point lights that have a copy; what the copies were last built for
+	struct SrcMesh { PruneBlock* base = nullptr; uint32_t nWide = 0, nRefs = 0; const RefA* refA = nullptr; const RefB* refB = nullptr; const RefC* refC = nullptr;
+	                 const uint32_t* slotRange = nullptr; float* refP = nullptr; float* blockP = nullptr; float vmax = 0; };
+	std::vector<SrcMesh> srcMeshes;
+	std::vector<std::array<float, 3>> srcLightPos;      // [l]: position of light l (point lights only count below nSrcLights)
+	std::vector<uint8_t> srcLightIsPoint;
+	float srcNmax = 1.0f;                 // the longest shading normal a shadow ray's origin is offset along (planes keep theirs un-normalised)
+	float srcBuiltBias = -1.0f; bool srcLightsBuilt = false;
+	float srcBuiltCam[3] = { 0, 0, 0 }; bool srcCamBuilt = false;
 	// rtx_render_frame: event pairs around the last few frames, read back (without waiting) by later calls
 	struct FrameProbe { hipEvent_t a = nullptr, b = nullptr; int mode = -1; size_t queue = 0; uint32_t generation = 0; bool pending = false; };
 	FrameProbe probes[8];
@@ -190,6 +202,7 @@ void readKnobs(Knobs& k)
 	auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? strtoll(e, nullptr, 10) : dflt; };
 	k.pass1BlocksPerCU = (int)num("RTX_PASS1_BLOCKS_PER_CU", 0); k.ssaaBlocksPerCU = (int)num("RTX_SSAA_BLOCKS_PER_CU", 0); k.frameBlocksPerCU = (int)num("RTX_FRAME_BLOCKS_PER_CU", 0);
 	k.prune = !getenv("RTX_NO_PRUNE");
+	k.sources = !getenv("RTX_NO_SRC");
 	k.pruneBoxes = (int)num("RTX_PRUNE_BOXES", -1);
 	k.estimate = !getenv("RTX_NO_COST_ESTIMATE");
 	if (const char* e = getenv("RTX_COST_COEFFS")) sscanf(e, "%f,%f,%f", &k.costPerRef, &k.costPerLeaf, &k.costBase);
@@ -291,6 +304,53 @@ int ensureWork(rtx_scene* s)
 
 int prepareView(rtx_scene* s);
 
+// The source copies of every mesh's prune records (rtx_source.hip): copy 1 for the camera of the current view, copy 2 + l for point
+// light l.  The camera's is rebuilt when the camera moved, the lights' when the bias changed (a shadow ray starts bias along the
+// shading normal off the surface, so it passes the light at that distance: sigma).  Part of setting the view, like the tile lists.
+int buildSources(rtx_scene* s)
+{
+	if (s->srcMeshes.empty() || !s->knobs.sources) return RTX_OK;
+	const View& v = s->params.view;
+	const bool camSame = s->srcCamBuilt && !memcmp(s->srcBuiltCam, v.camPos, 12);
+	const bool lightsSame = s->srcLightsBuilt && s->srcBuiltBias == v.bias;
+	if (camSame && lightsSame) return RTX_OK;
+	bool any = false;
+	for (const auto& sm : s->srcMeshes) any = any || sm.base;
+	if (!any) return RTX_OK;
+	HIPCHK(hipDeviceSynchronize());      // (a launch may still be reading the copies)
+	const uint32_t nLights = std::min<uint32_t>((uint32_t)s->srcLightPos.size(), kMaxSrcLights);
+	for (const auto& sm : s->srcMeshes) {
+		if (!sm.base) continue;
+		auto build = [&](uint32_t copy, const float* S, double sigma, bool cam) {
+			PruneBlock* dst = sm.base + (size_t)copy * sm.nWide;
+			// (back to copy 0 first: a slot the kernel leaves alone must not keep the P of an earlier camera)
+			(void)hipMemcpyAsync(dst, sm.base, (size_t)sm.nWide * sizeof(PruneBlock), hipMemcpyDeviceToDevice, nullptr);
+			if (!(sigma >= 0.0) || !std::isfinite(sigma) || !std::isfinite((double)S[0] + S[1] + S[2])) return;      // no certificate: the copy stays generic
+			hipLaunchKernelGGL(rtxsrc::rtxSourceRefKernel, dim3((sm.nRefs + 255) / 256), dim3(256), 0, nullptr, sm.refA, sm.refB, sm.refC, sm.nRefs,
+			                   (double)S[0], (double)S[1], (double)S[2], sigma, cam ? 1 : 0, sm.refP, sm.blockP);
+			hipLaunchKernelGGL(rtxsrc::rtxSourceSlotKernel, dim3(sm.nWide), dim3(256), 0, nullptr, sm.slotRange, sm.nWide, (const float*)sm.refP, (const float*)sm.blockP, dst);
+		};
+		if (!camSame) build(1, v.camPos, 0.0, true);
+		if (!lightsSame)
+			for (uint32_t l = 0; l < nLights; l++) {
+				if (!s->srcLightIsPoint[l]) continue;      // (its copy stays generic; the kernels never select it)
+				// the line of a shadow ray -- orig = P + N bias, dir = -normalize(P - pos), both rounded (scene.cpp:787, lights.cpp:32-38) -- passes
+				// pos within |N| bias (1 + 2 u) + sqrt(3) u (3.01 |P|_inf + 2.01 |pos|_inf); |P|_inf <= vmax + kSrcAinfMax + |N| bias for the
+				// origins pruneAlive lets the copy serve.  Twice the rounding part for good measure.
+				const float* lp = s->srcLightPos[l].data();
+				const double nb = (double)s->srcNmax * std::fabs((double)v.bias);
+				const double lpm = std::max(std::fabs((double)lp[0]), std::max(std::fabs((double)lp[1]), std::fabs((double)lp[2])));
+				const double sigma = nb * 1.001 + 4.0 * 0x1p-24 * (3.01 * ((double)sm.vmax + kSrcAinfMax + nb) + 2.01 * lpm);
+				build(2 + l, lp, sigma, false);
+			}
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipDeviceSynchronize());
+	memcpy(s->srcBuiltCam, v.camPos, 12); s->srcCamBuilt = true;
+	s->srcBuiltBias = v.bias; s->srcLightsBuilt = true;
+	return RTX_OK;
+}
+
 // First-frame cost estimate of the current view into tileCost (rtx_kernels.hip, rtxCostSplatKernel).  Part of loading the
 // scene / setting the view, like the upload: the reference's "Render scene" timer starts after its loader too.
 int estimateCosts(rtx_scene* s)
@@ -345,6 +405,7 @@ struct FlatMesh {
 	std::vector<Node> nodes;
 	std::vector<WideNode> wide;
 	std::vector<PruneBlock> prune;
+	std::vector<uint32_t> slotRange;      // per wide-node slot: [begin, end) of leaf references covering the slot's subtree (rtx_source.hip)
 	PruneRec rootRec;
 	float vmaxMesh = 0;
 	bool boxesRegular = true;
@@ -430,13 +491,14 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 			// Prune records (rtxd::PruneRec): per binary node the true box of the triangles its subtree references and the
 			// largest |e1|_1 |e2|_1 among them (bottom-up over the pre-order array), then one record per wide-node slot.
 			// The triangle as the exact test sees it: v0, v0 + e1, v0 + e2 with the fp32 differences of makeRef (objects.cpp:70-71).
-			struct Agg { double lo[3], hi[3], ps, qlo[3], qhi[3], wlo, whi; bool planes; };
+			struct Agg { double lo[3], hi[3], ps, qlo[3], qhi[3], wlo, whi; bool planes; uint32_t rb, re; };
 			std::vector<Agg> agg(m.n_nodes);
 			for (uint32_t i = m.n_nodes; i-- > 0;) {
 				Agg& a = agg[i];
 				for (int k = 0; k < 3; k++) { a.lo[k] = a.qlo[k] = INFINITY; a.hi[k] = a.qhi[k] = -INFINITY; }
-				a.ps = 0; a.wlo = INFINITY; a.whi = -INFINITY; a.planes = true;
+				a.ps = 0; a.wlo = INFINITY; a.whi = -INFINITY; a.planes = true; a.rb = 0xffffffffu; a.re = 0;
 				auto merge = [&](const Agg& b) {
+					a.rb = std::min(a.rb, b.rb); a.re = std::max(a.re, b.re);
 					for (int k = 0; k < 3; k++) {
 						a.lo[k] = std::min(a.lo[k], b.lo[k]); a.hi[k] = std::max(a.hi[k], b.hi[k]);
 						a.qlo[k] = std::min(a.qlo[k], b.qlo[k]); a.qhi[k] = std::max(a.qhi[k], b.qhi[k]);
@@ -446,6 +508,7 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 				};
 				if (!isLeaf(i)) { merge(agg[i + 1]); merge(agg[rightOf(i)]); continue; }
 				const uint32_t begin = (uint32_t)m.leaf_begin[i], count = (uint32_t)m.leaf_count[i];
+				if (count) { a.rb = begin; a.re = begin + count; }
 				for (uint32_t r = begin; r < begin + count; r++) {
 					RefA ra; RefB rb; RefC rc;
 					makeRef(m, r, ra, rb, rc);
@@ -475,17 +538,18 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 				if (!(a.lo[0] <= a.hi[0])) return;         // no triangles
 				bool finite = std::isfinite(a.ps);
 				for (int c = 0; c < 3; c++) finite = finite && std::isfinite(a.lo[c]) && std::isfinite(a.hi[c]);
-				if (!finite) { pr.h[0] = pr.h[1] = pr.h[2] = INFINITY; pr.P = INFINITY; return; }      // never pruned
+				if (!finite) { pr.h[0] = pr.h[1] = pr.h[2] = INFINITY; pr.P = pr.Pgen = INFINITY; return; }      // never pruned
 				for (int c = 0; c < 3; c++) {
 					const double mid = 0.5 * (a.lo[c] + a.hi[c]), big = std::max(std::fabs(a.lo[c]), std::fabs(a.hi[c]));
 					pr.c[c] = (float)mid;
 					// [c - h, c + h] really contains [lo, hi] (c is rounded, h rounded up)
 					pr.h[c] = (float)((0.5 * (a.hi[c] - a.lo[c]) + std::fabs((double)pr.c[c] - mid)) * (1.0 + 0x1p-20) + 0x1p-24 * big + 1e-37);
 				}
-				pr.P = (float)(a.ps * (1.0 + 0x1p-20) + 1e-37);
+				pr.P = pr.Pgen = (float)(a.ps * (1.0 + 0x1p-20) + 1e-37);
 			};
 			makeRec(agg[0], rootRec);
 			prune.resize(wide.size());
+			out.slotRange.assign(wide.size() * 8, 0u);
 			for (int c = 0; c < 3; c++) vmaxMesh = std::max(vmaxMesh, (float)std::max(std::fabs(agg[0].lo[c]), std::fabs(agg[0].hi[c])));
 			for (size_t wi = 0; wi < wide.size(); wi++)
 				for (int k = 0; k < 4; k++) {
@@ -497,6 +561,7 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 					const uint32_t nd = slotNode[wi][k];
 					if (nd == kNoNode) continue;
 					const Agg& a = agg[nd];
+					if (a.rb < a.re) { out.slotRange[(wi * 4 + k) * 2] = a.rb; out.slotRange[(wi * 4 + k) * 2 + 1] = a.re; }
 					makeRec(a, pr);
 					if (!(a.lo[0] <= a.hi[0]) || !std::isfinite(pr.P)) continue;
 					if (a.planes && a.wlo <= a.whi && std::isfinite(a.wlo) && std::isfinite(a.whi)) {
@@ -603,13 +668,35 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		}
 		if ((rc = upload(s->owned, wide.data(), wide.size(), &dm.wide))) return bail(rc);
 		dm.nWide = (uint32_t)wide.size();
-		if ((rc = upload(s->owned, prune.data(), prune.size(), &dm.prune))) return bail(rc);
+		// prune blocks: copy 0 (any ray) followed by the source copies (rtxd::PruneRec: the camera's, the point lights'), all
+		// equal to copy 0 until buildSources patches their P
+		rtx_scene::SrcMesh sm;
+		const uint32_t nCopies = (s->knobs.sources && !prune.empty()) ? 2u + std::min<uint32_t>(desc->n_lights, kMaxSrcLights) : 1u;
+		if (!prune.empty()) {
+			PruneBlock* pb = nullptr;
+			if (hipMalloc((void**)&pb, (size_t)nCopies * prune.size() * sizeof(PruneBlock)) != hipSuccess) return bail(fail(RTX_ERR_DEVICE, "hipMalloc (prune blocks)"));
+			s->owned.push_back(pb);
+			gUploadedBytes += (size_t)nCopies * prune.size() * sizeof(PruneBlock);
+			for (uint32_t c = 0; c < nCopies; c++)
+				if (hipMemcpy(pb + (size_t)c * prune.size(), prune.data(), prune.size() * sizeof(PruneBlock), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(RTX_ERR_DEVICE, "hipMemcpy (prune blocks)"));
+			dm.prune = pb;
+			if (nCopies > 1) { sm.base = pb; sm.nWide = (uint32_t)prune.size(); }
+		}
 		dm.vmax = vmaxMesh;
 		dm.rootRec = rootRec;
 		if (!(vmaxMesh < 0x1p40f)) { dm.prune = nullptr; dm.rootRec.h[0] = dm.rootRec.h[1] = dm.rootRec.h[2] = INFINITY; }      // (huge or non-finite coordinates: nothing is pruned)
 		if ((rc = upload(s->owned, refA.data(), refA.size(), &dm.refA))) return bail(rc);
 		if ((rc = upload(s->owned, refB.data(), refB.size(), &dm.refB))) return bail(rc);
 		if ((rc = upload(s->owned, refC.data(), refC.size(), &dm.refC))) return bail(rc);
+		if (sm.base && vmaxMesh < 0x1p40f && m.n_refs) {
+			sm.nRefs = m.n_refs; sm.refA = dm.refA; sm.refB = dm.refB; sm.refC = dm.refC; sm.vmax = vmaxMesh;
+			if ((rc = upload(s->owned, flat.slotRange.data(), flat.slotRange.size(), &sm.slotRange))) return bail(rc);
+			if (hipMalloc((void**)&sm.refP, ((size_t)m.n_refs + m.n_refs / 64 + 2) * sizeof(float)) != hipSuccess) return bail(fail(RTX_ERR_DEVICE, "hipMalloc (source scratch)"));
+			s->owned.push_back(sm.refP);
+			sm.blockP = sm.refP + m.n_refs;
+		}
+		else sm.base = nullptr;
+		s->srcMeshes.push_back(sm);
 		if ((rc = upload(s->owned, m.tri_nrm, (size_t)m.n_tris * 9, &dm.nrm))) return bail(rc);
 		if ((rc = upload(s->owned, m.tri_uv, (size_t)m.n_tris * 6, &dm.uv))) return bail(rc);
 		if ((rc = upload(s->owned, m.tri_tb, m.tri_tb ? (size_t)m.n_tris * 6 : 0, &dm.tb))) return bail(rc);
@@ -648,6 +735,10 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		if (o.material < 0 || o.material > 3) return bail(fail(RTX_ERR_ARG, "bad material"));
 		if (o.type == RTX_OBJ_MESH && (o.mesh < 0 || (uint32_t)o.mesh >= desc->n_meshes)) return bail(fail(RTX_ERR_ARG, "bad mesh index"));
 		if (o.type == RTX_OBJ_MESH) s->analytic = false;
+		if (o.type == RTX_OBJ_PLANE) {
+			const double nl = std::sqrt((double)o.normal[0] * o.normal[0] + (double)o.normal[1] * o.normal[1] + (double)o.normal[2] * o.normal[2]);
+			if (!(nl <= 1e30)) s->srcNmax = INFINITY; else s->srcNmax = std::max(s->srcNmax, (float)(nl * 1.000001));
+		}
 		d.type = o.type; d.material = o.material;
 		memcpy(d.pos, o.pos, 12); memcpy(d.color, o.color, 12); memcpy(d.normal, o.normal, 12);
 		d.ior = o.ior; d.ambient = o.ambient; d.diffuse = o.diffuse; d.specular = o.specular; d.nSpecular = o.n_specular;
@@ -660,6 +751,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 			d.meshFlags = (hm.n_nodes ? 1u : 0u) | (dm.boxesRegular ? 2u : 0u) | (dm.nWide ? 4u : 0u);
 			d.nodes = dm.nodes; d.refA = dm.refA; d.refB = dm.refB; d.refC = dm.refC; d.wide = dm.wide; d.prune = dm.prune;
 			d.nNodes = dm.nNodes; d.vmax = dm.vmax;
+			d.srcStride = (dm.prune && s->srcMeshes[o.mesh].base) ? s->srcMeshes[o.mesh].nWide : 0u;
 			// The box test inflates a slot's true box by 216 dmax |orig - v0|_inf P (pruneAlive): with the origin about a mesh size away
 			// that is 216 P mesh sizes, so only meshes of small triangles gain from it; the plane test does not depend on P.
 			d.pruneBoxes = (dm.prune && std::isfinite(dm.rootRec.P) && dm.rootRec.P < 1.0f / 216.0f) ? 1u : 0u;
@@ -690,6 +782,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		d.type = l.type; memcpy(d.color, l.color, 12); d.intensity = l.intensity;
 		memcpy(d.dir, l.dir, 12); memcpy(d.pos, l.pos, 12);
 		d.nPoints = l.n_points;
+		s->srcLightPos.push_back({ { l.pos[0], l.pos[1], l.pos[2] } });
+		s->srcLightIsPoint.push_back(l.type == RTX_LIGHT_POINT ? 1 : 0);
 		if (l.type == RTX_LIGHT_AREA) {
 			if (!l.points || l.n_points == 0) return bail(fail(RTX_ERR_ARG, "area light without sample points"));
 			int rc;
@@ -701,6 +795,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 	if ((rc = upload(s->owned, objs.data(), objs.size(), &s->params.objects))) return bail(rc);
 	if ((rc = upload(s->owned, lights.data(), lights.size(), &s->params.lights))) return bail(rc);
 	s->params.nObjects = desc->n_objects; s->params.nLights = desc->n_lights;
+	s->params.nSrcLights = s->knobs.sources ? std::min<uint32_t>(desc->n_lights, kMaxSrcLights) : 0u;
 	if (desc->sky_w && desc->sky_h && desc->sky[0]) {
 		const float* faces[6];
 		for (int k = 0; k < 6; k++) {
@@ -913,8 +1008,9 @@ int ensureFrameBuffers(rtx_scene* s, size_t tiles, size_t* perQueueOut)
 // frame for either way of rendering it, the buffers of the single launch.
 int prepareView(rtx_scene* s)
 {
-	int rc = estimateCosts(s);
+	int rc = buildSources(s);
 	if (rc) return rc;
+	if ((rc = estimateCosts(s))) return rc;
 	const View& v = s->params.view;
 	if (v.width > 0xffffu || v.height > 0xffffu || s->params.bandH) return RTX_OK;
 	const uint32_t tilesX = (v.width - 1 + 7) / 8, lastRow = v.height - 1;
@@ -1493,6 +1589,15 @@ int rtx_cost_grid_read(rtx_scene* s, uint32_t* out, size_t n, uint32_t* grid_w, 
 	HIPCHK(hipSetDevice(s->device));
 	HIPCHK(hipDeviceSynchronize());
 	HIPCHK(hipMemcpy(out, s->costGrid, std::min(n, 2 * cells) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	return RTX_OK;
+}
+
+// Host only: P_S of triangles (v0, e1, e2: 9 floats each) for the source S, sigma (rtx_source.hip, sourceP) -- the very function the
+// device kernels run, for the CPU tests of the bound.
+int rtx_source_p_probe(const float* tris9, uint32_t n, const double* S3, double sigma, int cam, float* out)
+{
+	if (!tris9 || !S3 || !out) return fail(RTX_ERR_ARG, "rtx_source_p_probe: NULL argument");
+	for (uint32_t i = 0; i < n; i++) out[i] = rtxsrc::sourceP(tris9 + (size_t)i * 9, tris9 + (size_t)i * 9 + 3, tris9 + (size_t)i * 9 + 6, S3, sigma, cam != 0);
 	return RTX_OK;
 }
 

@@ -50,8 +50,20 @@ static_assert(sizeof(RefA) == 16 && sizeof(RefB) == 16 && sizeof(RefC) == 8, "re
 // cell of its leaf (objects.cpp:587-631) but what it ACCEPTS lies near the triangle: with det_c >= 1e-8 (objects.cpp:75-79)
 // the point orig + t_c dir is within 36 u dmax |orig - v0|_inf P / 1e-8 of it, whatever the conditioning.  A slot whose
 // inflated box no ray of the bundle can meet within [0, limit] cannot contribute and is not walked.  h < 0: no triangles.
-struct PruneRec { float c[3]; float P; float h[3]; float pad; };
+//
+// Source records (round 4): the bound above takes the worst conditioning the reference lets through (det_c = 1e-8).
+// When every ray of a walk passes within sigma of ONE point S -- the camera (primary rays: sigma = 0) or a point light (shadow
+// rays: sigma ~ bias) -- the conditioning of an accepted pair is bounded by geometry instead: det = H |dir| / |S' - X*| with H the
+// height of S' above the triangle's plane and X* the exact plane intersection, so the accepted point lies within
+//     216 dmax |orig - v0|_inf P_S,    P_S ~ 0.0152 E u lsum D / (H |m|_2)                          (rtx_source.hip, sourceP)
+// of the triangle -- the same formula with a per-source P, two to three orders of magnitude below s1 s2 for all but the few
+// triangles whose plane passes close to S.  Every mesh therefore has 2 + nSrcLights copies of its prune blocks: copy 0 holds
+// P = Pgen = max s1 s2 (any ray), copy 1 the camera's P_S (rebuilt with the view), copy 2 + l point light l's.  Pgen is the
+// fallback inside a source copy where the certificate's side condition fails at run time (origin further than kSrcAinfMax from the box).
+struct PruneRec { float c[3]; float P; float h[3]; float Pgen; };
 static_assert(sizeof(PruneRec) == 32, "prune record = two dwordx4");
+constexpr uint32_t kMaxSrcLights = 6;        // point lights with a source copy (lights beyond use copy 0)
+constexpr float kSrcAinfMax = 32.0f;         // the source certificate assumes |orig - v0|_inf <= this (sourceP)
 // Its companion: box (centre qc, half-extent qr) of the scaled plane normals q = (e2 x e1) / (|e1|_1 |e2|_1) of those triangles
 // (|q|_inf <= 1) and the range [wlo, whi] of their plane offsets v0 . q.  The first stage of the bundle filter -- every ray
 // certainly sees the back / starts beyond the plane / ends before it -- holds for ALL triangles of the slot when it holds for
@@ -107,7 +119,7 @@ struct Object {
 	const Node* nodes; const RefA* refA; const RefB* refB; const RefC* refC; const struct WideNode* wide; const struct PruneBlock* prune;
 	uint32_t nNodes; float vmax;
 	uint32_t pruneBoxes;       // the PruneRec test can prune for this mesh (small triangles: P well under 1 / 216, see rtx_scene_create)
-	uint32_t pad3;
+	uint32_t srcStride;        // prune blocks per source copy (= the number of wide nodes), 0: the mesh has only copy 0
 };
 static_assert(sizeof(Object) == 192, "object record = three 64-byte lines");
 
@@ -159,7 +171,7 @@ struct Params {
 	// recursion frames: [slot][field][lane]
 	float* frames;
 	uint32_t totalLanes;
-	uint32_t pad0;
+	uint32_t nSrcLights;            // point lights 0 .. nSrcLights - 1 have a source copy of the prune blocks (rtxd::PruneRec)
 	float* fb;
 	// probe rays (rtx_cast_rays)
 	const float* probeRays;

@@ -655,6 +655,9 @@ __shared__ float pruneUni[4][16];
 #ifndef RTX_PRUNE_ROOT
 #define RTX_PRUNE_ROOT 0      // 1: the prune records of the root's slots are evaluated too
 #endif
+#ifndef RTX_SRC
+#define RTX_SRC 1             // source copies of the prune records (rtxd::PruneRec): 0 = every walk uses copy 0
+#endif
 #ifndef RTX_PRUNE_RCP
 #define RTX_PRUNE_RCP 1       // the range of 1 / dir from the bundle's direction box (six v_rcp_f32) instead of three wave-wide min / max reductions
 #endif
@@ -697,7 +700,10 @@ __device__ __forceinline__ bool pruneAlive(const f4v& r0, const f4v& r1, const f
 	const float cx = (fl & 1u) ? -r0.x : r0.x, cy = (fl & 2u) ? -r0.y : r0.y, cz = (fl & 4u) ? -r0.z : r0.z;
 	// largest |orig - vertex| coordinate over the bundle and the box
 	const float ainf = fmaxf(fmaxf(fmaxf(cx - ub.z, ub.w - cx) + r1.x, fmaxf(cy - uc.x, uc.y - cy) + r1.y), fmaxf(cz - uc.z, uc.w - cz) + r1.z);
-	const float rho = __builtin_fmaf(ue.x * ainf, r0.w, 0x1p-17f * (ainf + ue.y)) * (1.0f + 0x1p-20f) + 1e-30f;
+	// P of the walk's source copy (rtxd::PruneRec: the camera's, a point light's) holds for origins within kSrcAinfMax of the box;
+	// beyond, and in copy 0 (r0.w == r1.w), the unconditional Pgen
+	const float Pn = ainf <= kSrcAinfMax ? r0.w : r1.w;
+	const float rho = __builtin_fmaf(ue.x * ainf, Pn, 0x1p-17f * (ainf + ue.y)) * (1.0f + 0x1p-20f) + 1e-30f;
 	const float hx = r1.x + rho, hy = r1.y + rho, hz = r1.z + rho;
 	const float inf = __builtin_inff();
 	// per axis (mirrored so that 1 / dir > 0): entry >= (lo' - o_hi) inv, exit <= (hi' - o_lo) inv over the ranges
@@ -748,7 +754,7 @@ __device__ __forceinline__ bool planeAlive(const f4v& r0, const f4v& r1, const B
 template <bool STATS, bool CULL, bool REGULAR, bool WIDE = false, bool FEWRAYS = false, bool BOXES = true>
 __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
                                          float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
-                                         float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt)
+                                         float& bt, float& bu, float& bv, uint32_t& btri, Counts& cnt, uint32_t srcSel = 0)
 {
 	// mp = the third line of the object's record (rtxd::Object): nodes, refA, refB, refC, wide, prune, nNodes, vmax
 #define RTX_MP(k) (((uint64_t)mp[2 * (k) + 1] << 32) | mp[2 * (k)])
@@ -780,6 +786,8 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 		pruneRecs = (const RTX_AS1 char*)(uintptr_t)RTX_MP(5);
 #undef RTX_MP
 		if (pruneRecs != nullptr) {
+			// the copy of the prune blocks that belongs to the source all rays of this walk pass through (0: none -- traceWave)
+			pruneRecs += (size_t)srcSel * mp[15] * sizeof(PruneBlock);
 			// Range of 1 / dir over the rays of this walk, from the bundle's direction box (every ray's direction lies in dc +- rd):
 			// 1 / x is monotone on either side of 0, so every lane's RN(1 / d) lies between the reciprocals of the box's ends --
 			// v_rcp_f32 (1 ulp) widened by 2^-21 covers its own error, the rounding of the ends and the lane's own rounding.
@@ -1132,8 +1140,10 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 // state machine fits the register file, and a small frame lasts as long as its slowest wave's chain of dependent rays.
 template <bool STATS, bool MESH = true, bool FEWRAYS = false, bool BOXES = true>
 __device__ __forceinline__ void traceWave(const Params& P, bool active, bool shadow, V3 o, V3 d, float tmax,
-                                          Hit& h, Counts& cnt)
+                                          Hit& h, Counts& cnt, uint32_t src = 0)
 {
+	// src: what the lane's ray is known to pass through (rtxd::PruneRec): 0 nothing, 1 the camera (o == view.camPos exactly),
+	// 2 + l point light l (o = P + N bias, d = -normalize(P - pos_l): castRayWave)
 	h.obj = -1; h.t = tmax; h.tri = 0; h.u = 0; h.v = 0;
 	if (STATS) cnt.rays += __popcll(ballot(active));
 	const bool cull = (uni(P.view.flags) & 1u) != 0;
@@ -1221,7 +1231,17 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 					B = makeBundle(cl, o, d);
 				}
 				float bt, bu, bv; uint32_t btri;
-				if (!STATS && cull && regular && wideOk) meshWalk<STATS, true, true, true, FEWRAYS, BOXES>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
+				// The walk may use a source copy of the prune records when ALL its rays pass through that source and have a direction
+				// of length 0.99 .. 1.001 (what sourceP assumes; origins further than kSrcAinfMax from a box fall back per record)
+				uint32_t srcSel = 0;
+				if (RTX_SRC && !STATS) {
+					const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)src, __builtin_ctzll(ballot(cl)));
+					if (s0 != 0) {
+						const float l2 = len2(d);
+						if (ballot(cl && !(src == s0 && l2 >= 0.9802f && l2 <= 1.002f)) == 0) srcSel = s0;
+					}
+				}
+				if (!STATS && cull && regular && wideOk) meshWalk<STATS, true, true, true, FEWRAYS, BOXES>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt, srcSel);
 				else if (cull && regular) meshWalk<STATS, true, true, false, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				else if (cull) meshWalk<STATS, true, false, false, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				else meshWalk<STATS, false, false, false, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
@@ -1279,6 +1299,7 @@ struct Lane {
 	float qtmax;                  // (origin / direction of the pending request are derived from the state: see castRayWave)
 	bool qmoot;                   // the pending shadow ray cannot influence the pixel (see advance)
 	bool qarea;                   // the pending shadow ray goes to a sample point of an area light (consume: no second look at the light's record)
+	uint32_t qsrc;                // the pending shadow ray's source class: 2 + l for point light l with a source copy of the prune records, else 0
 };
 
 __device__ __forceinline__ float& frameAt(const Params& P, uint32_t gl, int slot, int field)
@@ -1428,6 +1449,7 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 			// ray cannot influence the pixel ("moot"), and the product kernels do not walk it (castRayWave).
 			s.qmoot = s.mat == 0 && fmaxRef(0.f, dot(s.N, -s.L)) == 0.f;
 			s.qarea = lt == 3;
+			s.qsrc = (lt == 2 && s.li < P.nSrcLights) ? 2u + s.li : 0u;
 			s.qtmax = dist;               // the ray itself: Ray{P + N*bias, -L, ShadowRay} (scene.cpp:787), built in castRayWave
 			s.state = ST_WAIT_SHADOW;
 			RTX_ACC(1)
@@ -1594,7 +1616,8 @@ __device__ __forceinline__ const Params& freshParams(const Params& P)
 #endif
 }
 
-template <bool STATS, bool MESH = true, bool FEWRAYS = false, bool BOXES = true>
+// CAM: the rays handed in start at the camera (o == view.camPos bit for bit: pass 1, SSAA, the frame kernel -- not the probe rays)
+template <bool STATS, bool MESH = true, bool FEWRAYS = false, bool BOXES = true, bool CAM = true>
 __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3 d, uint32_t gl, Counts& cnt)
 {
 	const Params& P = freshParams(P0);
@@ -1604,7 +1627,7 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 	s.obj = 0; s.mat = 0; s.li = 0; s.si = 0;
 	s.P = s.N = s.objColor = s.diff = s.spec = s.L = s.I = mk(0, 0, 0);
 	s.specCoef = s.nSpec = s.dsum = s.ssum = 0;
-	s.qtmax = kFltMax; s.qmoot = false; s.qarea = false;
+	s.qtmax = kFltMax; s.qmoot = false; s.qarea = false; s.qsrc = 0;
 	advance(P, s, gl);
 #if RTX_DBG
 	unsigned long long dbgRounds = 0, dbgTrace = 0, dbgState = 0;
@@ -1623,6 +1646,8 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 		const V3 qo = qshadow ? s.P + s.N * P.view.bias : s.ro, qd = qshadow ? -s.L : s.rd;
 		const bool qactive = s.state != ST_DONE && (STATS || !moot);
 		const float qtmax = s.qtmax;
+		// (a ray of recursion depth 0 is the one handed in; reflected / refracted rays pass through no known point)
+		const uint32_t qsrc = qshadow ? s.qsrc : ((CAM && s.sp == 0) ? 1u : 0u);
 		if (MESH && RTX_PARK) {
 			const uint32_t t = threadIdx.x;
 			parkedState[0][t] = s.P.x; parkedState[1][t] = s.P.y; parkedState[2][t] = s.P.z;
@@ -1638,7 +1663,7 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 			}
 			asm volatile("" ::: "memory");
 		}
-		traceWave<STATS, MESH, FEWRAYS, BOXES>(freshParams(P0), qactive, qshadow, qo, qd, qtmax, h, cnt);
+		traceWave<STATS, MESH, FEWRAYS, BOXES>(freshParams(P0), qactive, qshadow, qo, qd, qtmax, h, cnt, qsrc);
 		if (MESH && RTX_PARK) {
 			asm volatile("" ::: "memory");
 			const uint32_t t = threadIdx.x;
@@ -2204,7 +2229,7 @@ __global__ void __launch_bounds__(256) rtxProbeKernel(const Params P)
 			out[0] = hit ? 1.f : 0.f; out[1] = hit ? (float)h.obj : -1.f; out[2] = mesh ? (float)h.tri : -1.f;
 			out[3] = h.t; out[4] = hit ? h.u : -1.f; out[5] = hit ? h.v : -1.f; out[6] = 0; out[7] = 0;
 		}
-		const V3 c = castRayWave<false>(P, valid, o, d, gl, cnt);
+		const V3 c = castRayWave<false, true, false, true, false>(P, valid, o, d, gl, cnt);
 		if (valid) { float* pc = P.probeColours + (size_t)i * 3; pc[0] = c.x; pc[1] = c.y; pc[2] = c.z; }
 	}
 }

@@ -14,3 +14,39 @@ def test_accepted_hits_lie_within_the_bound_and_not_within_an_ulp_margin():
         assert ratio < 0.25, "%s: an accepted hit at %.3f of the bound (the margin of 4 is gone)" % (mode, ratio)
         worst_off = max(worst_off, off)
     assert worst_off > 1e-3, "the adversarial pairs no longer reach hits that lie visibly off their triangle"
+
+
+def test_source_records_bound_accepted_hits():
+    """with the source certificate (rays that start at the camera / end at a point light) an accepted hit lies within
+    216 dmax ainf P_S + 2^-17 (ainf + |orig|) of its triangle's box, P_S from the function the device runs (rtx_source_p_probe); pairs
+    without a certificate fall back to Pgen and stay within the unconditional bound."""
+    from tools.research.src_bound_check import run
+    rng = np.random.default_rng(11)
+    certified = 0
+    for cam in (True, False):
+        for mode in ("graze", "sliver", "generic"):
+            ratio, ncert, off_cert, ratio_cert = run(40000, mode, cam, rng, quiet=True)
+            assert ratio < 0.25, "%s %s: an accepted hit at %.3f of the bound" % ("camera" if cam else "light", mode, ratio)
+            assert ratio_cert < 0.25
+            certified += ncert
+    assert certified > 5000, "the sample no longer exercises the certificate"
+
+
+def test_source_p_never_exceeds_pgen_and_needs_height():
+    import rendering_amd as RA
+    rng = np.random.default_rng(3)
+    n = 2000
+    v0 = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    e1 = (rng.normal(size=(n, 3)) * 0.02).astype(np.float32); e2 = (rng.normal(size=(n, 3)) * 0.02).astype(np.float32)
+    pgen = np.abs(e1.astype(np.float64)).sum(1) * np.abs(e2.astype(np.float64)).sum(1)
+    for cam in (True, False):
+        p = RA.source_p_probe(v0, e1, e2, [0.3, 4.0, -2.0], 1e-4, cam).astype(np.float64)
+        assert (p <= pgen * (1 + 1e-5) + 1e-36).all() and (p > 0).all()
+        assert (p < 0.05 * pgen).mean() > 0.9           # a source well off the planes: the certificate holds nearly everywhere
+    # a source IN the plane of a triangle has no certificate; so have big triangles and degenerate ones
+    S = (v0[0].astype(np.float64) + 0.3 * e1[0] + 5.0 * e2[0])
+    assert RA.source_p_probe(v0[:1], e1[:1], e2[:1], S, 0.0, True)[0] >= np.float32(pgen[0])
+    big = RA.source_p_probe(v0[:1], e1[:1] * 50, e2[:1] * 50, [0.3, 4.0, -2.0], 0.0, True)[0]
+    assert big >= np.float32(pgen[0] * 2500 * 0.999)
+    z = RA.source_p_probe(v0[:1], e1[:1] * 0, e2[:1], [0.3, 4.0, -2.0], 0.0, True)[0]
+    assert z == z and z >= 0
