@@ -1508,6 +1508,8 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 		{ unsigned long long z[32] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gDbgHist), z, sizeof(z), 16 * sizeof(unsigned long long))); }
 		if (h[32] + h[33] + h[34]) fprintf(stderr, "[rtx] walk cycles (waves whose walk ended early inside the reference passes are not counted for that batch): nodes %llu, reference passes without the exact tests %llu, exact tests %llu\n", h[32], h[33], h[34]);
 		{ unsigned long long z[3] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gDbgHist), z, sizeof(z), 32 * sizeof(unsigned long long))); }
+		if (h[40]) fprintf(stderr, "[rtx] wide walks %llu, of shadow bundles %llu: their node visits %llu, leaves %llu, filter passes %llu, exact tests %llu (these six: since the last print)\n", h[40], h[41], h[42], h[43], h[44], h[45]);
+		{ unsigned long long z[6] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gDbgHist), z, sizeof(z), 40 * sizeof(unsigned long long))); }
 		if (h[15]) fprintf(stderr, "[rtx] work items %llu: slowest = %llu trace rounds, %llu cycles in Render::trace + %llu in the castRay state machine; "
 		                   "all items: %llu rounds, %.0f + %.0f cycles per round\n", h[15], h[9], h[10], h[11], h[12], (double)h[13] / (double)h[12], (double)h[14] / (double)h[12]);
 	}

@@ -58,6 +58,9 @@ namespace {
 #ifndef RTX_TRI_BPERMUTE
 #define RTX_TRI_BPERMUTE 1
 #endif
+#ifndef RTX_RO_EXACT
+#define RTX_RO_EXACT 1        // bundle filter: the origin box weighted by |dc x e| per axis instead of dmax |e|_1 (bundleRejects2)
+#endif
 #define RTX_AS4 __attribute__((address_space(4)))
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -376,7 +379,8 @@ __device__ unsigned long long gDbgHist[64];   // [0,8) certificate outcomes (one
 #define RTX_T0
 #define RTX_ACC(k)
 #endif
-struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips, wChunks, wChunkSkips, triLanes, moot, cNodes, cFilter, cExact; };
+struct Counts { unsigned long long rays, box, tri, wNodes, wTri, wS2, wS3, wS4, wLeaves, wLeafSkips, wChunks, wChunkSkips, triLanes, moot, cNodes, cFilter, cExact,
+                aWalks, sWalks, sVisits, sLeaves, sPasses, sExact; };      // (RTX_DBG: wide walks; s*: of shadow bundles only)
 
 // Ordering of scalar loads.  SMEM returns out of order, so lgkmcnt can only be waited down to zero: a load issued
 // before the first use of the previous one is covered by the same wait and nothing overlaps.  after(x, v) is an
@@ -415,6 +419,7 @@ struct Bundle {
 	float kd;          // K * dmax            (K = 2^-18, dmax = max |dir_i| over the bundle)
 	float roMax;       // max_i ro_i
 	float kdRoSum;     // dmax * (rox + roy + roz)
+	float roRd;        // (rox + roy + roz) * max_i rd_i: the second-order part of the u / v radii (bundleRejects2)
 	bool sane;         // every active lane has finite, moderate coordinates (|orig_i| < 2^40, |dir_i| < 2^20)
 };
 constexpr float kFilterK = 0x1p-18f;     // 64 u: covers the reference's rounding errors AND the filter's own (see bundleRejects)
@@ -459,6 +464,7 @@ __device__ __forceinline__ Bundle makeBundle(bool active, const V3& o, const V3&
 	B.kd = unif(kFilterK * dmax);
 	B.roMax = unif(fmaxf(fmaxf(B.rox, B.roy), B.roz));
 	B.kdRoSum = unif(dmax * (B.rox + B.roy + B.roz) * (1.0f + 0x1p-20f));
+	B.roRd = unif((B.rox + B.roy + B.roz) * fmaxf(fmaxf(B.rdx, B.rdy), B.rdz) * (1.0f + 0x1p-20f));
 	// NaN / inf / huge coordinates fail these compares: the filter then rejects nothing and the lanes run the exact path
 	const bool tame = fabsf(o.x) < 0x1p40f && fabsf(o.y) < 0x1p40f && fabsf(o.z) < 0x1p40f && fabsf(d.x) < 0x1p20f && fabsf(d.y) < 0x1p20f && fabsf(d.z) < 0x1p20f;
 	B.sane = ballot(active && !tame) == 0;
@@ -535,12 +541,30 @@ __device__ __forceinline__ bool bundleRejects2(const Bundle& B, const RefA& ra, 
 	// u: Nu = d . (e2 x a)
 	const float wux = __builtin_fmaf(e2y, az, -(e2z * ay)), wuy = __builtin_fmaf(e2z, ax, -(e2x * az)), wuz = __builtin_fmaf(e2x, ay, -(e2y * ax));
 	float nuc = __builtin_fmaf(B.dcz, wuz, __builtin_fmaf(B.dcy, wuy, B.dcx * wux));
-	const float nur = __builtin_fmaf(B.kdRoSum, s2, __builtin_fmaf(B.rdz, fabsf(wuz), __builtin_fmaf(B.rdy, fabsf(wuy), B.rdx * fabsf(wux)))) * (1.0f + 0x1p-20f);
+#if RTX_RO_EXACT
+	// The origin box's part of the radius.  Nu = (a + do) . ((dc + dd) x e2) = Nu(centre) + dd . wu + do . (dc x e2) + do . (dd x e2): the third
+	// term is bounded by sum ro_k |(dc x e2)_k| -- not by dmax |e2|_1 sum ro_k, which is what a box of origins costs a bundle of
+	// SHADOW rays (a tilted patch of surface points; primary rays share their origin: nothing changes for them): 41 % fewer
+	// survivors for shadow bundles in tools/research/bundle_filter_sim.py, exact tests per headline launch 9.45 M -> 5.02 M -- and
+	// the last by (sum ro_k) max rd |e2|_1.
+	const float cux = __builtin_fmaf(B.dcy, e2z, -(B.dcz * e2y)), cuy = __builtin_fmaf(B.dcz, e2x, -(B.dcx * e2z)), cuz = __builtin_fmaf(B.dcx, e2y, -(B.dcy * e2x));
+	const float nurO = __builtin_fmaf(B.roRd, s2, __builtin_fmaf(B.roz, fabsf(cuz), __builtin_fmaf(B.roy, fabsf(cuy), B.rox * fabsf(cux))));
+#else
+	const float nurO = B.kdRoSum * s2;
+#endif
+	const float nur = (nurO + __builtin_fmaf(B.rdz, fabsf(wuz), __builtin_fmaf(B.rdy, fabsf(wuy), B.rdx * fabsf(wux)))) * (1.0f + 0x1p-19f);
 	const float Eu = __builtin_fmaf(f.kda, s2, kFilterEta);
 	// v: Nv = d . (a x e1)
 	const float wvx = __builtin_fmaf(ay, e1z, -(az * e1y)), wvy = __builtin_fmaf(az, e1x, -(ax * e1z)), wvz = __builtin_fmaf(ax, e1y, -(ay * e1x));
 	float nvc = __builtin_fmaf(B.dcz, wvz, __builtin_fmaf(B.dcy, wvy, B.dcx * wvx));
-	const float nvr = __builtin_fmaf(B.kdRoSum, s1, __builtin_fmaf(B.rdz, fabsf(wvz), __builtin_fmaf(B.rdy, fabsf(wvy), B.rdx * fabsf(wvx)))) * (1.0f + 0x1p-20f);
+#if RTX_RO_EXACT
+	// (Nv = (dc + dd) . ((a + do) x e1): do . (e1 x dc))
+	const float cvx = __builtin_fmaf(e1y, B.dcz, -(e1z * B.dcy)), cvy = __builtin_fmaf(e1z, B.dcx, -(e1x * B.dcz)), cvz = __builtin_fmaf(e1x, B.dcy, -(e1y * B.dcx));
+	const float nvrO = __builtin_fmaf(B.roRd, s1, __builtin_fmaf(B.roz, fabsf(cvz), __builtin_fmaf(B.roy, fabsf(cvy), B.rox * fabsf(cvx))));
+#else
+	const float nvrO = B.kdRoSum * s1;
+#endif
+	const float nvr = (nvrO + __builtin_fmaf(B.rdz, fabsf(wvz), __builtin_fmaf(B.rdy, fabsf(wvy), B.rdx * fabsf(wvx)))) * (1.0f + 0x1p-19f);
 	const float Ev = __builtin_fmaf(f.kda, s1, kFilterEta);
 	if (!CULL) { nuc *= f.sg; nvc *= f.sg; }
 	const float nuLo = nuc - nur - Eu;
@@ -826,6 +850,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 			if (!B.sane) pruneRecs = nullptr;      // NaN / inf / huge coordinates somewhere in the bundle: nothing is pruned
 		}
 	}
+	if (WIDE && RTX_DBG) { cnt.aWalks++; if (shadow) cnt.sWalks++; }
 	if (WIDE) {
 		// (the rays in `consider` have passed the root box: traceWave)
 		const uint64_t m0 = ballot(consider);
@@ -846,7 +871,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 			auto noteLeaf = [&](int32_t link, uint32_t first, uint64_t m) {
 				const bool in = ((((lane & 32u) ? (uint32_t)(m >> 32) : (uint32_t)m) >> (lane & 31u)) & 1u) != 0;
 				const uint32_t n = (uint32_t)~link;
-				if (RTX_DBG) cnt.wLeaves++;
+				if (RTX_DBG) { cnt.wLeaves++; if (shadow) cnt.sLeaves++; }
 				if (m != 0 && n != 0) {
 					if (lane == 0) {
 						LeafEntry en;
@@ -870,7 +895,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 					continue;
 				}
 				if (inM == 0) continue;
-				if (RTX_DBG) cnt.wNodes++;
+				if (RTX_DBG) { cnt.wNodes++; if (shadow) cnt.sVisits++; }
 				const WideNode* w = wideNodes + (uint32_t)(link - 1);
 				const u32x16 wa = sload16(w), wb = sload16((const char*)w + 64);
 				// Which slots can contribute at all: lane k & 3 looks at slot k & 3 (bits 0..3 of the ballot are used).
@@ -1029,11 +1054,11 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 			FilterState fs;
 			const bool valid = p0 + lane < total;
 			const bool rej1 = bundleRejects1<CULL>(B, tmaxB, ra, rb, rc, fs);
-			if (RTX_DBG) cnt.wChunks++;
+			if (RTX_DBG) { cnt.wChunks++; if (shadow) cnt.sPasses++; }
 			if (ballot(valid && !rej1) == 0) { if (RTX_DBG) cnt.wChunkSkips++; return false; }
 			const bool rej2 = bundleRejects2<CULL>(B, ra, rb, rc, fs);
 			uint64_t cand = ballot(valid && !rej1 && !rej2);
-			if (RTX_DBG) { cnt.wTri += __popcll(cand); if (cand == 0) cnt.wS2++; }
+			if (RTX_DBG) { cnt.wTri += __popcll(cand); if (shadow) cnt.sExact += __popcll(cand); if (cand == 0) cnt.wS2++; }
 			if (cand == 0) return false;
 			bool improved = false;
 #if RTX_DBG
@@ -1736,6 +1761,7 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 		atomicAdd(P.counters + 15, c.moot);
 #if RTX_DBG
 		atomicAdd(&gDbgHist[32], c.cNodes); atomicAdd(&gDbgHist[33], c.cFilter); atomicAdd(&gDbgHist[34], c.cExact);
+		atomicAdd(&gDbgHist[40], c.aWalks); atomicAdd(&gDbgHist[41], c.sWalks); atomicAdd(&gDbgHist[42], c.sVisits); atomicAdd(&gDbgHist[43], c.sLeaves); atomicAdd(&gDbgHist[44], c.sPasses); atomicAdd(&gDbgHist[45], c.sExact);
 #endif
 	}
 }
