@@ -13,6 +13,7 @@ image is compared with the frame rank 0 renders alone (--no-verify skips that). 
 """
 import argparse
 import subprocess
+import tempfile
 import json
 import os
 import sys
@@ -32,13 +33,20 @@ REF_CHILD = r"""
 import os, sys, time
 sys.path.insert(0, %r)
 from tools import ref_harness as R
+import numpy as np
 s = R.RefScene(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), workers=int(sys.argv[4]))
-t0 = time.perf_counter(); s.pass1(); dt = time.perf_counter() - t0
+t0 = time.perf_counter(); fb = s.pass1(); dt = time.perf_counter() - t0
 print("REF_PASS1_SECONDS %%.6f" %% dt)
+# (untimed) the framebuffers themselves, for the whole-frame comparison with what the GPU renders in the timed region
+np.save(sys.argv[5] + ".pass1.npy", fb)
+if int(sys.argv[6]):
+    t0 = time.perf_counter(); fb2 = s.ssaa(fb); dt = time.perf_counter() - t0
+    print("REF_SSAA_SECONDS %%.6f" %% dt)
+    np.save(sys.argv[5] + ".frame.npy", fb2)
 """
 
 
-def reference_baseline(scene_path, width, height, gpu_scene, cores):
+def reference_baseline(scene_path, width, height, gpu_scene, cores, ssaa=True):
     """The REAL reference (oracle/_ref, built from /root/reference by oracle/Makefile where that tree exists; the .so
     travels with the repo): Scene::launchWorkers of the whole frame with nWorkers = host cores, in a child process
     (the reference prints progress to stdout and keeps process-global option flags).  None if it is not available."""
@@ -46,8 +54,9 @@ def reference_baseline(scene_path, width, height, gpu_scene, cores):
     if not ref_harness.available():
         return None
     try:
-        out = subprocess.run([sys.executable, "-c", REF_CHILD % ROOT, scene_path, str(width), str(height), str(cores)],
-                             cwd=ROOT, capture_output=True, text=True, timeout=180)
+        dump = os.path.join(tempfile.gettempdir(), "bench_ref_%d" % os.getpid())
+        out = subprocess.run([sys.executable, "-c", REF_CHILD % ROOT, scene_path, str(width), str(height), str(cores), dump, "1" if ssaa else "0"],
+                             cwd=ROOT, capture_output=True, text=True, timeout=300)
         sec = [float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith("REF_PASS1_SECONDS")]
         if out.returncode != 0 or not sec:
             return None
@@ -60,9 +69,40 @@ def reference_baseline(scene_path, width, height, gpu_scene, cores):
     gpu_scene.render_pass1(fb)
     rays = int(gpu_scene.counters()[0])
     gpu_scene.counters_enable(False)
-    return {"value": round(rays / sec[0] / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "reference",
-            "sample": "pass 1 (Scene::launchWorkers, nWorkers = %d) of the whole %dx%d frame by the reference itself: %d rays in %.1f s"
-                      % (cores, width, height, rays, sec[0])}
+    res = {"value": round(rays / sec[0] / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "reference",
+           "sample": "pass 1 (Scene::launchWorkers, nWorkers = %d) of the whole %dx%d frame by the reference itself: %d rays in %.1f s"
+                     % (cores, width, height, rays, sec[0])}
+    # Whole-frame parity of what is timed: the reference's own framebuffers of THIS frame against the product path's
+    # (rtx_render_frame, as in the timed region), bit for bit -- pass 1 everywhere; the frame after SSAA everywhere but row 0 / column 0,
+    # where the reference reads uninitialised mask entries.
+    try:
+        ref1 = np.load(dump + ".pass1.npy")
+        gpu_scene.render_pass1(fb)
+        torch.cuda.synchronize()
+        got = fb.cpu().numpy()
+        nd = int((got.view(np.uint32) != ref1.view(np.uint32)).any(-1).sum())
+        res["parity"] = {"pass1_equals_reference_full_frame": nd == 0, "pass1_pixels_differing": nd}
+        if ssaa and os.path.exists(dump + ".frame.npy"):
+            ref2 = np.load(dump + ".frame.npy")
+            mask = torch.zeros((height, width), dtype=torch.uint8, device="cuda")
+            for _ in range(3):      # (whichever way rtx_render_frame settles on: the frames are identical -- and compared)
+                gpu_scene.render_frame(fb, mask)
+                if gpu_scene.frame_status() != 0:
+                    raise RuntimeError("frame kernel gave up")
+                got = fb.cpu().numpy()
+                nd2 = int((got.view(np.uint32) != ref2.view(np.uint32)).any(-1)[1:, 1:].sum())
+                res["parity"]["frame_equals_reference_full_frame"] = bool(res["parity"].get("frame_equals_reference_full_frame", True) and nd2 == 0)
+                res["parity"]["frame_pixels_differing"] = max(nd2, res["parity"].get("frame_pixels_differing", 0))
+            res["parity"]["ssaa_pixels"] = int(mask.sum())
+    except Exception as e:          # noqa: BLE001 -- reported in the line, never hidden
+        res["parity"] = {"error": repr(e)}
+    finally:
+        for suffix in (".pass1.npy", ".frame.npy"):
+            try:
+                os.remove(dump + suffix)
+            except OSError:
+                pass
+    return res
 
 
 def cpu_baseline(scene_path, width, height, gpu_scene, target_s=15.0):
@@ -334,8 +374,13 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0])
+    frame_status = 0
     if ssaa:
-        scene.frame_status()      # raises if the frame kernel of any rtx_render_frame gave up: no number from a broken frame
+        # 0, or error | 0x100 when the single launch of some timed frame gave up (the last one was rendered again in three launches, earlier
+        # ones stayed incomplete: rtx_frame_status raises for those): either way the timed frames were not all whole frames -- no number
+        frame_status = scene.frame_status()
+        if frame_status != 0:
+            raise SystemExit("bench.py: rtx_frame_status = 0x%x -- a timed frame's single launch gave up; the timing is void" % frame_status)
 
     verified = None
     if args.verify and world > 1:
@@ -443,6 +488,11 @@ def main():
         out["config"]["gathered_image_equals_single_gpu_image"] = verified
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.scene, W, H, scene)
+        par = (out["cpu_baseline"] or {}).get("parity")
+        if par:      # the reference's own framebuffers of this very frame against the product path's (reference_baseline)
+            for k in ("pass1_equals_reference_full_frame", "frame_equals_reference_full_frame"):
+                if k in par:
+                    out["config"][k] = par[k]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -157,7 +157,10 @@ struct rtx_scene {
 		bool fusedGaveUp = false;         // the single launch once ended with an error for this view: three launches from then on
 	};
 	// the last frame rendered in one launch (rtx_frame_status renders it again in three if the launch gave up)
-	struct LastFused { bool valid = false; uint32_t rowBegin = 0, rowEnd = 0; float* fb = nullptr; uint8_t* mask = nullptr; void* stream = nullptr; size_t queue = ~(size_t)0; uint32_t generation = 0; };
+	// (only while nothing it depends on has changed: the view and the row ownership it was rendered with are part of it, and
+	// rtx_scene_set_view / rtx_set_row_ownership / a later frame in three launches drop it -- ADVICE r3)
+	struct LastFused { bool valid = false; uint32_t rowBegin = 0, rowEnd = 0; float* fb = nullptr; uint8_t* mask = nullptr; void* stream = nullptr; size_t queue = ~(size_t)0; uint32_t generation = 0;
+	                   uint64_t viewSerial = 0; uint32_t bandH = 0, nParts = 0, part = 0, halo = 0; };
 	LastFused lastFused;
 	uint32_t framesRecovered = 0;
 	// first-frame cost estimate (estimateCosts): the leaf arrays of the meshes, the cell grid, whether tileCost holds usable
@@ -844,6 +847,7 @@ int rtx_scene_set_view(rtx_scene* s, const rtx_view* v)
 	int rc = setView(s, v);
 	if (rc) return rc;
 	s->viewSerial++;
+	s->lastFused.valid = false;
 	if ((rc = ensureWork(s))) return rc;
 	return prepareView(s);
 }
@@ -1254,9 +1258,10 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	if (mode == 1) {
 		rc = renderFrameFused(s, rowBegin, rowEnd, fb_dev, mask_dev, stream, warm);
 		// what rtx_frame_status needs to render the frame again should the single launch have given up
-		s->lastFused = { true, rowBegin, rowEnd, fb_dev, mask_dev, stream, tq ? (size_t)(tq - s->tileQueues.data()) : ~(size_t)0, tq ? tq->generation : 0u };
+		s->lastFused = { true, rowBegin, rowEnd, fb_dev, mask_dev, stream, tq ? (size_t)(tq - s->tileQueues.data()) : ~(size_t)0, tq ? tq->generation : 0u,
+		                 s->viewSerial, s->params.bandH, s->params.nParts, s->params.part, s->params.halo };
 	}
-	else rc = renderFrameSplit(s, rowBegin, rowEnd, fb_dev, mask_dev, stream);
+	else { s->lastFused.valid = false; rc = renderFrameSplit(s, rowBegin, rowEnd, fb_dev, mask_dev, stream); }
 	if (rc) { if (s->evUsed[3] & 1) s->evUsed[3]--; return rc; }      // (the open event pair is dropped with the frame)
 	if ((rc = stamp(s, 3, st))) return rc;
 	if (pr) {
@@ -1327,6 +1332,7 @@ int rtx_frame_status(rtx_scene* s, uint32_t* status)
 	HIPCHK(hipMemcpy(&err, (const uint32_t*)s->frameCtl + FC_ERROR, sizeof(err), hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(&earlier, s->work + 24, sizeof(earlier), hipMemcpyDeviceToHost));
 	if (earlier) HIPCHK(hipMemset(s->work + 24, 0, sizeof(uint32_t)));
+	const bool lastFrameFailed = err != 0;
 	if (!err) err = earlier;
 	*status = err;
 	if (!err) return RTX_OK;
@@ -1337,7 +1343,11 @@ int rtx_frame_status(rtx_scene* s, uint32_t* status)
 	const rtx_scene::LastFused lf = s->lastFused;
 	s->lastFused.valid = false;
 	if (lf.queue < s->tileQueues.size() && s->tileQueues[lf.queue].generation == lf.generation) s->tileQueues[lf.queue].fusedGaveUp = true;
-	if (!lf.valid) return fail(RTX_ERR_DEVICE, "rtx_render_frame: the frame kernel gave up and the frame is not known any more");
+	// Only the LAST frame can be rendered again, and only into what it was rendered with: an error left by an earlier frame, or a
+	// view / row ownership that changed since, means a frame the caller may already have consumed is incomplete.
+	const Params& pp = s->params;
+	if (!lf.valid || !lastFrameFailed || lf.viewSerial != s->viewSerial || lf.bandH != pp.bandH || lf.nParts != pp.nParts || lf.part != pp.part || lf.halo != pp.halo)
+		return fail(RTX_ERR_DEVICE, "rtx_render_frame: the frame kernel gave up on a frame that cannot be rendered again (an earlier frame, or the view / row ownership changed since)");
 	int rc = renderFrameSplit(s, lf.rowBegin, lf.rowEnd, lf.fb, lf.mask, lf.stream);
 	if (rc) return rc;
 	HIPCHK(hipStreamSynchronize((hipStream_t)lf.stream));
@@ -1623,6 +1633,7 @@ int rtx_set_row_ownership(rtx_scene* s, uint32_t band_height, uint32_t n_parts, 
 	if (!s) return fail(RTX_ERR_ARG, "scene is NULL");
 	if (band_height != 0 && (n_parts == 0 || part >= n_parts)) return fail(RTX_ERR_ARG, "bad ownership");
 	s->params.bandH = band_height; s->params.nParts = n_parts ? n_parts : 1; s->params.part = part; s->params.halo = halo ? 1u : 0u;
+	s->lastFused.valid = false;      // (rtx_frame_status renders a failed frame again only under the ownership it was rendered with)
 	return RTX_OK;
 }
 

@@ -3,7 +3,7 @@
 # -> rendering_amd/_variants/librtx_<name>.so (benchmarked by tools/bench_variants.sh)
 cd "$(dirname "$0")/.."
 mkdir -p rendering_amd/_variants build/var
-rm -f rendering_amd/_variants/librtx_*.so
+[ -n "$KEEP" ] || rm -f rendering_amd/_variants/librtx_*.so
 for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Rpass-analysis=kernel-resource-usage $defs \
