@@ -173,7 +173,7 @@ struct rtx_scene {
 	// source copies of the prune records (rtxd::PruneRec, rtx_source.hip): per mesh the copies' base, the reference arrays and the
 	// slots' reference ranges; the point lights that have a copy; what the copies were last built for
 	struct SrcMesh { PruneBlock* base = nullptr; uint32_t nWide = 0, nRefs = 0; const RefA* refA = nullptr; const RefB* refB = nullptr; const RefC* refC = nullptr;
-	                 const uint32_t* slotRange = nullptr; float* refP = nullptr; float* blockP = nullptr; float vmax = 0; };
+	                 const uint32_t* slotRange = nullptr; float* refP = nullptr; float* blockP = nullptr; float vmax = 0; uint32_t meshIndex = 0; float rootPgen = 0; };
 	std::vector<SrcMesh> srcMeshes;
 	std::vector<std::array<float, 3>> srcLightPos;      // [l]: position of light l (point lights only count below nSrcLights)
 	std::vector<uint8_t> srcLightIsPoint;
@@ -332,6 +332,9 @@ int buildSources(rtx_scene* s)
 			hipLaunchKernelGGL(rtxsrc::rtxSourceRefKernel, dim3((sm.nRefs + 255) / 256), dim3(256), 0, nullptr, sm.refA, sm.refB, sm.refC, sm.nRefs,
 			                   (double)S[0], (double)S[1], (double)S[2], sigma, cam ? 1 : 0, sm.refP, sm.blockP);
 			hipLaunchKernelGGL(rtxsrc::rtxSourceSlotKernel, dim3(sm.nWide), dim3(256), 0, nullptr, sm.slotRange, sm.nWide, (const float*)sm.refP, (const float*)sm.blockP, dst);
+			if (copy < 8 && std::isfinite(sm.rootPgen))      // the whole mesh's P for this source (the per-ray test before the walk: traceWave)
+				hipLaunchKernelGGL(rtxsrc::rtxSourceRootKernel, dim3(1), dim3(256), 0, nullptr, (const float*)sm.blockP, (sm.nRefs + 63) / 64, sm.rootPgen,
+				                   (float*)((char*)const_cast<Mesh*>(s->params.meshes + sm.meshIndex) + offsetof(Mesh, rootPS)) + copy);
 		};
 		if (!camSame) build(1, v.camPos, 0.0, true);
 		if (!lightsSame)
@@ -687,12 +690,13 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		}
 		dm.vmax = vmaxMesh;
 		dm.rootRec = rootRec;
+		for (int k = 0; k < 8; k++) dm.rootPS[k] = rootRec.P;
 		if (!(vmaxMesh < 0x1p40f)) { dm.prune = nullptr; dm.rootRec.h[0] = dm.rootRec.h[1] = dm.rootRec.h[2] = INFINITY; }      // (huge or non-finite coordinates: nothing is pruned)
 		if ((rc = upload(s->owned, refA.data(), refA.size(), &dm.refA))) return bail(rc);
 		if ((rc = upload(s->owned, refB.data(), refB.size(), &dm.refB))) return bail(rc);
 		if ((rc = upload(s->owned, refC.data(), refC.size(), &dm.refC))) return bail(rc);
 		if (sm.base && vmaxMesh < 0x1p40f && m.n_refs) {
-			sm.nRefs = m.n_refs; sm.refA = dm.refA; sm.refB = dm.refB; sm.refC = dm.refC; sm.vmax = vmaxMesh;
+			sm.nRefs = m.n_refs; sm.refA = dm.refA; sm.refB = dm.refB; sm.refC = dm.refC; sm.vmax = vmaxMesh; sm.meshIndex = mi; sm.rootPgen = rootRec.P;
 			if ((rc = upload(s->owned, flat.slotRange.data(), flat.slotRange.size(), &sm.slotRange))) return bail(rc);
 			if (hipMalloc((void**)&sm.refP, ((size_t)m.n_refs + m.n_refs / 64 + 2) * sizeof(float)) != hipSuccess) return bail(fail(RTX_ERR_DEVICE, "hipMalloc (source scratch)"));
 			s->owned.push_back(sm.refP);

@@ -95,6 +95,7 @@ struct Mesh {
 	const PruneBlock* prune;   // one per wide node, or null
 	float vmax, padv;          // largest |vertex coordinate| of the mesh
 	PruneRec rootRec;          // the PruneRec of the whole mesh (h = +inf: none): a ray whose segment misses it takes no part in the walk
+	float rootPS[8];           // its P per source (rtxd::PruneRec: [0] = Pgen, [1] the camera's, [2 + l] point light l's; buildSources)
 	// bundle splitting (rtx_kernels.hip, traceWave): a wave's rays are walked as ONE bundle unless the bundle is wider than
 	// fatRadius at this mesh (a few mean triangle edges); centre / radius = bounding sphere of the root box
 	float fatRadius, centre[3], radius;

@@ -1220,12 +1220,20 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 				// A ray whose SEGMENT [0, limit] stays clear of the mesh's true box (inflated by how far the reference's accepted hit
 				// can lie from its triangle: pruneAlive, here per ray with the ray's own dmax / ainf) cannot be given a hit by this
 				// mesh: it takes no part in the walk.  Most shadow rays that start on the floor in front of the mesh end here --
-				// their LINE meets the root box, which is all the reference's test asks (objects.cpp:534-570).
+				// their LINE meets the root box, which is all the reference's test asks (objects.cpp:534-570) -- and with the P of the
+				// rays' source (rtxd::PruneRec; round 3 had only Pgen: a margin of 0.4 at the headline, nearly every ray passed) the
+				// inflation is 1e-3: a tile of the floor costs no bundle and no walk.
 				if (!STATS && cull) {
 					const u32x8 rr = sload8(&M->rootRec);      // c.xyz, P, h.xyz, -
+					const u32x8 rp = sload8(M->rootPS);
 					const float ainf = fmaxf(fmaxf(fabsf(o.x - F(rr[0])) + F(rr[4]), fabsf(o.y - F(rr[1])) + F(rr[5])), fabsf(o.z - F(rr[2])) + F(rr[6]));
 					const float dmx = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), omx = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-					const float rho = __builtin_fmaf(kPruneC * dmx * ainf, F(rr[3]), 0x1p-17f * (ainf + omx)) * (1.0f + 0x1p-20f) + 1e-30f;
+					// the ray's own source (0: none), valid under sourceP's side conditions: |dir|_2 in [0.99, 1.001], origin within kSrcAinfMax of the box
+					const float l2 = len2(d);
+					const bool srcOk = RTX_SRC && src != 0 && src < 8u && l2 >= 0.9802f && l2 <= 1.002f && ainf <= kSrcAinfMax;
+					float Pr = F(rr[3]);
+					if (srcOk) Pr = src == 1u ? F(rp[1]) : (src == 2u ? F(rp[2]) : (src == 3u ? F(rp[3]) : (src == 4u ? F(rp[4]) : (src == 5u ? F(rp[5]) : (src == 6u ? F(rp[6]) : F(rp[7]))))));
+					const float rho = __builtin_fmaf(kPruneC * dmx * ainf, Pr, 0x1p-17f * (ainf + omx)) * (1.0f + 0x1p-20f) + 1e-30f;
 					const float hx = F(rr[4]) + rho, hy = F(rr[5]) + rho, hz = F(rr[6]) + rho;
 					const float ax = ((F(rr[0]) - hx) - o.x) * ix, bx = ((F(rr[0]) + hx) - o.x) * ix;
 					const float ay = ((F(rr[1]) - hy) - o.y) * iy, by = ((F(rr[1]) + hy) - o.y) * iy;

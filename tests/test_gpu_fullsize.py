@@ -100,6 +100,18 @@ def test_cfg2_1080p_oracle_bands(ra, oracle, torch_cuda):
     assert n > 1000
 
 
+def test_north_star_4096_ssaa_oracle_bands(ra, oracle, torch_cuda):
+    """The headline frame WITH its Sobel-adaptive 4-ray pass (what bench.py times): pass 1, the Sobel mask of the
+    whole frame and the re-rendered pixels against the oracle on row bands through the upper pole, the silhouette, the middle of
+    the mesh, the shadow on the floor and the last rows."""
+    from rendering_amd import assets
+    assets.ensure(["bumpy_250k.obj"])
+    g = ra.Scene("scenes/cfg2_smooth_250k.scene", 4096, 4096)
+    o = oracle.OracleScene("scenes/cfg2_smooth_250k.scene", 4096, 4096)
+    n = check_bands_against_oracle(torch_cuda, g, o, [(0, 4), (788, 800), (1100, 1108), (2044, 2052), (3100, 3112), (3292, 3304), (3600, 3604), (4088, 4096)])
+    assert n > 50000
+
+
 def test_cfg5_8192_ssaa_sharded_8_ways(ra, oracle, torch_cuda):
     """BASELINE cfg5: the 250k-triangle scene at 8192x8192 with the Sobel-adaptive 4-ray pass, rows dealt to 8 parts
     (rtx_set_row_ownership, 64-row bands, halo recomputed): the 8 parts assemble to exactly the unsharded frame, and the

@@ -56,13 +56,13 @@ def make_scene(seed, w, h):
 
 
 def fuzz_seeds():
-    """16 seeds by default; RTX_FUZZ_SEEDS=first:last (exclusive) runs any other range (tools/fuzz_many.py runs long ranges
+    """64 seeds by default (16 until round 3: they cost seconds); RTX_FUZZ_SEEDS=first:last (exclusive) runs any other range (tools/fuzz_many.py runs long ranges
     with larger scenes and keeps the evidence: profiles/r03_fuzz.txt)."""
     e = os.environ.get("RTX_FUZZ_SEEDS")
     if e:
         a, b = e.split(":")
         return list(range(int(a), int(b)))
-    return list(range(16))
+    return list(range(64))
 
 
 @pytest.mark.parametrize("seed", fuzz_seeds())

@@ -50,3 +50,14 @@ def test_source_p_never_exceeds_pgen_and_needs_height():
     assert big >= np.float32(pgen[0] * 2500 * 0.999)
     z = RA.source_p_probe(v0[:1], e1[:1] * 0, e2[:1], [0.3, 4.0, -2.0], 0.0, True)[0]
     assert z == z and z >= 0
+
+
+def test_prune_bounds_on_the_headline_frame_real_data():
+    """over rows of the headline frame the hits the reference accepts (CPU oracle: closest hits of primary rays and of
+    the shadow rays towards the three lights) stay within the inflation the prune records allow -- with Pgen and with the sources' P_S."""
+    from tools.research.rho_real_data import main
+    import io
+    res = main(stride=1024, S=4096, out=io.StringIO())
+    assert len(res) == 4
+    for ratio_src, ratio_gen, n in res:
+        assert n > 500 and ratio_src < 0.25 and ratio_gen < 0.25

@@ -18,3 +18,12 @@ idx = np.argsort(c.ravel())[::-1][:n]
 print("slowest:", " ".join("(%d,%d)=%.3f" % (i % c.shape[1], i // c.shape[1], c.ravel()[i]) for i in idx))
 h, e = np.histogram(np.log10(np.maximum(c.ravel(), 1e-5)), bins=12, range=(-3, 1))
 print("log10(ms) histogram -3..1:", h.tolist())
+# share of the wave-time by region (headline scene: the mesh's disc has a radius of ~1255 px around the centre at 4096^2; the floor lies below the horizon y = H / 2)
+ty, tx = np.mgrid[0:c.shape[0], 0:c.shape[1]]
+r = np.hypot((tx + 0.5) * 8 - W / 2, (ty + 0.5) * 8 - H / 2) * 4096.0 / W
+mesh = r < 1420; sky = (~mesh) & ((ty + 1) * 8 <= H / 2); floor = (~mesh) & ~sky
+for name, m in (("mesh disc", mesh), ("floor", floor), ("sky", sky)):
+    print("%-9s tiles %7d (%.1f%%), wave-time %8.1f ms (%.1f%%), mean %.4f ms" % (name, m.sum(), 100.0 * m.mean(), c[m].sum(), 100.0 * c[m].sum() / c.sum(), c[m].mean()))
+fl = c[floor]
+print("floor tiles: median %.4f, 90%% %.4f, 99%% %.4f, max %.3f ms; by tile row (mean ms):" % (np.median(fl), np.quantile(fl, 0.9), np.quantile(fl, 0.99), fl.max()),
+      " ".join("%d:%.3f" % (y, c[y][floor[y]].mean()) for y in range(c.shape[0] // 2, c.shape[0], 16) if floor[y].any()))
