@@ -1239,6 +1239,10 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	const bool warm = tq && tq->costValid;
 	if (forced >= 0) mode = forced;
 	else if (!tq || tq->fusedGaveUp) mode = 0;
+	// By rule, not by measurement, where the single launch has never won: frames of more than 65 536 listed tiles
+	// (8 192 without meshes) are throughput-bound over cheap tiles -- 4096^2: 4.5 ms in one launch against 4.0 in three, 8192^2 18.1
+	// against 15.2 -- and probing there cost the headline two slow frames at the start and one in every 64.
+	else if (tq->listed > (s->analytic ? 8192u : 65536u)) mode = 0;
 	// no measured costs yet: by size -- the single launch where the frame is bounded by its slowest tiles; without meshes (cheap,
 	// even tiles: cfg3 at 1080p 2.0 ms in one launch, 1.1 in three) only for small frames
 	else if (!warm) mode = tq->listed <= (s->analytic ? 8192u : 65536u) ? 1 : 0;
@@ -1246,11 +1250,14 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	else if (tq->frameSamples[0] < 2 || tq->frameSamples[1] < 2) mode = (int)(tq->framesSeen & 1u);
 	else {
 		mode = tq->frameMs[1] <= tq->frameMs[0] ? 1 : 0;
-		if ((tq->framesSeen & 63u) == 63u) mode ^= 1;
+		// (the other way is tried again every 64 frames -- unless it lost by more than a fifth)
+		const float lo = std::min(tq->frameMs[0], tq->frameMs[1]), hi = std::max(tq->frameMs[0], tq->frameMs[1]);
+		if ((tq->framesSeen & 63u) == 63u && hi <= 1.2f * lo) mode ^= 1;
 	}
 	// The frame is bracketed by its own pair of events only while the choice is being made or re-examined (the frame that
 	// tries the other way every 64 frames and the one before it): an event costs the queue ~5 us.
-	const bool probing = forced < 0 && tq && (!warm || tq->frameSamples[0] < 2 || tq->frameSamples[1] < 2 || (tq->framesSeen & 63u) >= 62u);
+	const bool byRule = tq && tq->listed > (s->analytic ? 8192u : 65536u);
+	const bool probing = forced < 0 && tq && !byRule && (!warm || tq->frameSamples[0] < 2 || tq->frameSamples[1] < 2 || (tq->framesSeen & 63u) >= 62u);
 	rtx_scene::FrameProbe* pr = nullptr;
 	if (probing) {
 		pr = &s->probes[s->probeNext++ & 7u];

@@ -38,9 +38,10 @@ def same(torch, a, b):
 
 @pytest.mark.parametrize("size", [4096, 8192])
 def test_render_frame_fused_and_auto_at_full_size(ra, torch_cuda, size):
-    """The 250k-triangle scene at 4096^2 (headline) and 8192^2 (cfg5) through rtx_render_frame: the single launch (cold, then
-    warm frames that split slow tiles) and the measured choice over 70 frames -- so that the probing frames and the
-    every-64th re-probe run the OTHER way -- give the three stages' framebuffer and mask bit for bit."""
+    """The 250k-triangle scene at 4096^2 (headline) and 8192^2 (cfg5) through rtx_render_frame: the single launch, forced (cold, then
+    warm frames that split slow tiles), gives the three stages' framebuffer and mask bit for bit; left to choose, frames of this size
+    take three launches BY RULE (more than 65 536 tiles: the single launch has never won there and is no longer probed -- round 4),
+    over 70 frames, with the same pixels.  (The measured choice itself: tests/test_gpu_frame.py at the sizes where it applies.)"""
     from rendering_amd import assets
     torch = torch_cuda
     assets.ensure(["bumpy_250k.obj"])
@@ -57,19 +58,17 @@ def test_render_frame_fused_and_auto_at_full_size(ra, torch_cuda, size):
     g.set_frame_mode(AUTO)
     modes = []
     for it in range(70):
-        check = it < 8 or it >= 60
+        check = it < 4 or it >= 62
         if check:
             fb.zero_(); mask.fill_(7)
         g.render_frame(fb, mask)
         if check:
             assert g.frame_status() == 0
-            assert same(torch, ref_fb, fb), "measured choice, frame %d (mode %d)" % (it, g.frame_mode()[0])
-            assert torch.equal(ref_mask, mask), "measured choice, frame %d: mask" % it
+            assert same(torch, ref_fb, fb), "left to choose, frame %d (mode %d)" % (it, g.frame_mode()[0])
+            assert torch.equal(ref_mask, mask), "left to choose, frame %d: mask" % it
         modes.append(g.frame_mode()[0])
     assert g.frame_status() == 0
-    assert set(modes) == {SPLIT, FUSED}, "both ways must have run while the choice was measured"
-    m, split_ms, fused_ms = g.frame_mode()
-    assert split_ms > 0 and fused_ms > 0
+    assert set(modes) == {SPLIT}, "frames of more than 65 536 tiles take three launches by rule"
 
 
 @pytest.mark.parametrize("size,parts", [(4096, 2), (4096, 4), (8192, 2), (8192, 4)])
