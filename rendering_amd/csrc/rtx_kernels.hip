@@ -30,6 +30,9 @@
 
 using namespace rtxd;
 
+#ifndef RTX_FB_STORE
+#define RTX_FB_STORE 1     // pass 1: 1 = plain framebuffer stores; 0 / 2: the write-traffic experiments of profiles/r04_write_traffic.txt
+#endif
 #ifndef RTX_WAVES_SSAA
 #define RTX_WAVES_SSAA 4   // the SSAA launch lasts as long as its slowest wave: fewer, barely spilled waves (128 VGPRs)
 #endif
@@ -1837,10 +1840,19 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 				if (STATS) { atomicMax(P.counters + 3, dt); atomicAdd(P.counters + 4, dt); }
 			}
 			if (strip && lane < 8 && tx + lane < P.tilesX) P.tileCost[ty * P.tilesXFull + tx + lane] = (uint32_t)((dt > 0xffffffffull ? 0xffffffffull : dt) / 8);
+#if RTX_FB_STORE == 1
 			if (valid) {
 				float* px = P.fb + ((size_t)y * W + x) * 3;
 				px[0] = c.x; px[1] = c.y; px[2] = c.z;
 			}
+#elif RTX_FB_STORE == 2      // (experiment: non-temporal stores)
+			if (valid) {
+				float* px = P.fb + ((size_t)y * W + x) * 3;
+				__builtin_nontemporal_store(c.x, px); __builtin_nontemporal_store(c.y, px + 1); __builtin_nontemporal_store(c.z, px + 2);
+			}
+#else                        // (experiment: no framebuffer store at all -- what is left of WRITE_SIZE is scratch: profiles/r04_write_traffic.txt)
+			if (valid && c.x == 123456.0f) P.fb[0] = c.y + c.z;
+#endif
 		}
 	}
 #if RTX_DBG
