@@ -166,8 +166,9 @@ def cpu_baseline_port(scene_path, width, height, gpu_scene, target_s=15.0):
 # not observable with the counters at hand), falling back to 4 cycles per instruction when no stamped ISA summary exists.
 SIMDS, CLOCK_GHZ = 1024, 2.4
 VALU_PEAK_GINSTR = SIMDS * CLOCK_GHZ / 4
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pass1_pmc.json")
-ISA_JSON = os.path.join(ROOT, "profiles", "r03_pass1_isa.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r04_pass1_pmc.json")
+ISA_JSON = os.path.join(ROOT, "profiles", "r04_pass1_isa.json")
+ACCOUNT_JSON = os.path.join(ROOT, "profiles", "r04_issue_account.json")
 
 
 def stamped(path):
@@ -184,7 +185,7 @@ def stamped(path):
 
 def pmc_roofline(avg_ms, scene_bytes, fb_bytes, kernel="rtxPass1Kernel<false, true, true>", workload="headline"):
     """Hardware-counter side of the roofline of the dominant kernel (rtxPass1Kernel where the frame is three launches,
-    rtxFrameKernel where it is one): VALU wave-instructions and HBM-side bytes per launch from profiles/r03_pass1_pmc.json
+    rtxFrameKernel where it is one): VALU wave-instructions and HBM-side bytes per launch from profiles/r04_pass1_pmc.json
     (tools/pmc_pass1.sh: separate rocprofv3 --pmc passes of this command), over the launch duration measured live in THIS run."""
     d, why = stamped(PMC_JSON)
     if d is None:
@@ -211,6 +212,18 @@ def pmc_roofline(avg_ms, scene_bytes, fb_bytes, kernel="rtxPass1Kernel<false, tr
                    "traffic_over_compulsory": round((fetch + write) / max(scene_bytes + fb_bytes, 1), 2),
                    "l2_hit_rate": round(k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]), 3) if "TCC_HIT_sum" in k else None},
            "sq": {c: k[c] for c in k if c.startswith("SQ_")}, "source_hash": d["source_hash"]}
+    # where the wave-cycles go (SQ_WAVE_CYCLES = parked on s_waitcnt + ready but not issued + issuing: MI355X_MICROARCH.md, rocprofv3 PMC slots) and
+    # how full the VALU instructions are (SQ_THREAD_CYCLES_VALU / 64 lanes x the quad-cycles VALU instructions were active)
+    if all(c in k for c in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")):
+        wc = k["SQ_WAVE_CYCLES"]
+        out["wave_cycles"] = {"waiting_for_memory": round(k["SQ_WAIT_ANY"] / wc, 3), "ready_not_issued": round(k["SQ_WAIT_INST_ANY"] / wc, 3),
+                              "issuing": round(k["SQ_ACTIVE_INST_ANY"] / wc, 3), "issuing_valu": round(k["SQ_ACTIVE_INST_VALU"] / wc, 3)}
+    if "SQ_THREAD_CYCLES_VALU" in k and k.get("SQ_ACTIVE_INST_VALU"):
+        out["valu_lane_utilisation"] = round(k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"]), 3)
+    acc, _ = stamped(ACCOUNT_JSON)
+    if acc is not None and workload in acc.get("workloads", {}):
+        out["useful_valu_frac"] = acc["workloads"][workload].get("useful_valu_frac")
+        out["useful_valu_basis"] = acc.get("useful_valu_basis")
     isa, _ = stamped(ISA_JSON)
     if isa is not None:
         out["static_valu_mix"] = isa["valu_fraction_by_class"]
@@ -280,7 +293,23 @@ def main():
     if world > 1:
         dist.barrier()
     W, H = args.width, args.height
+    # scene load = .scene / OBJ / BMP parsing + acceleration-structure build + flatten + upload + view preparation: outside the metric (the
+    # reference's "Render scene" timer starts after its loader, scene.cpp:472), reported in config because the reference renders ONE
+    # frame per process (main.cpp:15) and the load dwarfs a 4-ms frame
+    torch.cuda.synchronize()
+    t_load = time.perf_counter()
     scene = RA.Scene(args.scene, W, H, device=local)
+    scene.gpu()
+    torch.cuda.synchronize()
+    scene_create_ms = (time.perf_counter() - t_load) * 1e3
+    bvh_ms = []
+    for oi in range(16):
+        try:
+            bi = scene.bvh_build_info(oi)
+        except Exception:
+            bi = None
+        if bi is not None and bi[1] >= 0:
+            bvh_ms.append({"object": oi, "on_device": bi[0], "ms": round(bi[1], 3)})
     fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     mask = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
     ssaa = not args.no_ssaa
@@ -351,6 +380,7 @@ def main():
     else:
         c2 = np.zeros(3, np.int64)
     scene.counters_enable(False)
+    tot_p1, tot_p2 = int(c1[0]), int(c2[0])      # rays of this rank's pass 1 / SSAA pass
     tot = torch.tensor([int(x) for x in (c1 + c2)] + [moot], dtype=torch.int64, device=rdev)
     if world > 1:
         dist.all_reduce(tot)
@@ -463,6 +493,7 @@ def main():
     out = {
         "metric": "Mrays/s + ms/frame at 4096^2, 250k-tri BVH scene",
         "value": round(rays_per_frame * args.steps / dt / 1e6, 3),
+        "value_walked": round(walked * args.steps / dt / 1e6, 3),      # without the moot shadow rays, which are counted (the reference casts them) but never walked
         "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -477,6 +508,8 @@ def main():
                    "frame": ("one launch (rtxFrameKernel)" if one_launch else "three launches (pass 1, Sobel, SSAA)") if ssaa else "pass 1 only",
                    "measured_three_launches_ms": None if split_ms < 0 else round(split_ms, 3), "measured_one_launch_ms": None if fused_ms < 0 else round(fused_ms, 3),
                    "pass1_ms": round(ms1 / n1, 3) if n1 else None, "ssaa_ms": round(ms2 / n2, 3) if n2 else None,
+                   "pass1_grays_s": round(float(tot_p1) / (ms1 / n1) / 1e6, 2) if n1 else None, "ssaa_grays_s": round(float(tot_p2) / (ms2 / n2) / 1e6, 2) if n2 and ssaa else None,
+                   "scene_create_ms": round(scene_create_ms, 1), "bvh_build": bvh_ms,
                    "frame_kernel_ms": round(ms4 / n4, 3) if n4 else None,
                    "cold_frame_ms": None if cold_ms is None else round(cold_ms, 3),
                    "cold_frame_gpu_busy_before_ms": None if cold_busy_ms is None else round(cold_busy_ms, 3),

@@ -363,6 +363,13 @@ class Scene:
         d.update(built_on_device=bool(on.value), build_ms=ms.value)
         return d
 
+    def bvh_build_info(self, obj_idx):
+        """(built on the device?, build ms) of object obj_idx's acceleration structure; None for objects without one."""
+        on, ms = C.c_int(0), C.c_float(-1)
+        if self.host.rah_bvh_build_info(self.h, obj_idx, C.byref(on), C.byref(ms)) != 0:
+            return None
+        return bool(on.value), ms.value
+
     # ---- GPU ------------------------------------------------------------------------------------
     def gpu(self):
         """rtx_scene* of the uploaded scene (flatten + upload on first use; re-applies the view after resize)."""

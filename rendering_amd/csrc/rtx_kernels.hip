@@ -923,6 +923,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				if ((int32_t)rec[base + 6] != 0 && ((aliveM >> k) & 1u)) {                                                           \
 					const bool fail = boxFailsRegular(F(rec[base]), F(rec[base + 1]), F(rec[base + 2]), F(rec[base + 3]), F(rec[base + 4]), F(rec[base + 5]), o, ix, iy, iz); \
 					const uint64_t mk_ = ballot(!fail) & inM;                                                                       \
+					if (RTX_DBG) cnt.wS3++;                                                                                         \
 					if (mk_ != 0) {                                                                                                 \
 						if (lane == 0) { WideItem ni; ni.link = (int32_t)rec[base + 6]; ni.first = rec[base + 7]; ni.maskLo = (uint32_t)mk_; ni.maskHi = (uint32_t)(mk_ >> 32); stack[sp] = ni; } \
 						sp = uni(sp + 1);                                                                                           \
@@ -933,6 +934,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				if ((int32_t)wa[6] != 0 && (aliveM & 1u)) {
 					const bool fail = boxFailsRegular(F(wa[0]), F(wa[1]), F(wa[2]), F(wa[3]), F(wa[4]), F(wa[5]), o, ix, iy, iz);
 					const uint64_t mk_ = ballot(!fail) & inM;
+					if (RTX_DBG) cnt.wS3++;
 					if (mk_ != 0) {
 						if ((int32_t)wa[6] < 0 && batch < RTX_LEAF_BATCH) noteLeaf((int32_t)wa[6], wa[7], mk_);
 						else {

@@ -1,9 +1,9 @@
 """A DYNAMIC issue account of the pass-1 kernel: static VALU instruction counts of the walk's inner loops
 (from the compiler's ISA, build/*.s) x how often each loop body runs in one launch of the headline frame (RTX_DBG wave-level
-counters, gpurun_out/r03/r03_dbg_counts.txt), against the SQ_INSTS_VALU the hardware counted for the same launch
-(profiles/r03_pass1_pmc.json).  The static count of a loop body is an upper bound of what one trip issues (not every branch
+counters, gpurun_out/r04/r04_dbg_counts.txt), against the SQ_INSTS_VALU the hardware counted for the same launch
+(profiles/r04_pass1_pmc.json).  The static count of a loop body is an upper bound of what one trip issues (not every branch
 of the body is taken), so the walk's share is an upper bound and "everything else" a lower bound.
-python tools/issue_account.py > profiles/r03_issue_account.txt"""
+python tools/issue_account.py > profiles/r04_issue_account.txt   (also writes profiles/r04_issue_account.json: useful_valu_frac for bench.py)"""
 import json, os, re, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -43,11 +43,11 @@ for ln in lines[start + 1:]:
 node = next(k for k in order if loops[k]["smem16"] >= 2 and loops[k]["vmem"] >= 2)
 after = order[order.index(node) + 1:]
 passes = [k for k in after if loops[k]["bperm"] >= 10][:4]
-dbg = open(os.path.join(ROOT, "gpurun_out", "r03", "r03_dbg_counts.txt")).read()
-sec = dbg.split("== noprune")[0]
+dbg = open(os.path.join(ROOT, "gpurun_out", "r04", "r04_dbg_counts.txt")).read()
+sec = dbg.split("== nosrc")[0]
 m = re.search(r"node visits (\d+), reached leaves (\d+), filter passes \(64 references\) (\d+), of which rejected whole by stage 1 (\d+), by stage 2 (\d+); survivors tested exactly (\d+)", sec)
 visits, leaves, npass, rej1, rej2, exact = [int(x) for x in m.groups()]
-pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pass1_pmc.json")))
+pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pass1_pmc.json")))
 kern = [v for n, v in pmc["workloads"]["headline"]["kernels"].items() if "Pass1Kernel<false, true, true>" in n][0]
 total = kern["SQ_INSTS_VALU"]
 pv = sum(loops[k]["valu"] for k in passes) / len(passes)
@@ -66,8 +66,18 @@ for name, k, v, n in rows:
     print("%-92s static %4d VALU x %9d trips = %.3e  (<= %4.1f %%)   [%s: readlane/writelane %d, v_mov %d, SALU %d, LDS %d, VMEM %d]" % (
         name, v, n, v * n, 100.0 * v * n / total, k, loops.get(k, {}).get("readlane", 0), loops.get(k, {}).get("mov", 0), loops.get(k, {}).get("salu", 0), loops.get(k, {}).get("lds", 0), loops.get(k, {}).get("vmem", 0)))
 print("sum of the three static upper bounds %.3e = %.0f %% of the measured count: the bodies are not executed in full (a pass that stage 1 rejects whole -- %d of %d -- skips stage 2; %d more end after stage 2)" % (acc, 100.0 * acc / total, rej1, npass, rej2))
-print("everything else (castRay state machine, parking in LDS, bundle, root tests, tile loop), measured apart: pass 1 of the same frame with the mesh moved behind the camera and "
-      "RTX_PRUNE_RAYS=1 (no ray enters the walk) issues 4.12e8 VALU instructions for 655 k trace rounds = 630 per round and takes 1.41 ms -- 292 G instructions/s: those rounds are bound by "
-      "their chains of dependent loads, not by issue (tools/overhead_probe.sh, round 3 log in DESIGN.md 3.2); at 630 per round the 764 k rounds of the real frame hold 4.8e8 = 16 %% of its instructions")
+salu = kern.get("SQ_INSTS_SALU", 0)
+print("scalar side of the same loops (SQ_INSTS_SALU %.3e per launch = %.2f per VALU instruction): node visit %d SALU, filter pass %d, exact test %d (static)" % (
+    salu, salu / total, loops[node]["salu"], loops[passes[0]]["salu"], loops[ex[0]]["salu"] if ex else 0))
+m2 = re.search(r"per-ray slot tests (\d+)", sec)
+# USEFUL arithmetic = what the reference's semantics need of this kernel: the per-ray box tests of the slots a walk really tests (21 VALU each: 6 sub,
+# 6 mul, 3 min, 3 max, max3, min3, compare) and the exact Moller-Trumbore tests of the survivors (the static body); everything else -- prune evaluation,
+# bundle filter, stack, state machine, parking -- is the machinery that decides what NOT to test
+slot_tests = int(m2.group(1)) if m2 else None
+useful = (21.0 * slot_tests if slot_tests else 0.0) + ev * exact
+print("useful arithmetic (per-ray slot box tests %s x 21 + exact tests %d x %d static): %.3e = %.1f %% of the issued VALU instructions" % (slot_tests, exact, ev, useful, 100.0 * useful / total))
+json.dump({"source_hash": pmc["source_hash"], "useful_valu_basis": "(per-ray slot box tests x 21 VALU + exact tests x the static body of the Moller-Trumbore loop) / SQ_INSTS_VALU; counts: RTX_DBG build of the same sources",
+           "workloads": {"headline": {"useful_valu_frac": round(useful / total, 4), "node_visits": visits, "reached_leaves": leaves, "filter_passes": npass, "exact_tests": exact, "slot_tests": slot_tests}}},
+          open(os.path.join(ROOT, "profiles", "r04_issue_account.json"), "w"), indent=1)
 print("spill traffic inside the loops above: v_readlane / v_writelane %d in the node loop, %d per pass body, %d per exact test (VERDICT r2: 122 SGPR spill slots in the loops -- the spills that remain sit in the round loop around the walk)" % (
     loops[node]["readlane"], loops[passes[0]]["readlane"], loops[ex[0]]["readlane"] if ex else 0))

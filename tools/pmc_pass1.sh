@@ -3,9 +3,10 @@
 # stamped with the source hash (tools/srchash.py) so that bench.py only quotes them for the kernels they were measured on.
 # Two workloads: the headline (three launches: rtxPass1Kernel / rtxSsaaKernel) and cfg2 at 1920x1080 (one launch:
 # rtxFrameKernel); the way the frame is rendered is fixed (RTX_FRAME_MODE) to what rtx_render_frame settles on without a
-# profiler attached.  Per workload four rocprofv3 --pmc passes (counters only, no trace domains) of
+# profiler attached.  Per workload five rocprofv3 --pmc passes (counters only, no trace domains) of
 #     python bench.py --steps 2 --warmup 1 --no-cpu-baseline [--config cfg2]
-# FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots); the SQ counters fill one pass.
+# FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots); the SQ counters fill two passes (round 4: the split of the wave-cycles --
+# SQ_WAIT_ANY = parked on s_waitcnt, SQ_WAIT_INST_ANY = ready but not issued, SQ_ACTIVE_INST_ANY = issuing -- and SQ_THREAD_CYCLES_VALU).
 # Usage: tools/pmc_pass1.sh <round tag, e.g. r02>
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -14,7 +15,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for wl in "headline:split" "cfg2:fused"; do
   cfg=${wl%%:*}; mode=${wl#*:}
-  for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "tcc:TCC_HIT_sum TCC_MISS_sum"; do
+  for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "sq2:SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_WR" "tcc:TCC_HIT_sum TCC_MISS_sum"; do
     name=${pass%%:*}; cnt=${pass#*:}
     RTX_FRAME_MODE=$mode rocprofv3 --pmc $cnt --output-format csv -d $OUT/$cfg/$name -o $name -- python $R/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$cfg.$name.log 2>&1
   done
