@@ -439,6 +439,14 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 		if (begin + count > m.n_refs) return (fail(RTX_ERR_ARG, "leaf range out of bounds"));
 		nd.link = ~m.leaf_count[i]; nd.first = (int32_t)begin;
 	}
+	// every inner node has both children inside the array and inside its own subtree [i + 1, skip): the bottom-up passes below index
+	// the right child of EVERY node, reachable from the root or not (rtx_mesh_flatten_probe feeds raw arrays in here)
+	for (uint32_t i = 0; i < m.n_nodes; i++) {
+		if (m.leaf_count[i] >= 0) continue;
+		if (i + 1 >= m.n_nodes) return fail(RTX_ERR_ARG, "inner node without children");
+		const uint32_t right = m.leaf_count[i + 1] >= 0 ? i + 2 : (uint32_t)m.node_skip[i + 1];
+		if (right <= i + 1 || right >= (uint32_t)m.node_skip[i] || right >= m.n_nodes) return fail(RTX_ERR_ARG, "inner node whose right child lies outside its subtree");
+	}
 	// the tree with every other level skipped (rtxd::WideNode), when every box lies inside its parent's
 	std::vector<WideNode> wide;
 	

@@ -635,41 +635,45 @@ void Scene::render()
 	const bool sharded = comm_ && nRanks_ > 1;
 	gpuCheck(rtx_set_row_ownership(g, sharded ? bandHeight((uint32_t)options.height, (uint32_t)nRanks_) : 0u, (uint32_t)nRanks_, (uint32_t)rank_, 1), "rtx_set_row_ownership");
 	hipCheck(hipMemset(d.fb, 0, options.width * options.height * sizeof(Vec3f)), "hipMemset");    // new Vec3f[H*W]() (scene.cpp:599)
+	// With other ranks waiting for this one's bands, a failure of ANY stage must not simply exit (the others would hang in rtx_gather):
+	// the verdicts of the stages are collected in rc, and the ranks agree on them once, immediately before the gather.
+	int rc = RTX_OK;
+	auto stage = [&](int r, const char* what) { if (sharded) { if (rc == RTX_OK && r != RTX_OK) { rc = r; std::cout << "rank " << rank_ << ": " << what << ": " << rtx_last_error() << '\n'; } } else gpuCheck(r, what); };
+	auto hipStage = [&](hipError_t e, const char* what) { if (sharded) { if (rc == RTX_OK && e != hipSuccess) { rc = RTX_ERR_DEVICE; std::cout << "rank " << rank_ << ": " << what << ": " << hipGetErrorString(e) << '\n'; } } else hipCheck(e, what); };
+	uint32_t status = 0;
 	if (options::enableSSAA && !statisticsOn()) {
 		// launchWorkers + launchSSAA as one call: the stages overlap on the device (rtx_render_frame)
 		Timer tp("Render scene + MSAA");
-		gpuCheck(rtx_counters_enable(g, 0), "rtx_counters_enable");
-		// With other ranks waiting for this one's bands, a failure here must not simply exit: every rank reports its verdict
-		// (rtx_comm_agree below) and they all leave together.
-		int rc = rtx_render_frame(g, 0, (uint32_t)options.height, d.fb, d.mask, nullptr);
+		stage(rtx_counters_enable(g, 0), "rtx_counters_enable");
+		if (rc == RTX_OK) stage(rtx_render_frame(g, 0, (uint32_t)options.height, d.fb, d.mask, nullptr), "rtx_render_frame");
 		// the host's synchronisation point: a single launch that gave up has been rendered again in three (include/rtx.h)
-		uint32_t status = 0;
-		if (rc == RTX_OK) rc = rtx_frame_status(g, &status);
-		if (sharded) {
-			int allOk = 0;
-			gpuCheck(rtx_comm_agree(comm_, rc == RTX_OK, &allOk, nullptr), "rtx_comm_agree");
-			if (!allOk) { std::cout << "rank " << rank_ << ": " << (rc == RTX_OK ? "another rank failed to render its rows" : rtx_last_error()) << '\n'; LOG_ERROR(); }
-		}
-		else gpuCheck(rc, "rtx_render_frame");
+		if (rc == RTX_OK) stage(rtx_frame_status(g, &status), "rtx_frame_status");
 		if (status && options::enableOutput) std::cout << "frame rendered again in three launches (single launch status " << (status & 0xffu) << ")\n";
 	}
 	else {
 		{
 			Timer tp("Render scene");
-			pass1OnDevice();
-			hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+			stage(rtx_counters_enable(g, statisticsOn()), "rtx_counters_enable");
+			if (rc == RTX_OK) stage(rtx_render_pass1(g, 0, (uint32_t)options.height, d.fb, nullptr), "rtx_render_pass1");
+			hipStage(hipDeviceSynchronize(), "hipDeviceSynchronize");
 		}
 		if (options::enableSSAA) {
 			Timer ts("MSAA");
-			ssaaOnDevice();
-			hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+			if (rc == RTX_OK) stage(rtx_sobel(g, d.fb, 0, (uint32_t)options.height, d.mask, nullptr), "rtx_sobel");
+			if (rc == RTX_OK) stage(rtx_render_ssaa(g, d.mask, 0, (uint32_t)options.height, d.fb, nullptr), "rtx_render_ssaa");
+			hipStage(hipDeviceSynchronize(), "hipDeviceSynchronize");
 		}
 	}
 	readTimes();
 	if (options::imageOutput || sharded) {
 		if (options.width % 4 != 0) { std::cout << "saveImage is only defined for width % 4 == 0 (util.cpp:28-29)\n"; LOG_ERROR(); }
-		gpuCheck(rtx_quantize_bgr8(g, d.fb, d.bgr, nullptr), "rtx_quantize_bgr8");
-		if (sharded) gpuCheck(rtx_gather(g, comm_, d.bgr, options.width * 3, 1, 0, nullptr), "rtx_gather");
+		if (rc == RTX_OK) stage(rtx_quantize_bgr8(g, d.fb, d.bgr, nullptr), "rtx_quantize_bgr8");
+		if (sharded) {
+			int allOk = 0;
+			gpuCheck(rtx_comm_agree(comm_, rc == RTX_OK, &allOk, nullptr), "rtx_comm_agree");
+			if (!allOk) { std::cout << "rank " << rank_ << ": " << (rc == RTX_OK ? "another rank failed to render its rows" : "this rank failed to render its rows") << '\n'; LOG_ERROR(); }
+			gpuCheck(rtx_gather(g, comm_, d.bgr, options.width * 3, 1, 0, nullptr), "rtx_gather");
+		}
 		hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
 		if (options::imageOutput && rank_ == 0) {
 			std::vector<unsigned char> bgr(options.width * options.height * 3);

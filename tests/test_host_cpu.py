@@ -235,3 +235,14 @@ def test_prune_records_enclose_what_they_stand_for(ra, scene, obj):
         for k in range(4):
             if link[w, k] != 0:
                 assert tuple(wide[w, k, 0:6].tolist()) in nb
+
+
+def test_flatten_rejects_a_right_child_outside_the_array(ra):
+    """an inner node whose right child index equals n_nodes (a leaf first child at n_nodes - 1) passed the skip-index check
+    and made the bottom-up passes of flattenMesh read past the arrays; rtx_mesh_flatten_probe feeds caller arrays straight in."""
+    bvh = dict(bounds=np.array([[0, 0, 0, 1, 1, 1], [0, 0, 0, 1, 1, 1], [0, 0, 0, 1, 1, 1]], np.float32),
+               skip=np.array([3, 3, 0], np.int32),            # node 1: inner, skip 3 = n_nodes; its first child (node 2) is a leaf -> right child = 3
+               leaf_begin=np.array([0, 0, 0], np.int32), leaf_count=np.array([-1, -1, 1], np.int32),
+               refs=np.array([0], np.uint32), tris=np.zeros((1, 30), np.float32))
+    with pytest.raises(ra.RtxError):
+        ra.mesh_flatten_probe(bvh)
