@@ -1511,7 +1511,7 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	HIPCHK(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
 	out->rays = c[0]; out->box_tests = c[1]; out->tri_tests = c[2]; out->moot_rays = c[15];
 	if (s->knobs.debugItems) fprintf(stderr, "[rtx] slowest work item %.3f ms, sum of items %.3f ms (100 MHz wall clock)\n", c[3] * 1e-5, c[4] * 1e-5);
-	if (s->knobs.debugItems) fprintf(stderr, "[rtx] wave-level: node visits %llu, reached leaves %llu, filter passes (64 references) %llu, of which rejected whole by stage 1 %llu, by stage 2 %llu; survivors tested exactly %llu; slots pruned by their records %llu, per-ray slot tests %llu\n", c[5], c[10], c[12], c[13], c[7], c[6], c[11], c[8]);
+	if (s->knobs.debugItems) fprintf(stderr, "[rtx] wave-level: node visits %llu, reached leaves %llu, filter passes (64 references) %llu, of which rejected whole by stage 1 %llu, by stage 2 %llu; survivors tested exactly %llu; slots pruned by their records %llu, per-ray slot tests %llu, evaluations of prune records %llu\n", c[5], c[10], c[12], c[13], c[7], c[6], c[11], c[8], c[9]);
 #if RTX_DBG
 	if (s->knobs.debugItems) {
 		std::vector<unsigned long long> w(3 * 16384);

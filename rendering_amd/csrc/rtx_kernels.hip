@@ -30,6 +30,9 @@
 
 using namespace rtxd;
 
+#ifndef RTX_BURN
+#define RTX_BURN 0         // (experiment: extra VALU instructions per node visit)
+#endif
 #ifndef RTX_FB_STORE
 #define RTX_FB_STORE 1     // pass 1: 1 = plain framebuffer stores; 0 / 2: the write-traffic experiments of profiles/r04_write_traffic.txt
 #endif
@@ -750,6 +753,7 @@ __device__ __forceinline__ bool pruneAlive(const f4v& r0, const f4v& r1, const f
 #ifndef RTX_PRUNE_PLANES
 #define RTX_PRUNE_PLANES 1
 #endif
+
 // The first stage of the bundle filter (bundleRejects1) for ALL triangles below a wide-node slot at once.  r0 / r1 = the slot's
 // rtxd::PlaneRec: every triangle's scaled plane normal q = (e2 x e1) / (s1 s2) lies in the box qc +- qr and its plane offset
 // v0 . q in [wlo, whi].  Dividing the filter's inequalities by s1 s2 > 0:
@@ -899,6 +903,16 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				}
 				if (inM == 0) continue;
 				if (RTX_DBG) { cnt.wNodes++; if (shadow) cnt.sVisits++; }
+#if RTX_BURN
+				// (experiment, profiles/r04_burn.txt: RTX_BURN extra VALU instructions per node visit on four independent registers -- does the launch get
+				// longer by their issue time (the VALU port is the bound) or not (the waves wait for something else)?)
+				{
+					float b0 = o.x, b1 = o.y, b2 = o.z, b3 = ix;
+#pragma unroll
+					for (int k = 0; k < RTX_BURN / 4; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+					asm volatile("" :: "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+				}
+#endif
 				const WideNode* w = wideNodes + (uint32_t)(link - 1);
 				const u32x16 wa = sload16(w), wb = sload16((const char*)w + 64);
 				// Which slots can contribute at all: lane k & 3 looks at slot k & 3 (bits 0..3 of the ballot are used).
@@ -916,7 +930,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 #else
 					aliveM = (uint32_t)ballot(aliveBox) & 0xfu;
 #endif
-					if (RTX_DBG) cnt.wLeafSkips += 4u - (uint32_t)__popc(aliveM);
+					if (RTX_DBG) { cnt.wS4++; cnt.wLeafSkips += 4u - (uint32_t)__popc(aliveM); }
 				}
 				// slots 3..0, so that slot 0 ends up on top of the stack
 #define RTX_SLOT(rec, base, k)                                                                                                     \
