@@ -256,6 +256,8 @@ def main():
     ap.add_argument("--verify", dest="verify", action="store_true", default=True,
                     help="N > 1 (default): after the timed region rank 0 also renders the whole frame alone and compares the gathered image with it")
     ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--serial-gather", action="store_true",
+                    help="N > 1: rtx_gather on the render stream, frame by frame (default: on a second stream, overlapping the next frame)")
     args = ap.parse_args()
     cscene, cw, ch = CONFIGS[args.config]
     custom = bool(args.scene or args.width or args.height or args.no_ssaa)
@@ -336,6 +338,10 @@ def main():
     elif world > 1:
         gather_via = "torch.distributed P2P over %s, staged through host memory (functional check)" % backend
 
+    pipe = parallel.FrameGather(scene, comm, img) if (comm is not None and not args.serial_gather) else None
+    if pipe is not None:
+        gather_via += ", overlapped with the next frame's render (second stream)"
+
     def step():
         # (fb was zeroed when it was allocated and only ever holds frames of this view and row ownership: the reference's
         # zero-initialised allocation, scene.cpp:599, is outside its timers too)
@@ -343,6 +349,9 @@ def main():
         if world > 1:
             # the frame has to end up in ONE place: quantise to the BGR8 image saveImage writes (4x fewer bytes than
             # the fp32 framebuffer) and send every owned band straight into rank 0's image
+            if pipe is not None:
+                pipe.submit(fb)      # quantise on this stream, rtx_gather on a second one: it overlaps the next frame's render
+                return
             scene.quantize(fb, img)
             if comm is not None:
                 comm.gather(scene, img, bottom_up=True)
@@ -354,6 +363,8 @@ def main():
                 img.copy_(host)
 
     def sync():
+        if pipe is not None:
+            pipe.wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -195,7 +195,8 @@ int rtx_render_ssaa(rtx_scene* scene, const uint8_t* mask_dev, uint32_t row_begi
                     float* fb_dev, void* stream);
 
 /* saveImage's quantiser (util.cpp:46-58): bottom-up rows, BGR, (uint8)(clamp(0,1,v)*255).
- * bgr_dev: H*W*3 bytes (W % 4 == 0). */
+ * bgr_dev: H*W*3 bytes (W % 4 == 0), 4-byte aligned; fb_dev 16-byte aligned.  Under rtx_set_row_ownership only the rows this
+ * device owns are converted; the others are not touched (rtx_gather fills them on the root). */
 int rtx_quantize_bgr8(rtx_scene* scene, const float* fb_dev, uint8_t* bgr_dev, void* stream);
 
 /* Convenience for hosts that hold a plain `Vec3f*`: pass 1 (+ optional Sobel/SSAA) into a host buffer;

@@ -1458,8 +1458,10 @@ int rtx_quantize_bgr8(rtx_scene* s, const float* fb_dev, uint8_t* bgr_dev, void*
 	const uint32_t W = s->params.view.width, H = s->params.view.height;
 	if (W % 4) return fail(RTX_ERR_UNSUPPORTED, "saveImage is only defined for width % 4 == 0 (util.cpp:28-29)");
 	HIPCHK(hipSetDevice(s->device));
-	const size_t n = (size_t)W * H;
-	hipLaunchKernelGGL(rtxQuantizeKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fb_dev, bgr_dev, W, H);
+	if (((uintptr_t)fb_dev & 15u) || ((uintptr_t)bgr_dev & 3u)) return fail(RTX_ERR_ARG, "rtx_quantize_bgr8: fb must be 16-byte aligned, the image 4-byte aligned");
+	const size_t n = (size_t)(W / 4) * H;
+	hipLaunchKernelGGL(rtxQuantizeKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fb_dev, bgr_dev, W, H,
+	                   s->params.bandH, s->params.nParts, s->params.part);
 	HIPCHK(hipGetLastError());
 	return RTX_OK;
 }

@@ -1894,6 +1894,9 @@ __device__ __forceinline__ uint32_t nthSetBit(uint64_t m, uint32_t n)   // posit
 	return pos;
 }
 
+#ifndef RTX_SSAA_SPREAD_PX
+#define RTX_SSAA_SPREAD_PX 4u      // pixels per wave for the tiles that were very slow in pass 1 (rtxSsaaCountKernel)
+#endif
 template <bool STATS, bool MESH = true, bool BOXES = true>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTIC) rtxSsaaKernel(const Params P)
 {
@@ -2231,7 +2234,7 @@ __global__ void __launch_bounds__(256) rtxSsaaCountKernel(const Params P, uint32
 	// spreadSlots extra ones (mode[2] = handed out so far), a tile that does not get its share is packed normally.  The
 	// scatter kernel recognises the layout from the tile's slot count.
 	if (local) {
-		const uint32_t packed = (nf + 15u) & ~15u, spread = ((nf + 3u) >> 2) * 16u;
+		const uint32_t packed = (nf + 15u) & ~15u, spread = ((nf + RTX_SSAA_SPREAD_PX - 1u) / RTX_SSAA_SPREAD_PX) * 16u;
 		nf = packed;
 		if (P.tileCost[t] > RTX_SSAA_VERY * heavyTicks && spread > packed && atomicAdd(mode + 2, spread - packed) + (spread - packed) <= spreadSlots) nf = spread;
 	}
@@ -2255,12 +2258,12 @@ __global__ void __launch_bounds__(256) rtxSsaaScatterKernel(const Params P, cons
 	uint32_t slot = scan[idx];
 	const uint32_t slots = scan[idx + 1] - slot, nf = (uint32_t)__popcll(m);      // (the other half's entry of a tile is 0 slots wide)
 	const bool spread = mode[0] && slots > ((nf + 15u) & ~15u);      // 4 pixels per group of 16 slots
-	uint32_t n = 0;
+	uint32_t n = 0, px = 0;
 	while (m) {
 		const uint32_t pos = (uint32_t)__builtin_ctzll(m);
 		m &= m - 1;
 		pixels[slot + n++] = (tx * 8 + (pos & 7)) | (ty * 8 + (pos >> 3)) << 16;
-		if (spread && (n & 3u) == 0) for (int k = 0; k < 12; k++) pixels[slot + n++] = 0xffffffffu;
+		if (spread && ++px % RTX_SSAA_SPREAD_PX == 0) for (uint32_t k = 0; k < 16u - RTX_SSAA_SPREAD_PX; k++) pixels[slot + n++] = 0xffffffffu;
 	}
 	if (mode[0]) for (; n < slots; n++) pixels[slot + n] = 0xffffffffu;
 }
@@ -2332,6 +2335,11 @@ __global__ void __launch_bounds__(256) rtxSobelKernel(const float* __restrict__ 
 	const int x = (int)(blockIdx.x * 62 + lane) - 1;
 	const uint32_t y0 = rowBegin + (blockIdx.y * 4 + (threadIdx.x >> 6)) * kSobelRows;
 	if (y0 >= rowEnd || y0 >= H) return;
+	// (a wave none of whose rows this device owns has nothing to write: one part of an 8-way sharded frame spent as long
+	// here as the whole frame does, reading rows it then did not flag)
+	bool anyOwned = false;
+	for (uint32_t r = 0; r < kSobelRows; ++r) anyOwned = anyOwned || rowOwned(bandH, nParts, part, y0 + r);
+	if (!anyOwned) return;
 	const bool xin = x >= 0 && x < (int)W;
 	const bool interiorX = x >= 1 && x + 1 < (int)W && lane >= 1 && lane <= 62;
 	// (all the rows requested before the first is used: walked one load at a time a wave waited for 18 memory round trips)
@@ -2715,15 +2723,30 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 	}
 }
 
-// saveImage's quantiser (util.cpp:46-58)
+// saveImage's quantiser (util.cpp:46-58): bottom-up rows, BGR, (uint8)(clamp(0, 1, v) * 255).  A thread converts four
+// pixels (W % 4 == 0, util.cpp:28-29): 48 bytes in as three 16-byte loads, 12 bytes out as three dwords.  Rows of the
+// image that belong to another device (rtx_set_row_ownership) are left alone -- rtx_gather fills them on the root.
 __global__ void __launch_bounds__(256) rtxQuantizeKernel(const float* __restrict__ fb, uint8_t* __restrict__ out,
-                                                         uint32_t W, uint32_t H)
+                                                         uint32_t W, uint32_t H, uint32_t bandH, uint32_t nParts, uint32_t part)
 {
-	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // output pixel index, bottom-up rows
-	if (i >= (size_t)W * H) return;
-	const uint32_t row = (uint32_t)(i / W), x = (uint32_t)(i - (size_t)row * W);
-	const float* px = fb + ((size_t)(H - 1 - row) * W + x) * 3;
-	for (int k = 2; k >= 0; --k) out[i * 3 + (2 - k)] = (uint8_t)(int)(clampRef(0.0f, 1.0f, px[k]) * 255);
+	const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of four output pixels, bottom-up rows
+	const uint32_t perRow = W / 4;
+	if (q >= (size_t)perRow * H) return;
+	const uint32_t row = (uint32_t)(q / perRow), x = (uint32_t)(q - (size_t)row * perRow) * 4;
+	const uint32_t y = H - 1 - row;
+	if (!rowOwned(bandH, nParts, part, y)) return;
+	const float4* in = (const float4*)(fb + ((size_t)y * W + x) * 3);
+	const float4 a = in[0], b = in[1], c = in[2];
+	const float v[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
+	uint32_t o[3] = { 0, 0, 0 };
+	for (int px = 0; px < 4; ++px)
+		for (int k = 0; k < 3; ++k) {
+			const uint32_t byte = (uint32_t)(uint8_t)(int)(clampRef(0.0f, 1.0f, v[px * 3 + (2 - k)]) * 255);
+			const int at = px * 3 + k;
+			o[at >> 2] |= byte << ((at & 3) * 8);
+		}
+	uint32_t* dst = (uint32_t*)(out + ((size_t)row * W + x) * 3);
+	dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
 }
 
 // Device-math self-check (rtx_math_probe)

@@ -8,6 +8,10 @@ Per frame and rank:
     quantise to BGR8 (what saveImage writes, util.cpp:46-58; 4x fewer bytes than the fp32 framebuffer)
     ONE exchange: every owned band is sent to rank 0 as a point-to-point message, placed directly -- rtx_gather of the
     C ABI (RCCL, include/rtx.h); make_comm() bootstraps its communicator over an existing torch.distributed group.
+In a sequence of frames the exchange of frame k runs on a second HIP stream while frame k + 1 is rendered (FrameGather):
+a part's stages last as long as their slowest wave, not as long as their work (tools/shard_stages.py: one eighth of the
+headline frame's SSAA takes 0.37 ms, the whole 0.51), so cutting a frame into band groups to send the first while the second
+renders would pay those tails once per group -- frames, not bands, are what is pipelined.
 The scene (<= ~60 MB) is replicated on every GPU.  gather_frame() is the same exchange over torch.distributed
 point-to-point operations; it exists for the CPU (gloo) tests and for boxes where the ranks have to share a device.
 """
@@ -80,6 +84,40 @@ def gather_frame(img, n_parts, part, band=None, dst=0, group=None, bottom_up=Fal
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return img
+
+
+class FrameGather:
+    """The exchange of one frame overlapped with the rendering of the next.  submit(fb), called after a frame's kernels
+    were queued on the current stream, queues there the quantiser (this rank's rows of fb -> img, BGR8 bottom-up) and on a
+    second stream rtx_gather of img; the next frame's kernels do not wait for it.  img is reused: the quantiser of frame
+    k + 1 waits (on the device, an event) until the exchange of frame k has left / filled img -- long after it ended, as
+    a frame renders several times longer than it travels.  wait() makes the current stream wait for the last exchange:
+    rank `root`'s img then holds the last frame submitted.  A consumer that needs every frame calls wait() per frame (and
+    gives up the overlap) or hands in a different img per frame."""
+
+    def __init__(self, scene, comm, img, root=0):
+        import torch
+        self.scene, self.comm, self.img, self.root = scene, comm, img, root
+        self.side = torch.cuda.Stream()
+        self.done = None
+
+    def submit(self, fb):
+        import torch
+        cur = torch.cuda.current_stream()
+        if self.done is not None:
+            cur.wait_event(self.done)
+        self.scene.quantize(fb, self.img)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self.side.wait_event(ready)
+        self.comm.gather(self.scene, self.img, bottom_up=True, root=self.root, stream=self.side)
+        self.done = torch.cuda.Event()
+        self.done.record(self.side)
+
+    def wait(self):
+        import torch
+        if self.done is not None:
+            torch.cuda.current_stream().wait_event(self.done)
 
 
 def make_comm(n_parts, part, device, group=None):

@@ -272,6 +272,41 @@ def test_comm_single_rank_and_gather_noop(ra, torch_cuda):
     c.close()
 
 
+def test_quantize_owned_rows_only_and_frame_gather(ra, torch_cuda):
+    """rtx_quantize_bgr8 under row ownership converts the owned rows and leaves the others alone (they are another device's to
+    deliver); parallel.FrameGather (quantiser on the render stream, rtx_gather on a second one, the image reused frame after frame)
+    ends with the image of the last frame."""
+    torch = torch_cuda
+    from rendering_amd import parallel
+    H = W = 256
+    g = ra.Scene("scenes/cfg1_simple_shapes.scene", W, H)
+    fb, _ = render(torch, g)
+    whole = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    g.quantize(fb, whole)
+    g.set_row_ownership(64, 2, 1, halo=True)
+    part = torch.full((H, W, 3), 7, dtype=torch.uint8, device="cuda")
+    g.quantize(fb, part)
+    torch.cuda.synchronize()
+    own = torch.zeros(H, dtype=torch.bool)
+    own[parallel.owned_rows(H, 64, 2, 1)] = True
+    own = own.flip(0).cuda()                      # image row y is stored at H-1-y
+    assert torch.equal(part[own], whole[own]) and bool((part[~own] == 7).all())
+    g.set_row_ownership(0, 1, 0, halo=False)
+    c = ra.Comm(1, 0, 0, lambda raw: raw)
+    img = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    pipe = parallel.FrameGather(g, c, img)
+    for k in range(3):
+        fb.mul_(0.5) if k else None
+        pipe.submit(fb)
+    pipe.wait()
+    torch.cuda.synchronize()
+    last = torch.zeros_like(img)
+    g.quantize(fb, last)
+    torch.cuda.synchronize()
+    assert torch.equal(img, last)
+    c.close()
+
+
 def test_cpp_cli_multi_gpu(ra, tmp_path):
     """`render_amd --gpus 2 <scene>`: two processes, one GPU each, bands collected on rank 0 by rtx_gather -- the BMP is
     the single-GPU one.  On a box with one GPU the launcher must refuse (exit status 2) instead of hanging."""
