@@ -33,6 +33,17 @@ using namespace rtxd;
 #ifndef RTX_BURN
 #define RTX_BURN 0         // (experiment: extra VALU instructions per node visit)
 #endif
+#ifndef RTX_POP_MANY
+#define RTX_POP_MANY 4     // pass 1: tiles taken per atomic in the cheap half of a queue (0: one everywhere).  Headline pass 1 3.366 -> 3.271 ms, cfg5 11.70 -> 11.38;
+                           // 8 or 16 per atomic, and helpings that shrink towards the end of the queue, lost to 4 at 4096^2 (profiles/r04_ab_pop.txt)
+#endif
+#ifndef RTX_POP_NUM
+#define RTX_POP_NUM 1u     // ... from this fraction of the queue on
+#define RTX_POP_DEN 2u
+#endif
+#ifndef RTX_POP_NOPRIO
+#define RTX_POP_NOPRIO 1   // ... and there no look at the tile's previous cost for the wave priority (one dependent load less per tile)
+#endif
 #ifndef RTX_PR8
 #define RTX_PR8 0          // (experiment) the prune records are fetched and evaluated by lanes 0-7 only (exec-masked vector loads: an eighth of the address / return traffic)
 #endif
@@ -1902,10 +1913,27 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 	for (uint32_t attempt = 0; attempt < 8; attempt = uni(attempt + 1)) {
 		const uint32_t q = (xcd + attempt) & 7u;
 		const uint32_t qBase = sload1(P.tileList + q), qSize = sload1(P.tileList + 8 + q);
+#if RTX_POP_MANY
+		// The queues are ordered heaviest-first: from the middle of a queue on the tiles are the cheap ones (sky, floor: 10-20 us), where the
+		// returning atomic and the dependent read of the list are a sizeable part of a tile -- there a wave takes RTX_POP_MANY tiles per atomic.
+		uint32_t take = 1, jEnd = 0, j = 0;
+		for (;;) {
+			if (j >= jEnd) {
+				uint32_t w = 0;
+				if (__lane_id() == 0) w = atomicAdd(P.workCounter + q * 16, take);
+				j = __builtin_amdgcn_readfirstlane(w);
+				if (j >= qSize) break;
+				jEnd = j + take < qSize ? j + take : qSize;
+				if (RTX_POP_DEN * j >= RTX_POP_NUM * qSize) take = RTX_POP_MANY;
+			}
+			const uint32_t tile = sload1(P.tileList + qBase + j);
+			j = uni(j + 1);
+#else
 		for (;;) {
 			const uint32_t j = nextWork(P.workCounter + q * 16);
 			if (j >= qSize) break;
 			const uint32_t tile = sload1(P.tileList + qBase + j);
+#endif
 #if RTX_DBG
 			if (P.pad3 != 0 && tile != P.pad3 - 1) continue;      // RTX_DBG_TILE=tx,ty: only this tile (counters of one work item)
 #endif
@@ -1922,6 +1950,10 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 #if RTX_PRIO
 			// a tile that was slow in the previous launch of this view (a pole, a silhouette) runs at raised priority: the
 			// launch ends when its slowest wave does, and such a wave otherwise gets one issue slot in RTX_WAVES
+#if RTX_POP_MANY && RTX_POP_NOPRIO
+			if (take > 1) __builtin_amdgcn_s_setprio(0);      // (the cheap part of the queue: no look at the tile's cost)
+			else
+#endif
 			if (sload1(P.tileCost + ty * P.tilesXFull + tx) > RTX_PRIO_TICKS) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 #endif
 			const unsigned long long t0 = wall_clock64();
