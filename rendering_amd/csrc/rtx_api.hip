@@ -112,6 +112,7 @@ struct Knobs {
 	uint32_t spreadSlots = 1u << 20;     // RTX_SSAA_SPREAD_SLOTS: slot budget of the 4-pixel SSAA waves
 	uint32_t splitPercent = 100;         // RTX_SPLIT_PERCENT: frame kernel, tile split limit in % of the even share; 0 = never
 	long long localBelow = -1;           // RTX_SSAA_LOCAL_BELOW: tile-local SSAA list below this many flagged pixels; -1 = by device size
+	long long sparseBelow = -1;          // RTX_SSAA_SPARSE_BELOW: one-step-finer SSAA items below this many flagged pixels (rtxSsaaCountKernel); -1 = by device size, 0 = never
 	int frameMode = -1;                  // RTX_FRAME_MODE=split|fused
 	uint32_t frameQueueCap = 0;          // RTX_FRAME_QUEUE_CAP: entries per SSAA item queue of the frame kernel; 0 = sized from the frame
 	bool debugItems = false;             // RTX_DEBUG_ITEMS: rtx_counters_read prints the wave-level counters
@@ -215,6 +216,7 @@ void readKnobs(Knobs& k)
 	k.spreadSlots = (uint32_t)std::min<long long>(num("RTX_SSAA_SPREAD_SLOTS", k.spreadSlots), 1ll << 20);
 	k.splitPercent = (uint32_t)num("RTX_SPLIT_PERCENT", k.splitPercent);
 	k.localBelow = num("RTX_SSAA_LOCAL_BELOW", -1);
+	k.sparseBelow = num("RTX_SSAA_SPARSE_BELOW", -1);
 	if (const char* e = getenv("RTX_FRAME_MODE")) k.frameMode = !strcmp(e, "split") ? 0 : (!strcmp(e, "fused") ? 1 : -1);
 	k.frameQueueCap = (uint32_t)num("RTX_FRAME_QUEUE_CAP", 0);
 	k.debugItems = getenv("RTX_DEBUG_ITEMS") != nullptr;
@@ -1305,6 +1307,7 @@ int rtx_set_knob(rtx_scene* s, const char* name, double value)
 	else if (n == "ssaa_spread_slots") k.spreadSlots = (uint32_t)std::min(value, (double)kSsaaSpreadSlots);
 	else if (n == "split_percent") k.splitPercent = (uint32_t)value;
 	else if (n == "ssaa_local_below") k.localBelow = (long long)value;
+	else if (n == "ssaa_sparse_below") k.sparseBelow = (long long)value;
 	else if (n == "frame_queue_cap") k.frameQueueCap = (uint32_t)value;
 	else if (n == "debug_items") k.debugItems = value != 0;
 	else return fail(RTX_ERR_ARG, "unknown knob: " + n);
@@ -1431,7 +1434,7 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	// The layout (tile-local or packed) follows from the number of flagged pixels: a count, a scan and a copy before the
 	// real count.  It only changes when the view does, so it is decided on the first frame of a view (and again every 16th)
 	// and kept in between -- five small launches less per frame.
-	const uint64_t key = ((((((uint64_t)s->viewSerial * 0x9e3779b97f4a7c15ull + W) * 31 + H) * 31 + rowBegin) * 31 + rowEnd) * 31 + p.bandH * 64 + p.nParts * 8 + p.part) * 31 + localBelow;
+	const uint64_t key = (((((((uint64_t)s->viewSerial * 0x9e3779b97f4a7c15ull + W) * 31 + H) * 31 + rowBegin) * 31 + rowEnd) * 31 + p.bandH * 64 + p.nParts * 8 + p.part) * 31 + localBelow) * 31 + (uint64_t)(s->knobs.sparseBelow + 1);
 	const bool decideNow = key != s->ssaaLayoutKey || (s->ssaaLayoutAge++ & 15u) == 15u;
 	if (decideNow) {
 		hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, 0u, 0u, 0u);
@@ -1439,7 +1442,10 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 		HIPCHK(hipMemcpyAsync(mode + 1, s->items + 2 * (size_t)p.nTiles, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
 		s->ssaaLayoutKey = key; s->ssaaLayoutAge = 0;
 	}
-	hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, decideNow ? 1u : 2u, localBelow, spreadSlots);
+	// "sparse" (rtxSsaaCountKernel): fewer 16-pixel items than half the waves of the launch
+	uint32_t sparseBelow = (uint32_t)s->blocksSsaa * 4u * 16u / 2u;
+	if (s->knobs.sparseBelow >= 0) sparseBelow = (uint32_t)std::min<long long>(s->knobs.sparseBelow, 0xffffffffll);
+	hipLaunchKernelGGL(rtxSsaaCountKernel, dim3((scanN + 255) / 256), dim3(256), 0, st, p, s->items, mode, heavyTicks, decideNow ? 1u : 2u, localBelow, spreadSlots, sparseBelow);
 	if ((rc = scanExclusive(s->items, scanN, s->items + scanN, st, launches))) return rc;
 	hipLaunchKernelGGL(rtxSsaaScatterKernel, dim3((p.nTiles + 255) / 256), dim3(256), 0, st, p, s->items, mode, s->ssaaPixels, heavyTicks);
 	HIPCHK(hipGetLastError());

@@ -2331,14 +2331,18 @@ __device__ __forceinline__ uint64_t ssaaFlagged(const Params& P, uint32_t tx, ui
 // Chosen on the device (decide != 0: from the total of the previous, unpadded count): with few flagged pixels the
 // launch is bounded by its slowest wave and coherent, tile-local waves are shorter; with many, full waves win.
 __global__ void __launch_bounds__(256) rtxSsaaCountKernel(const Params P, uint32_t* __restrict__ scan, uint32_t* __restrict__ mode,
-                                                          uint32_t heavyTicks, uint32_t decide, uint32_t localBelow, uint32_t spreadSlots)
+                                                          uint32_t heavyTicks, uint32_t decide, uint32_t localBelow, uint32_t spreadSlots, uint32_t sparseBelow = 0)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t > 2 * P.nTiles) return;
 	// mode[1] = number of flagged pixels found by the previous (unpadded) count
 	// decide: 0 = the plain count (for the decision), 1 = decide from it, 2 = the layout decided for an earlier frame of this view
 	const uint32_t local = decide == 2 ? mode[0] : (decide ? (mode[1] < localBelow ? 1u : 0u) : 0u);
-	if (t >= P.nTiles) { if (t == 2 * P.nTiles) { scan[t] = 0; if (decide == 1) mode[0] = local; } return; }
+	// mode[3] ("sparse"): fewer 16-pixel items than half the waves of the launch (a device's share of a frame, a small frame): every wave
+	// gets at most one item anyway and the launch lasts as long as its slowest item, so the items are cut one step finer -- 4 pixels for
+	// the tiles that were slow in pass 1, ONE pixel for the very slow ones.
+	const uint32_t sparse = decide == 2 ? mode[3] : (decide ? (mode[1] < sparseBelow ? 1u : 0u) : 0u);
+	if (t >= P.nTiles) { if (t == 2 * P.nTiles) { scan[t] = 0; if (decide == 1) { mode[0] = local; mode[3] = sparse; } } return; }
 	const uint32_t ty = t / P.tilesXFull, tx = t - ty * P.tilesXFull;
 	uint32_t nf = (uint32_t)__popcll(ssaaFlagged(P, tx, ty));
 	// local mode: a wave holds 16 pixels of one tile -- or only 4 of a tile that was VERY slow in pass 1 (a silhouette),
@@ -2346,9 +2350,13 @@ __global__ void __launch_bounds__(256) rtxSsaaCountKernel(const Params P, uint32
 	// spreadSlots extra ones (mode[2] = handed out so far), a tile that does not get its share is packed normally.  The
 	// scatter kernel recognises the layout from the tile's slot count.
 	if (local) {
-		const uint32_t packed = (nf + 15u) & ~15u, spread = ((nf + RTX_SSAA_SPREAD_PX - 1u) / RTX_SSAA_SPREAD_PX) * 16u;
+		const uint32_t cost = P.tileCost[t];
+		uint32_t per = 16u;
+		if (cost > RTX_SSAA_VERY * heavyTicks) per = sparse ? 1u : RTX_SSAA_SPREAD_PX;
+		else if (sparse && cost > heavyTicks) per = RTX_SSAA_SPREAD_PX;
+		const uint32_t packed = (nf + 15u) & ~15u, spread = ((nf + per - 1u) / per) * 16u;
 		nf = packed;
-		if (P.tileCost[t] > RTX_SSAA_VERY * heavyTicks && spread > packed && atomicAdd(mode + 2, spread - packed) + (spread - packed) <= spreadSlots) nf = spread;
+		if (per < 16u && spread > packed && atomicAdd(mode + 2, spread - packed) + (spread - packed) <= spreadSlots) nf = spread;
 	}
 	const bool heavy = P.tileCost[t] > heavyTicks;
 	scan[t] = heavy ? nf : 0u;
@@ -2369,13 +2377,14 @@ __global__ void __launch_bounds__(256) rtxSsaaScatterKernel(const Params P, cons
 	P.tileCost[P.nTiles + t] = 0;      // (the SSAA item costs of this frame are collected from here on: rtxSsaaKernel)
 	uint32_t slot = scan[idx];
 	const uint32_t slots = scan[idx + 1] - slot, nf = (uint32_t)__popcll(m);      // (the other half's entry of a tile is 0 slots wide)
-	const bool spread = mode[0] && slots > ((nf + 15u) & ~15u);      // 4 pixels per group of 16 slots
+	const bool spread = mode[0] && slots > ((nf + 15u) & ~15u);      // 4 pixels (or one: the count kernel's "sparse" layout) per group of 16 slots
+	const uint32_t per = !spread ? 16u : (slots == ((nf + RTX_SSAA_SPREAD_PX - 1u) / RTX_SSAA_SPREAD_PX) * 16u ? RTX_SSAA_SPREAD_PX : 1u);
 	uint32_t n = 0, px = 0;
 	while (m) {
 		const uint32_t pos = (uint32_t)__builtin_ctzll(m);
 		m &= m - 1;
 		pixels[slot + n++] = (tx * 8 + (pos & 7)) | (ty * 8 + (pos >> 3)) << 16;
-		if (spread && ++px % RTX_SSAA_SPREAD_PX == 0) for (uint32_t k = 0; k < 16u - RTX_SSAA_SPREAD_PX; k++) pixels[slot + n++] = 0xffffffffu;
+		if (spread && ++px % per == 0) for (uint32_t k = 0; k < 16u - per; k++) pixels[slot + n++] = 0xffffffffu;
 	}
 	if (mode[0]) for (; n < slots; n++) pixels[slot + n] = 0xffffffffu;
 }
