@@ -680,13 +680,21 @@ __device__ __forceinline__ void triTestLane(const RefA& ra, const RefB& rb, cons
 #ifndef RTX_MAX_SPLITS
 #define RTX_MAX_SPLITS 4          // halvings of a wide bundle
 #endif
+// Leaves noted before their references are processed (meshWalk): ONE where a launch is bound by throughput (pass 1: a hit found in a
+// leaf tightens the bundle's limit / ends a shadow ray before the next node is visited -- headline pass 1 3.275 -> 3.176 ms, cfg5 11.40 ->
+// 11.01 against the 4 of round 3), TWO where it lasts as long as its slowest wave's chain of fetches (SSAA items, the frame kernel: FEWRAYS;
+// cfg2 at 1080p 1.306 (4) / 1.292 (2) / 1.353 (1) ms).  profiles/r04_ab_leaf_batch.txt
 #ifndef RTX_LEAF_BATCH
-#define RTX_LEAF_BATCH 4
+#define RTX_LEAF_BATCH 1
 #endif
+#ifndef RTX_LEAF_BATCH_FEW
+#define RTX_LEAF_BATCH_FEW 2
+#endif
+#define RTX_LEAF_BATCH_MAX (RTX_LEAF_BATCH > RTX_LEAF_BATCH_FEW ? RTX_LEAF_BATCH : RTX_LEAF_BATCH_FEW)
 // one reached leaf: first reference, number of references, the lanes (rays) that passed its box, start in the batch's stream
 struct LeafEntry { uint32_t start, count, first, pad0, maskLo, maskHi, pad1, pad2; };      // (what the assignment of a pass needs arrives with one 16-byte read)
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-__shared__ LeafEntry leafBatch[4][RTX_LEAF_BATCH];      // per wave of a 256-thread block; private to the wave (no barrier)
+__shared__ LeafEntry leafBatch[4][RTX_LEAF_BATCH_MAX];      // per wave of a 256-thread block; private to the wave (no barrier)
 // WIDE walk: pending subtrees / leaves of the wave, top of the stack = next in the reference's order.  link > 0: wide node
 // link - 1; link < 0: leaf with ~link references from `first`; mask = the rays that passed the item's own box.
 struct WideItem { int32_t link; uint32_t first, maskLo, maskHi; };
@@ -816,6 +824,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 	const uint32_t nN = mp[12];
 	bt = kFltMax; bu = 0; bv = 0; btri = 0;
 	if (nN == 0) return;
+	constexpr uint32_t kLeafBatch = FEWRAYS ? RTX_LEAF_BATCH_FEW : RTX_LEAF_BATCH;
 	// the largest limit of any ray of the wave: a triangle whose t is certainly not below it cannot be recorded by any
 	// lane (tightened whenever a lane finds a closer hit)
 	float tmaxB = unif(waveMax(consider ? tLimit : -__builtin_inff()));
@@ -922,7 +931,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				if (tosValid) { if (lane == 0) { WideItem ni; ni.link = tosLink; ni.first = tosFirst; ni.maskLo = (uint32_t)tosMask; ni.maskHi = (uint32_t)(tosMask >> 32); stack[sp] = ni; } sp = uni(sp + 1); } \
 				tosLink = (int32_t)(lnk); tosFirst = (fst); tosMask = (m); tosValid = true;                                         \
 			}
-			while ((tosValid || sp != 0) && batch < RTX_LEAF_BATCH) {
+			while ((tosValid || sp != 0) && batch < kLeafBatch) {
 				int32_t link; uint32_t itFirst; uint64_t itMask;
 				if (tosValid) { link = tosLink; itFirst = tosFirst; itMask = tosMask; tosValid = false; }
 				else {
@@ -938,7 +947,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				if (lane == 0) { WideItem ni; ni.link = (int32_t)(lnk); ni.first = (fst); ni.maskLo = (uint32_t)(m); ni.maskHi = (uint32_t)((m) >> 32); stack[sp] = ni; } \
 				sp = uni(sp + 1);                                                                                              \
 			}
-			while (sp != 0 && batch < RTX_LEAF_BATCH) {
+			while (sp != 0 && batch < kLeafBatch) {
 				sp = uni(sp - 1);
 				const WideItem it = stack[sp];
 				const int32_t link = (int32_t)uni((uint32_t)it.link);
@@ -997,7 +1006,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				if (sm2 != 0 && (aliveM & 4u)) RTX_PUSH(wb[6], wb[7], sm2)
 				if (sm1 != 0 && (aliveM & 2u)) RTX_PUSH(wa[14], wa[15], sm1)
 				if (sm0 != 0 && (aliveM & 1u)) {
-					if ((int32_t)wa[6] < 0 && batch < RTX_LEAF_BATCH) noteLeaf((int32_t)wa[6], wa[7], sm0);
+					if ((int32_t)wa[6] < 0 && batch < kLeafBatch) noteLeaf((int32_t)wa[6], wa[7], sm0);
 					else RTX_PUSH(wa[6], wa[7], sm0)
 				}
 #else
@@ -1042,7 +1051,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 					const uint64_t mk_ = ballot(!fail) & inM;
 					if (RTX_DBG) cnt.wS3++;
 					if (mk_ != 0) {
-						if ((int32_t)wa[6] < 0 && batch < RTX_LEAF_BATCH) noteLeaf((int32_t)wa[6], wa[7], mk_);
+						if ((int32_t)wa[6] < 0 && batch < kLeafBatch) noteLeaf((int32_t)wa[6], wa[7], mk_);
 						else RTX_PUSH(wa[6], wa[7], mk_)
 					}
 				}
@@ -1055,7 +1064,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 #if RTX_NODE_PACKED
 			const f2 oxx = { o.x, o.x }, oyy = { o.y, o.y }, ozz = { o.z, o.z }, ixx = { ix, ix }, iyy = { iy, iy }, izz = { iz, iz };
 #endif
-			while (i < nN && batch < RTX_LEAF_BATCH) {
+			while (i < nN && batch < kLeafBatch) {
 				const int32_t link = (int32_t)nd[6];
 				const uint32_t next = uni(i + 1);
 				const uint32_t nxt = link > 0 ? (uint32_t)link : next;
