@@ -904,6 +904,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 #endif
 		// ---- phase 1: nodes.  The reached leaves are noted in a small per-wave table in LDS.
 		uint32_t batch = 0, total = 0;      // total = references of the batch: its leaves form ONE stream, entry k starts at entries[k].start
+		uint32_t soleFirst = 0;             // kLeafBatch == 1: the first reference of the batch's only leaf
 		uint32_t myReach = 0;               // bit k: this lane's ray reached leaf k of the batch (the lane's own column of the table's masks)
 		if (WIDE) {
 			const uint32_t lane = laneNow();
@@ -914,7 +915,9 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				const uint32_t n = (uint32_t)~link;
 				if (RTX_DBG) { cnt.wLeaves++; if (shadow) cnt.sLeaves++; }
 				if (m != 0 && n != 0) {
-					if (lane == 0) {
+					// (one leaf per batch: what the pass needs of it stays in SGPRs -- no trip through the table in LDS)
+					if (kLeafBatch == 1 && !FEWRAYS) soleFirst = uni(first);
+					else if (lane == 0) {
 						LeafEntry en;
 						en.first = first; en.count = n; en.maskLo = (uint32_t)m; en.maskHi = (uint32_t)(m >> 32); en.start = total; en.pad0 = en.pad1 = en.pad2 = 0;
 						entries[batch] = en;
@@ -1124,7 +1127,8 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 					if (STATS) cnt.tri += (unsigned long long)__popcll(m) * n;
 					if (RTX_DBG) cnt.wLeaves++;
 					if (n != 0) {
-						if (laneNow() == 0) {
+						if (kLeafBatch == 1 && !FEWRAYS) soleFirst = nd[7];
+						else if (laneNow() == 0) {
 							LeafEntry en;
 							en.first = nd[7]; en.count = n; en.maskLo = (uint32_t)m; en.maskHi = (uint32_t)(m >> 32); en.start = total; en.pad0 = en.pad1 = en.pad2 = 0;
 							entries[batch] = en;
@@ -1153,6 +1157,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 		// from their start on
 		auto assign = [&](uint32_t p0, uint32_t& r, uint32_t& myEnt) {
 			r = 0; myEnt = 0;
+			if (kLeafBatch == 1 && !FEWRAYS) { r = soleFirst + p0 + lane; return; }
 			for (uint32_t e = ecur; e < batch; e = uni(e + 1)) {
 				const u32x4v head = *(const u32x4v*)&entries[e];          // one LDS round trip per entry: start, count, first
 				const uint32_t st = uni(head.x);
@@ -1236,7 +1241,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 #if RTX_TRI_BPERMUTE
 				const uint32_t tri = (uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)ra.tri);
 				// the rays that reached the survivor's leaf
-				const uint32_t ent = (uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)myEnt);
+				const uint32_t ent = (kLeafBatch == 1 && !FEWRAYS) ? 0u : (uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)myEnt);
 #else
 				const uint32_t tri = (uint32_t)__builtin_amdgcn_readlane((int)ra.tri, c);
 				const uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)myEnt, c);
