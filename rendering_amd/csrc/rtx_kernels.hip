@@ -44,15 +44,6 @@ using namespace rtxd;
 #ifndef RTX_POP_NOPRIO
 #define RTX_POP_NOPRIO 1   // ... and there no look at the tile's previous cost for the wave priority (one dependent load less per tile)
 #endif
-#ifndef RTX_PR8
-#define RTX_PR8 0          // (experiment) the prune records are fetched and evaluated by lanes 0-7 only (exec-masked vector loads: an eighth of the address / return traffic)
-#endif
-#ifndef RTX_SLOTS_FIRST
-#define RTX_SLOTS_FIRST 0  // (experiment) the per-ray box tests of the four slots run while the prune records are in flight
-#endif
-#ifndef RTX_TOS
-#define RTX_TOS 0          // (experiment) the top of the wide stack lives in SGPRs: the next pop needs no LDS round trip
-#endif
 #ifndef RTX_FB_STORE
 #define RTX_FB_STORE 1     // pass 1: 1 = plain framebuffer stores; 0 / 2: the write-traffic experiments of profiles/r04_write_traffic.txt
 #endif
@@ -840,7 +831,6 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 	WideItem* stack = wideStack[threadIdx.x >> 6];
 	const WideNode* wideNodes = WIDE ? (const WideNode*)RTX_MP(4) : nullptr;
 	uint32_t sp = 0;
-	bool tosValid = false; int32_t tosLink = 0; uint32_t tosFirst = 0; uint64_t tosMask = 0;      // (RTX_TOS)
 	const RTX_AS1 char* pruneRecs = nullptr;
 	float* pu = pruneUni[threadIdx.x >> 6];
 	if (WIDE && RTX_PRUNE) {
@@ -891,12 +881,8 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 	if (WIDE) {
 		// (the rays in `consider` have passed the root box: traceWave)
 		const uint64_t m0 = ballot(consider);
-#if RTX_TOS
-		tosValid = true; tosLink = 1; tosFirst = 0; tosMask = m0;
-#else
 		if (laneNow() == 0) { WideItem it; it.link = 1; it.first = 0; it.maskLo = (uint32_t)m0; it.maskHi = (uint32_t)(m0 >> 32); stack[0] = it; }
 		sp = 1;
-#endif
 	}
 	for (;;) {
 #if RTX_DBG
@@ -927,24 +913,6 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 					total = uni(total + n);
 				}
 			};
-#if RTX_TOS
-			// the item pushed last stays in SGPRs (tosValid); the ones below it are in LDS as before
-#define RTX_PUSH(lnk, fst, m)                                                                                                  \
-			{                                                                                                                  \
-				if (tosValid) { if (lane == 0) { WideItem ni; ni.link = tosLink; ni.first = tosFirst; ni.maskLo = (uint32_t)tosMask; ni.maskHi = (uint32_t)(tosMask >> 32); stack[sp] = ni; } sp = uni(sp + 1); } \
-				tosLink = (int32_t)(lnk); tosFirst = (fst); tosMask = (m); tosValid = true;                                         \
-			}
-			while ((tosValid || sp != 0) && batch < kLeafBatch) {
-				int32_t link; uint32_t itFirst; uint64_t itMask;
-				if (tosValid) { link = tosLink; itFirst = tosFirst; itMask = tosMask; tosValid = false; }
-				else {
-					sp = uni(sp - 1);
-					const WideItem it = stack[sp];
-					link = (int32_t)uni((uint32_t)it.link); itFirst = uni(it.first);
-					itMask = (uint64_t)uni(it.maskHi) << 32 | uni(it.maskLo);
-				}
-				const uint64_t inM = itMask & openM;
-#else
 #define RTX_PUSH(lnk, fst, m)                                                                                                  \
 			{                                                                                                                  \
 				if (lane == 0) { WideItem ni; ni.link = (int32_t)(lnk); ni.first = (fst); ni.maskLo = (uint32_t)(m); ni.maskHi = (uint32_t)((m) >> 32); stack[sp] = ni; } \
@@ -957,7 +925,6 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				const uint32_t itFirst = it.first;
 				const uint32_t mlo = uni(it.maskLo), mhi = uni(it.maskHi);
 				const uint64_t inM = ((uint64_t)mhi << 32 | mlo) & openM;
-#endif
 				if (link < 0) {
 					// a leaf, in the reference's order: note it with the rays that reached it and are still open
 					noteLeaf(link, itFirst, inM);
@@ -981,52 +948,9 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				uint32_t aliveM = 0xfu;
 				// (not at the root: the four slots two levels down are as good as never pruned -- 7 of 259 in tools/research/pruned_walk_sim.py)
 				const bool evalPrune = RTX_PRUNE && pruneRecs != nullptr && (RTX_PRUNE_ROOT || link != 1);
-#if RTX_SLOTS_FIRST
-				// The records are requested first (a vector fetch: the longest wait of a visit), the per-ray box tests of all four slots
-				// run on the node (scalar fetch, long since arrived) while they are in flight, and the records are evaluated last.
-				f4v r0 = { 0, 0, 0, 0 }, r1 = { 0, 0, 0, 0 };
-				if (evalPrune && (!RTX_PR8 || lane < 8u)) {
-					const RTX_AS1 f4v* pr = (const RTX_AS1 f4v*)(pruneRecs + ((((uint32_t)(link - 1) << 3) | (lane & 7u)) << 5));
-					r0 = pr[0]; r1 = pr[1];
-				}
-#define RTX_SLOTM(rec, base) ((int32_t)rec[base + 6] != 0 ? (ballot(!boxFailsRegular(F(rec[base]), F(rec[base + 1]), F(rec[base + 2]), F(rec[base + 3]), F(rec[base + 4]), F(rec[base + 5]), o, ix, iy, iz)) & inM) : 0ull)
-				const uint64_t sm0 = RTX_SLOTM(wa, 0), sm1 = RTX_SLOTM(wa, 8), sm2 = RTX_SLOTM(wb, 0), sm3 = RTX_SLOTM(wb, 8);
-#undef RTX_SLOTM
-				if (RTX_DBG) cnt.wS3 += ((int32_t)wa[6] != 0) + ((int32_t)wa[14] != 0) + ((int32_t)wb[6] != 0) + ((int32_t)wb[14] != 0);
-				if ((sm0 | sm1 | sm2 | sm3) == 0) continue;
-				if (evalPrune) {
-					bool a = false;
-					if (!RTX_PR8 || lane < 8u) {
-						const bool aliveBox = !BOXES || pruneAlive(r0, r1, pu, tmaxB);
-						const bool alivePlane = planeAlive(r0, r1, B, pu[15], tmaxB);
-						a = (lane & 4u) ? alivePlane : aliveBox;
-					}
-					const uint32_t bal = (uint32_t)ballot(a);
-					aliveM = bal & (bal >> 4) & 0xfu;
-					if (RTX_DBG) { cnt.wS4++; cnt.wLeafSkips += 4u - (uint32_t)__popc(aliveM); }
-				}
-				if (sm3 != 0 && (aliveM & 8u)) RTX_PUSH(wb[14], wb[15], sm3)
-				if (sm2 != 0 && (aliveM & 4u)) RTX_PUSH(wb[6], wb[7], sm2)
-				if (sm1 != 0 && (aliveM & 2u)) RTX_PUSH(wa[14], wa[15], sm1)
-				if (sm0 != 0 && (aliveM & 1u)) {
-					if ((int32_t)wa[6] < 0 && batch < kLeafBatch) noteLeaf((int32_t)wa[6], wa[7], sm0);
-					else RTX_PUSH(wa[6], wa[7], sm0)
-				}
-#else
 				if (evalPrune) {
 					// lanes 0..3: the slots' boxes (PruneRec), lanes 4..7: their planes (PlaneRec); both tests run on every lane's record
 					const RTX_AS1 f4v* pr = (const RTX_AS1 f4v*)(pruneRecs + ((((uint32_t)(link - 1) << 3) | (lane & 7u)) << 5));
-#if RTX_PR8
-					bool a = false;
-					if (lane < 8u) {
-						const f4v r0 = pr[0], r1 = pr[1];
-						const bool aliveBox = !BOXES || pruneAlive(r0, r1, pu, tmaxB);
-						const bool alivePlane = planeAlive(r0, r1, B, pu[15], tmaxB);
-						a = (lane & 4u) ? alivePlane : aliveBox;
-					}
-					const uint32_t bal = (uint32_t)ballot(a);
-					aliveM = bal & (bal >> 4) & 0xfu;
-#else
 					const f4v r0 = pr[0], r1 = pr[1];
 					const bool aliveBox = !BOXES || pruneAlive(r0, r1, pu, tmaxB);      // (BOXES: see the kernels' template parameter)
 #if RTX_PRUNE_PLANES
@@ -1035,7 +959,6 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 					aliveM = bal & (bal >> 4) & 0xfu;
 #else
 					aliveM = (uint32_t)ballot(aliveBox) & 0xfu;
-#endif
 #endif
 					if (RTX_DBG) { cnt.wS4++; cnt.wLeafSkips += 4u - (uint32_t)__popc(aliveM); }
 				}
@@ -1059,7 +982,6 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 					}
 				}
 #undef RTX_SLOT
-#endif
 #undef RTX_PUSH
 			}
 		}
@@ -1281,7 +1203,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 #if RTX_DBG
 		cnt.cExact += dbgExact; cnt.cFilter += __builtin_readcyclecounter() - dbgP2 - dbgExact;
 #endif
-		if (WIDE ? (sp == 0 && !tosValid) : i >= nN) break;
+		if (WIDE ? sp == 0 : i >= nN) break;
 	}
 }
 
