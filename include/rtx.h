@@ -179,9 +179,9 @@ int rtx_source_p_probe(const float* tris9, uint32_t n, const double* S3, double 
  * grid_w x grid_h cells.  out == NULL: only the dimensions.  Diagnostic (tools/cost_fit.py); no pixel depends on the estimate. */
 int rtx_cost_grid_read(rtx_scene* scene, uint32_t* out, size_t n, uint32_t* grid_w, uint32_t* grid_h);
 /* Experiment / test knobs of a live scene.  Their environment variables (RTX_STRIP_LIMIT, RTX_SSAA_HEAVY_TICKS,
- * RTX_SSAA_SPREAD_SLOTS, RTX_SPLIT_PERCENT, RTX_SSAA_LOCAL_BELOW, RTX_FRAME_QUEUE_CAP, RTX_DEBUG_ITEMS, ...) are read
+ * RTX_SSAA_SPREAD_SLOTS, RTX_SPLIT_PERCENT, RTX_SSAA_LOCAL_BELOW, RTX_SSAA_SPARSE_BELOW, RTX_FRAME_QUEUE_CAP, RTX_DEBUG_ITEMS, ...) are read
  * once, by rtx_scene_create; names here: strip_limit, ssaa_heavy_ticks, ssaa_spread_slots, split_percent,
- * ssaa_local_below, frame_queue_cap, debug_items.  No knob changes a pixel. */
+ * ssaa_local_below, ssaa_sparse_below, frame_queue_cap, debug_items.  No knob changes a pixel. */
 int rtx_set_knob(rtx_scene* scene, const char* name, double value);
 
 /* Sobel edge mask of Scene::launchSSAA (scene.cpp:547-568) for rows [row_begin,row_end); reads the

@@ -137,6 +137,25 @@ def test_ssaa_four_pixel_waves_and_slot_budget(ra, oracle, monkeypatch, spread_s
         assert ndiff(ref, got) == 0
 
 
+@pytest.mark.parametrize("sparse_below", ["0", "4000000000"])
+@pytest.mark.parametrize("heavy_ticks", ["1", "25000"])
+def test_ssaa_sparse_layout_bit_exact(ra, oracle, monkeypatch, sparse_below, heavy_ticks):
+    """The "sparse" layout of the tile-local SSAA list (rtxSsaaCountKernel: 4 pixels per wave for the tiles that were slow in pass 1, ONE
+    for the very slow ones, chosen when a launch has fewer 16-pixel items than half its waves) forced on and off, with every tile classified
+    as very slow (threshold of 1 tick: one-pixel waves everywhere) and with the product's threshold: the frame is the reference's."""
+    monkeypatch.setenv("RTX_SSAA_LOCAL_BELOW", "4000000000")
+    monkeypatch.setenv("RTX_SSAA_SPARSE_BELOW", sparse_below)
+    monkeypatch.setenv("RTX_SSAA_HEAVY_TICKS", heavy_ticks)
+    for name, w, h in (("cfg2_smooth_4k", 320, 240), ("cfg3_reflective_refractive", 240, 136)):
+        path = "scenes/%s.scene" % name
+        o = oracle.OracleScene(path, w, h)
+        g = ra.Scene(path, w, h)
+        ref = o.ssaa(o.pass1())
+        for _ in range(2):          # (the second frame knows the tile costs of the first)
+            got = g.render_host(ssaa=True)
+            assert ndiff(ref, got) == 0
+
+
 def test_event_pool_does_not_grow(ra):
     """Launch timing keeps one event pair per kernel unless rtx_kernel_time_reset asked for accumulation."""
     g = ra.Scene("scenes/cfg1_simple_shapes.scene", 64, 64)
