@@ -1520,7 +1520,7 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 	out->rays = c[0]; out->box_tests = c[1]; out->tri_tests = c[2]; out->moot_rays = c[15];
 	if (s->knobs.debugItems) fprintf(stderr, "[rtx] slowest work item %.3f ms, sum of items %.3f ms (100 MHz wall clock)\n", c[3] * 1e-5, c[4] * 1e-5);
 	if (s->knobs.debugItems) fprintf(stderr, "[rtx] wave-level: node visits %llu, reached leaves %llu, filter passes (64 references) %llu, of which rejected whole by stage 1 %llu, by stage 2 %llu; survivors tested exactly %llu; slots pruned by their records %llu, per-ray slot tests %llu, evaluations of prune records %llu\n", c[5], c[10], c[12], c[13], c[7], c[6], c[11], c[8], c[9]);
-#if RTX_DBG
+#if RTX_DBG || RTX_WAVE_TRACE
 	if (s->knobs.debugItems) {
 		std::vector<unsigned long long> w(3 * 16384);
 		HIPCHK(hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(gDbgWave), w.size() * 8));
@@ -1531,6 +1531,10 @@ int rtx_counters_read(rtx_scene* s, rtx_counters* out)
 			for (int i = 0; i < 16384; i++) if (w[3 * i]) { int b = (int)(10.0 * (double)(w[3 * i + 1] - t0) / (double)(t1 - t0 + 1)); hist[b < 0 ? 0 : b > 9 ? 9 : b]++; idleEnd += (double)(t1 - w[3 * i + 1]); idleStart += (double)(w[3 * i] - t0); }
 			fprintf(stderr, "[rtx] pass-1 waves %d: span %.3f ms, mean busy %.3f ms, mean idle before first tile %.3f ms, after last tile %.3f ms; waves ending in each tenth of the span:", n, (t1 - t0) * 1e-5, busy / n * 1e-5, idleStart / n * 1e-5, idleEnd / n * 1e-5);
 			for (int b = 0; b < 10; b++) fprintf(stderr, " %d", hist[b]);
+			fprintf(stderr, "\n");
+			// the end of the launch in twentieths of a millisecond before its last wave's last tile: how many waves are still busy
+			fprintf(stderr, "[rtx] waves still rendering x ms before the end:");
+			for (int k = 12; k >= 0; k--) { int m = 0; const double at = (double)t1 - k * 5000.0; for (int i = 0; i < 16384; i++) if (w[3 * i] && (double)w[3 * i + 1] > at) m++; fprintf(stderr, " %.2f:%d", k * 0.05, m); }
 			fprintf(stderr, "\n");
 		}
 	}

@@ -30,6 +30,9 @@
 
 using namespace rtxd;
 
+#ifndef RTX_WAVE_TRACE
+#define RTX_WAVE_TRACE 0      // 1: the per-wave timeline of pass 1 (first pop, end of the last tile, busy ticks) in a product build: tools/wave_tail.py
+#endif
 #ifndef RTX_BURN
 #define RTX_BURN 0         // (experiment: extra VALU instructions per node visit)
 #endif
@@ -384,9 +387,11 @@ __device__ __forceinline__ float attenuation(float intensity, float l2)
 // Render::trace for a whole wave (scene.cpp:724-756)
 // ------------------------------------------------------------------------------------------------
 struct Hit { int obj; float t; uint32_t tri; float u, v; };
+#if RTX_DBG || RTX_WAVE_TRACE
+__device__ unsigned long long gDbgWave[3 * 16384];   // per wave of the last pass 1: first pop, last tile end, busy ticks
+#endif
 #if RTX_DBG
 __device__ unsigned long long gDbgTimeline[3 * 8192 * 160];   // frame kernel: per wave up to 160 work items (start, duration, kind << 32 | item); start 0 = unused
-__device__ unsigned long long gDbgWave[3 * 16384];   // per wave of the last pass 1: first pop, last tile end, busy ticks
 __device__ unsigned long long gDbgHist[64];   // [0,8) certificate outcomes (one sampled lane per evaluation), [16,64) by log2(leaf size)
 #endif
 #if RTX_DBG >= 3      // per-block timers of the castRay state machine (their atomics disturb a full launch: use on small frames)
@@ -1886,7 +1891,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 	// any wave may render any tile).  The queues are explicit tile lists built by the host (rtx_api.hip,
 	// buildTileList): tiles that can see a mesh come first, so the tail of the launch consists of cheap tiles.
 	const uint32_t xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
-#if RTX_DBG
+#if RTX_DBG || RTX_WAVE_TRACE
 	const unsigned long long dbgStart = wall_clock64();
 	unsigned long long dbgEnd = dbgStart, dbgBusy = 0;
 #endif
@@ -1939,7 +1944,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 			const unsigned long long t0 = wall_clock64();
 			const V3 c = castRayWave<STATS, MESH, false, BOXES>(P, valid, o, d, gl, cnt);
 			const unsigned long long dt = wall_clock64() - t0;
-#if RTX_DBG
+#if RTX_DBG || RTX_WAVE_TRACE
 			dbgEnd = t0 + dt; dbgBusy += dt;
 #endif
 			if (lane == 0) {
@@ -1963,7 +1968,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 #endif
 		}
 	}
-#if RTX_DBG
+#if RTX_DBG || RTX_WAVE_TRACE
 	if (lane == 0 && (gl >> 6) < 16384) { gDbgWave[3 * (gl >> 6)] = dbgStart; gDbgWave[3 * (gl >> 6) + 1] = dbgEnd; gDbgWave[3 * (gl >> 6) + 2] = dbgBusy; }
 #endif
 	if (STATS || RTX_DBG) flushCounts(P, cnt);

@@ -1,0 +1,16 @@
+"""GPU box, build with -DRTX_WAVE_TRACE=1 (or RTX_DBG): how the waves of a pass 1 end -- the launch lasts as long as its last wave.
+RTX_DEBUG_ITEMS=1 python tools/wave_tail.py [scene W H]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import rendering_amd as RA
+scene = sys.argv[1] if len(sys.argv) > 1 else "scenes/cfg2_smooth_250k.scene"
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+g = RA.Scene(scene, W, H)
+fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+for _ in range(4):
+    g.render_pass1(fb)
+torch.cuda.synchronize()
+print("pass1 ms", g.last_kernel_ms(0))
+g.counters()
