@@ -446,7 +446,7 @@ def main():
     # The GPU has been idle while the host loaded that scene, and its clocks need a few milliseconds to come back: a second
     # fresh scene is timed (HIP events) directly behind three frames of the warm one -- what the first frame costs in software
     # (no measured tile costs: the estimate of rtx_scene_create orders and splits it; tools/cold_probe.py).
-    cold_ms = cold_busy_ms = None
+    cold_ms = cold_busy_ms = set_view_ms = None
     if world == 1:
         scene2 = RA.Scene(args.scene, W, H, device=local)
         scene2.gpu()
@@ -468,6 +468,14 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         cold_busy_ms = e0.elapsed_time(e1)
+        # what a NEW VIEW of a loaded scene costs before its first frame (rtx_scene_set_view runs the first-frame cost estimate, builds the
+        # tile lists and the camera's copy of the prune records and synchronises the device): wall clock of re-applying the view, outside every frame time above
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        scene3.resize(W, H)
+        scene3.gpu()
+        torch.cuda.synchronize()
+        set_view_ms = (time.perf_counter() - tv) * 1e3
         scene3.close()
         del fb3, mask3
     # The SURVEY 8d byte model (32 B per box test + 40 B per triangle test counted under REFERENCE traversal semantics
@@ -524,6 +532,7 @@ def main():
                    "frame_kernel_ms": round(ms4 / n4, 3) if n4 else None,
                    "cold_frame_ms": None if cold_ms is None else round(cold_ms, 3),
                    "cold_frame_gpu_busy_before_ms": None if cold_busy_ms is None else round(cold_busy_ms, 3),
+                   "set_view_ms": None if set_view_ms is None else round(set_view_ms, 3),
                    "pass1_rays_rank0": int(c1[0]), "ssaa_rays_rank0": int(c2[0]), "ssaa_pixels_rank0": int(mask.sum()),
                    "ssaa_box_tests": int(c2[1]), "ssaa_tri_tests": int(c2[2])},
         "roofline": roof,
