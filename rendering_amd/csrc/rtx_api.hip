@@ -108,7 +108,7 @@ struct Knobs {
 	float costPerRef = 2.5f, costPerLeaf = 110.0f, costBase = 8000.0f;   // estimate = base + perRef refs + perLeaf leaves (100 MHz ticks per tile; tools/cost_fit.py)
 	float fatFactor = 3.0f;              // RTX_FAT_FACTOR: bundle width, in mean triangle edges, above which a bundle is split; 0 = never
 	uint32_t stripLimit = 100000u;       // RTX_STRIP_LIMIT: a halo strip slower than this (100 MHz ticks) is listed as tiles again
-	uint32_t heavyTicks = 25000u;        // RTX_SSAA_HEAVY_TICKS: tiles above go first in the SSAA list
+	uint32_t heavyTicks = 18000u;        // RTX_SSAA_HEAVY_TICKS: tiles above go first in the SSAA list (x RTX_SSAA_VERY: 4-pixel waves).  0.25 ms until pass 1 got a quarter faster in round 4: headline SSAA 0.506 (25 000) / 0.475 (20 000) / 0.478 (15 000) / 0.642 (10 000) ms
 	uint32_t spreadSlots = 1u << 20;     // RTX_SSAA_SPREAD_SLOTS: slot budget of the 4-pixel SSAA waves
 	uint32_t splitPercent = 100;         // RTX_SPLIT_PERCENT: frame kernel, tile split limit in % of the even share; 0 = never
 	long long localBelow = -1;           // RTX_SSAA_LOCAL_BELOW: tile-local SSAA list below this many flagged pixels; -1 = by device size

@@ -57,7 +57,7 @@ using namespace rtxd;
 #define RTX_WAVES_FRAME 4  // rtxFrameKernel runs where the frame is bounded by its slowest work items: likewise
 #endif
 #ifndef RTX_SSAA_VERY
-#define RTX_SSAA_VERY 2u   // x 0.25 ms of pass-1 time: tiles above get 4-pixel SSAA waves
+#define RTX_SSAA_VERY 2u   // x the "heavy" threshold of pass-1 time (knob ssaa_heavy_ticks, 0.18 ms): tiles above get 4-pixel SSAA waves
 #endif
 #ifndef RTX_DBG
 #define RTX_DBG 0     // 1: wave-level stage counters + per-wave pass-1 timeline, 2: + sampled certificate outcomes / leaf-size histograms (slow) (RTX_DEBUG_ITEMS=1 prints them)
