@@ -105,7 +105,7 @@ struct Knobs {
 	bool sources = true;                 // RTX_NO_SRC: no source copies of the prune records (every walk uses copy 0)
 	int pruneBoxes = -1;                 // RTX_PRUNE_BOXES=0|1: the kernels without / with the box test whatever the triangle sizes (-1: by the meshes)
 	bool estimate = true;                // RTX_NO_COST_ESTIMATE: no first-frame cost estimate
-	float costPerRef = 2.5f, costPerLeaf = 110.0f, costBase = 8000.0f;   // estimate = base + perRef refs + perLeaf leaves (100 MHz ticks per tile; tools/cost_fit.py)
+	float costPerRef = 2.0f, costPerLeaf = 95.0f, costBase = 6100.0f;   // estimate = base + perRef refs + perLeaf leaves (100 MHz ticks per tile; tools/cost_fit.py on the final round-4 kernels: profiles/r04_cost_fit.txt)
 	float fatFactor = 3.0f;              // RTX_FAT_FACTOR: bundle width, in mean triangle edges, above which a bundle is split; 0 = never
 	uint32_t stripLimit = 100000u;       // RTX_STRIP_LIMIT: a halo strip slower than this (100 MHz ticks) is listed as tiles again
 	uint32_t heavyTicks = 18000u;        // RTX_SSAA_HEAVY_TICKS: tiles above go first in the SSAA list (x RTX_SSAA_VERY: 4-pixel waves).  0.25 ms until pass 1 got a quarter faster in round 4: headline SSAA 0.506 (25 000) / 0.475 (20 000) / 0.478 (15 000) / 0.642 (10 000) ms
