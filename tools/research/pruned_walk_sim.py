@@ -54,6 +54,9 @@ def main():
         if not is_leaf[i]:
             depth[i + 1] = depth[i] + 1; depth[skip[i + 1]] = depth[i] + 1
     hist_visit = np.zeros(40, int); hist_prune = np.zeros(40, int)
+    # round 4: nodes reached (some open ray passes their box) by binary depth, per mode -- the number of WIDE-node visits if g binary levels share a fetch is about the
+    # sum over the depths that are multiples of g (the kernel walks g = 2 today; DESIGN.md section 7.1 asks what g = 3 / 4 would save)
+    reached_by_depth = {}
     scale, aspect, M, pos = g.camera()
     M = M.reshape(4, 4)
     rng = np.random.default_rng(1)
@@ -156,6 +159,7 @@ def main():
                 nodes += 1
                 if not p.any():
                     continue
+                reached_by_depth.setdefault(mo, np.zeros(40, int))[depth[i]] += 1
                 if mo == "unc_plane":
                     hist_visit[depth[i]] += 1
                 if mo in ("plane", "both", "bothc", "bothc_ord", "unc_plane", "mix_plane") and plane_dead(o[open_], d[open_], best[open_].max(), i):
@@ -243,6 +247,8 @@ def main():
     print("unc_plane: by binary depth: tested / pruned:", [(int(a), int(b)) for a, b in zip(hist_visit, hist_prune)][:30])
     n = ntr[0]
     print("traces", n, "mismatching lanes vs today:", mism[0])
+    for mo, h in reached_by_depth.items():
+        print(mo, "nodes reached per trace at the depths that are multiples of g (~ wide-node visits with g levels per fetch): " + ", ".join("g=%d: %.1f" % (gg, h[::gg].sum() / n) for gg in (1, 2, 3, 4)))
     for mo in modes:
         print(mo, {k: round(v / n, 1) for k, v in tot[mo].items()})
 
