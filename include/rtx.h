@@ -162,12 +162,13 @@ int rtx_render_frame(rtx_scene* scene, uint32_t row_begin, uint32_t row_end, flo
 int rtx_frame_status(rtx_scene* scene, uint32_t* status);
 int rtx_frame_mode(rtx_scene* scene, int* mode, float* split_ms, float* fused_ms);
 int rtx_set_frame_mode(rtx_scene* scene, int mode); /* -1 measure and choose (default), 0 always three launches, 1 always one */
-/* Host only (no device is touched): what rtx_scene_create derives from a mesh before uploading it -- the tree with every other
- * level skipped (n_wide records of 128 bytes: four slots of {lo.x hi.x lo.y hi.y lo.z hi.z, link, first}; 0 when the boxes are
- * not nested) and the prune blocks of its slots (n_wide records of 256 bytes: four {c[3], P, h[3], Pgen} then four
+/* Host only (no device is touched): what rtx_scene_create derives from a mesh before uploading it -- the tree with S = rtx_wide_node_slots()
+ * descendants per node (log2 S binary levels per fetch; n_wide records of 32 S bytes: S slots of {lo.x hi.x lo.y hi.y lo.z hi.z, link,
+ * first}; 0 when the boxes are not nested) and the prune blocks of its slots (n_wide records of 64 S bytes: S {c[3], P, h[3], Pgen} then S
  * {qc[3], wlo, qr[3], whi}; rtx_device.h), plus the record of the whole mesh.  For the CPU tests of their
  * invariants (tests/test_host_cpu.py); cap_wide = records the output arrays hold. */
 int rtx_mesh_flatten_probe(const rtx_mesh* mesh, uint32_t* n_wide, void* wide_out, void* prune_out, uint32_t cap_wide, float* root_rec8);
+int rtx_wide_node_slots(void);      /* slots of a wide node in this build: 4 or 8 */
 /* Host only: the P of the source copies of the prune records (rtx_device.h PruneRec, csrc/rtx_source.hip sourceP)
  * for n triangles given as (v0, e1, e2) = 9 floats each, the source point S3, its radius sigma and cam != 0 when the rays start
  * at S (the camera) rather than pass through it (a point light).  The function the device kernels run, for the CPU tests of the

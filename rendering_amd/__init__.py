@@ -34,7 +34,7 @@ _host = None
 # every entry point declared in include/rtx.h
 RTX_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_set_view", "rtx_scene_bytes",
-    "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_render_frame", "rtx_frame_status", "rtx_frame_mode", "rtx_set_frame_mode", "rtx_set_knob", "rtx_cost_grid_read", "rtx_mesh_flatten_probe", "rtx_source_p_probe", "rtx_quantize_bgr8", "rtx_render_frame_host",
+    "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_render_frame", "rtx_frame_status", "rtx_frame_mode", "rtx_set_frame_mode", "rtx_set_knob", "rtx_cost_grid_read", "rtx_mesh_flatten_probe", "rtx_wide_node_slots", "rtx_source_p_probe", "rtx_quantize_bgr8", "rtx_render_frame_host",
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
     "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
     "rtx_bvh_build", "rtx_bvh_info", "rtx_bvh_read", "rtx_bvh_destroy",
@@ -238,7 +238,8 @@ class _RtxMesh(C.Structure):
 
 def mesh_flatten_probe(bvh):
     """Host only: the wide nodes and prune blocks rtx_scene_create derives from a mesh (rtx_mesh_flatten_probe).  bvh = Scene.bvh(obj).
-    Returns (wide [n, 4, 8] float32 -- link / first as bit patterns in [..., 6:8] --, box records [n, 4, 8], plane records [n, 4, 8], root record [8])."""
+    Returns (wide [n, S, 8] float32 -- link / first as bit patterns in [..., 6:8] --, box records [n, S, 8], plane records [n, S, 8], root record [8]);
+    S = rtx_wide_node_slots()."""
     rtx, _ = load()
     bounds = np.ascontiguousarray(bvh["bounds"], np.float32); skip = np.ascontiguousarray(bvh["skip"], np.int32)
     lb = np.ascontiguousarray(bvh["leaf_begin"], np.int32); lc = np.ascontiguousarray(bvh["leaf_count"], np.int32)
@@ -250,9 +251,10 @@ def mesh_flatten_probe(bvh):
     n = C.c_uint32(0)
     root = np.zeros(8, np.float32)
     _check(rtx.rtx_mesh_flatten_probe(C.byref(m), C.byref(n), None, None, 0, _np_ptr(root)), "rtx_mesh_flatten_probe")
-    wide = np.zeros((n.value, 4, 8), np.float32); prune = np.zeros((n.value, 8, 8), np.float32)
+    S = int(rtx.rtx_wide_node_slots())
+    wide = np.zeros((n.value, S, 8), np.float32); prune = np.zeros((n.value, 2 * S, 8), np.float32)
     _check(rtx.rtx_mesh_flatten_probe(C.byref(m), C.byref(n), _np_ptr(wide), _np_ptr(prune), n.value, _np_ptr(root)), "rtx_mesh_flatten_probe")
-    return wide, prune[:, 0:4], prune[:, 4:8], root
+    return wide, prune[:, 0:S], prune[:, S:2 * S], root
 
 
 def source_p_probe(v0, e1, e2, S, sigma, cam):

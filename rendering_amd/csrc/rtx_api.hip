@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <algorithm>
 #include <array>
+#include <functional>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -333,7 +334,7 @@ int buildSources(rtx_scene* s)
 			if (!(sigma >= 0.0) || !std::isfinite(sigma) || !std::isfinite((double)S[0] + S[1] + S[2])) return;      // no certificate: the copy stays generic
 			hipLaunchKernelGGL(rtxsrc::rtxSourceRefKernel, dim3((sm.nRefs + 255) / 256), dim3(256), 0, nullptr, sm.refA, sm.refB, sm.refC, sm.nRefs,
 			                   (double)S[0], (double)S[1], (double)S[2], sigma, cam ? 1 : 0, sm.refP, sm.blockP);
-			hipLaunchKernelGGL(rtxsrc::rtxSourceSlotKernel, dim3(sm.nWide), dim3(256), 0, nullptr, sm.slotRange, sm.nWide, (const float*)sm.refP, (const float*)sm.blockP, dst);
+			hipLaunchKernelGGL(rtxsrc::rtxSourceSlotKernel, dim3(sm.nWide * (kWideSlots / 4)), dim3(256), 0, nullptr, sm.slotRange, sm.nWide, (const float*)sm.refP, (const float*)sm.blockP, dst);
 			if (copy < 8 && std::isfinite(sm.rootPgen))      // the whole mesh's P for this source (the per-ray test before the walk: traceWave)
 				hipLaunchKernelGGL(rtxsrc::rtxSourceRootKernel, dim3(1), dim3(256), 0, nullptr, (const float*)sm.blockP, (sm.nRefs + 63) / 64, sm.rootPgen,
 				                   (float*)((char*)const_cast<Mesh*>(s->params.meshes + sm.meshIndex) + offsetof(Mesh, rootPS)) + copy);
@@ -457,8 +458,9 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 	PruneRec rootRec;
 	memset(&rootRec, 0, sizeof(rootRec));
 	rootRec.h[0] = rootRec.h[1] = rootRec.h[2] = INFINITY; rootRec.P = INFINITY;
-	std::vector<std::array<uint32_t, 4>> slotNode;      // binary node behind every wide-node slot
+	std::vector<std::array<uint32_t, kWideSlots>> slotNode;      // binary node behind every wide-node slot
 	constexpr uint32_t kNoNode = 0xffffffffu;
+	std::array<uint32_t, kWideSlots> noSlots; noSlots.fill(kNoNode);
 	if (boxesRegular && m.n_nodes > 0) {
 		bool nested = true;
 		uint32_t depthMax = 0;
@@ -473,27 +475,30 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 		struct Item { uint32_t node, wideIndex, depth; };
 		std::vector<Item> todo;
 		wide.emplace_back(); memset(&wide[0], 0, sizeof(WideNode));
-		slotNode.push_back({ { kNoNode, kNoNode, kNoNode, kNoNode } });
+		slotNode.push_back(noSlots);
 		if (isLeaf(0)) { wide[0].slot[0] = nodes[0]; slotNode[0][0] = 0; }
 		else todo.push_back({ 0u, 0u, 1u });
 		while (!todo.empty() && nested) {
 			const Item it = todo.back(); todo.pop_back();
 			depthMax = std::max(depthMax, it.depth);
-			uint32_t slots[4]; int ns = 0;
-			const uint32_t kids[2] = { it.node + 1, rightOf(it.node) };
-			for (uint32_t c : kids) {
-				if (c >= m.n_nodes || !inside(c, it.node)) { nested = false; break; }
-				if (isLeaf(c)) slots[ns++] = c;
-				else {
-					const uint32_t g[2] = { c + 1, rightOf(c) };
-					for (uint32_t gc : g) { if (gc >= m.n_nodes || !inside(gc, c)) { nested = false; break; } slots[ns++] = gc; }
+			// the slots: the descendants kWideLevels levels below the node, left to right (a leaf on the way takes a slot itself)
+			uint32_t slots[kWideSlots]; int ns = 0;
+			std::function<void(uint32_t, int)> gather = [&](uint32_t node, int levels) {
+				if (!nested) return;
+				const uint32_t kids[2] = { node + 1, rightOf(node) };
+				for (uint32_t c : kids) {
+					if (c >= m.n_nodes || !inside(c, node)) { nested = false; return; }
+					if (isLeaf(c) || levels == 1) slots[ns++] = c;
+					else gather(c, levels - 1);
+					if (!nested) return;
 				}
-			}
+			};
+			gather(it.node, kWideLevels);
 			if (!nested) break;
 			// children wide nodes are created in REVERSE so that the vector stays in pre-order when popped; indices are fixed here
-			uint32_t childWide[4] = { 0, 0, 0, 0 };
+			uint32_t childWide[kWideSlots] = { 0 };
 			for (int k = 0; k < ns; k++)
-				if (!isLeaf(slots[k])) { childWide[k] = (uint32_t)wide.size(); wide.emplace_back(); memset(&wide.back(), 0, sizeof(WideNode)); slotNode.push_back({ { kNoNode, kNoNode, kNoNode, kNoNode } }); }
+				if (!isLeaf(slots[k])) { childWide[k] = (uint32_t)wide.size(); wide.emplace_back(); memset(&wide.back(), 0, sizeof(WideNode)); slotNode.push_back(noSlots); }
 			for (int k = ns - 1; k >= 0; k--) {
 				slotNode[it.wideIndex][k] = slots[k];
 				Node sl = nodes[slots[k]];
@@ -501,8 +506,8 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 				wide[it.wideIndex].slot[k] = sl;
 			}
 		}
-		// the walk's stack holds at most 3 entries per wide level + 4
-		if (!nested || 3 * depthMax + 4 > 52) wide.clear();      // (wideStack holds 56 entries per wave)
+		// the walk's stack holds at most kWideSlots - 1 entries per wide level + 4
+		if (!nested || (kWideSlots - 1) * depthMax + 4 > kWideStackEntries - 4) wide.clear();      // (wideStack holds kWideStackEntries per wave)
 		if (!wide.empty() && pruneWanted) {
 			// Prune records (rtxd::PruneRec): per binary node the true box of the triangles its subtree references and the
 			// largest |e1|_1 |e2|_1 among them (bottom-up over the pre-order array), then one record per wide-node slot.
@@ -565,10 +570,10 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 			};
 			makeRec(agg[0], rootRec);
 			prune.resize(wide.size());
-			out.slotRange.assign(wide.size() * 8, 0u);
+			out.slotRange.assign(wide.size() * kWideSlots * 2, 0u);
 			for (int c = 0; c < 3; c++) vmaxMesh = std::max(vmaxMesh, (float)std::max(std::fabs(agg[0].lo[c]), std::fabs(agg[0].hi[c])));
 			for (size_t wi = 0; wi < wide.size(); wi++)
-				for (int k = 0; k < 4; k++) {
+				for (int k = 0; k < kWideSlots; k++) {
 					PruneRec& pr = prune[wi].box[k];
 					PlaneRec& pl = prune[wi].plane[k];
 					memset(&pr, 0, sizeof(pr)); memset(&pl, 0, sizeof(pl));
@@ -577,7 +582,7 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 					const uint32_t nd = slotNode[wi][k];
 					if (nd == kNoNode) continue;
 					const Agg& a = agg[nd];
-					if (a.rb < a.re) { out.slotRange[(wi * 4 + k) * 2] = a.rb; out.slotRange[(wi * 4 + k) * 2 + 1] = a.re; }
+					if (a.rb < a.re) { out.slotRange[(wi * kWideSlots + k) * 2] = a.rb; out.slotRange[(wi * kWideSlots + k) * 2 + 1] = a.re; }
 					makeRec(a, pr);
 					if (!(a.lo[0] <= a.hi[0]) || !std::isfinite(pr.P)) continue;
 					if (a.planes && a.wlo <= a.whi && std::isfinite(a.wlo) && std::isfinite(a.whi)) {
@@ -1643,6 +1648,8 @@ int rtx_source_p_probe(const float* tris9, uint32_t n, const double* S3, double 
 	for (uint32_t i = 0; i < n; i++) out[i] = rtxsrc::sourceP(tris9 + (size_t)i * 9, tris9 + (size_t)i * 9 + 3, tris9 + (size_t)i * 9 + 6, S3, sigma, cam != 0);
 	return RTX_OK;
 }
+
+int rtx_wide_node_slots(void) { return kWideSlots; }
 
 int rtx_mesh_flatten_probe(const rtx_mesh* m, uint32_t* n_wide, void* wide_out, void* prune_out, uint32_t cap_wide, float* root_rec8)
 {

@@ -24,8 +24,18 @@ static_assert(sizeof(Node) == 32, "node must be one s_load_dwordx8");
 // of the reference's tree.  Skipping the boxes of the levels in between is exact: every box lies inside its parent's, and
 // for nested boxes the slab products are monotone in the bounds, so a ray that passes a box passes every box around it --
 // a ray reaches a leaf (objects.cpp:587-631) iff it passes the leaf's OWN box (no NaN: see meshWalk).
-struct WideNode { Node slot[4]; };
-static_assert(sizeof(WideNode) == 128, "wide node = two s_load_dwordx16");
+// RTX_WIDE_LEVELS binary levels per wide node: 2 (four slots, rounds 2-4) or 3 (eight slots: the descendants three levels down -- the walk is a chain
+// of dependent fetches, one per wide level, and a third fewer levels is a third fewer visits; the slots are fetched four at a time).
+#ifndef RTX_WIDE_LEVELS
+#define RTX_WIDE_LEVELS 3
+#endif
+constexpr int kWideLevels = RTX_WIDE_LEVELS;
+constexpr int kWideSlots = 1 << kWideLevels;
+// entries of the walk's per-wave stack in LDS (meshWalk): at most kWideSlots - 1 per wide level + 4 -- rtx_scene_create checks a mesh's depth against it
+// (a deeper tree is walked in the binary form).  56 x 16 B x 4 waves left a block 1.4 KB short of its 32 KB at five blocks per CU; 76 use them.
+constexpr int kWideStackEntries = kWideSlots == 4 ? 56 : 76;
+struct WideNode { Node slot[kWideSlots]; };
+static_assert(sizeof(WideNode) == 32 * kWideSlots && (kWideSlots == 4 || kWideSlots == 8), "wide node = two s_load_dwordx16 per four slots");
 
 // Leaf references, duplicated per leaf in the reference's DFS-left-first order (objects.cpp:622-629): reference r of the
 // mesh (r = Node::first + position in the leaf) is one entry of three parallel arrays, so that LANE i of a wave reads
@@ -70,9 +80,9 @@ constexpr float kSrcAinfMax = 32.0f;         // the source certificate assumes |
 // the box (interval arithmetic): det / (s1 s2) = dir . q,  Nt / (s1 s2) = v0 . q - orig . q.   qr < 0: no usable bound.
 struct PlaneRec { float qc[3]; float wlo; float qr[3]; float whi; };
 static_assert(sizeof(PlaneRec) == 32, "plane record = two dwordx4");
-// per wide node: PruneRec[4] then PlaneRec[4] (slot order) = 256 bytes; lane k & 7 of a wave reads record k & 7
-struct PruneBlock { PruneRec box[4]; PlaneRec plane[4]; };
-static_assert(sizeof(PruneBlock) == 256, "prune block");
+// per wide node: PruneRec[kWideSlots] then PlaneRec[kWideSlots] (slot order) = 64 bytes per slot; lane k of the first 2 kWideSlots lanes of a wave reads record k
+struct PruneBlock { PruneRec box[kWideSlots]; PlaneRec plane[kWideSlots]; };
+static_assert(sizeof(PruneBlock) == 64 * kWideSlots, "prune block");
 
 struct Mesh {
 	const Node* nodes;

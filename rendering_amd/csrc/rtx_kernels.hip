@@ -700,7 +700,7 @@ __shared__ LeafEntry leafBatch[4][RTX_LEAF_BATCH_MAX];      // per wave of a 256
 // WIDE walk: pending subtrees / leaves of the wave, top of the stack = next in the reference's order.  link > 0: wide node
 // link - 1; link < 0: leaf with ~link references from `first`; mask = the rays that passed the item's own box.
 struct WideItem { int32_t link; uint32_t first, maskLo, maskHi; };
-__shared__ WideItem wideStack[4][RTX_POW_LDS ? 56 : 64];      // (3 entries per wide level + 4: rtx_scene_create checks the depth; 512 bytes went to powTab)
+__shared__ WideItem wideStack[4][kWideStackEntries];      // (kWideSlots - 1 entries per wide level + 4: rtx_scene_create checks the depth)
 // WIDE walk with prune records (rtxd::PruneRec): what the slot test needs from the wave's bundle, per wave, written once per
 // walk: [0..5] the range of 1 / dir over the rays per axis (lo, hi; mirrored so that it is positive), [6..11] the range of
 // the origins per axis in the same mirrored coordinates (lo, hi), [12] 216 dmax, [13] the largest |origin| coordinate,
@@ -979,42 +979,60 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				}
 #endif
 				const WideNode* w = wideNodes + (uint32_t)(link - 1);
-				const u32x16 wa = sload16(w), wb = sload16((const char*)w + 64);
-				// Which slots can contribute at all: lane k & 3 looks at slot k & 3 (bits 0..3 of the ballot are used).
-				uint32_t aliveM = 0xfu;
-				// (not at the root: the four slots two levels down are as good as never pruned -- 7 of 259 in tools/research/pruned_walk_sim.py)
+				// slots 3..0 are requested at once (their fetch runs while the prune records are evaluated); of slots 7..4 only the two lines, into the
+				// scalar cache (the SGPR file does not hold eight slots: see below)
+				u32x16 wa = sload16(w), wb = sload16((const char*)w + 64);
+				uint32_t touch0 = 0, touch1 = 0;
+				if (kWideSlots == 8) asm volatile("s_load_dword %0, %2, 0x80\n\ts_load_dword %1, %2, 0xc0" : "=s"(touch0), "=s"(touch1) : "s"(w));
+				// Which slots can contribute at all: of the first 2 kWideSlots lanes, lane k looks at record k (boxes, then planes: rtxd::PruneBlock).
+				uint32_t aliveM = (1u << kWideSlots) - 1u;
+				// (not at the root: its slots are as good as never pruned -- 7 of 259 in tools/research/pruned_walk_sim.py)
 				const bool evalPrune = RTX_PRUNE && pruneRecs != nullptr && (RTX_PRUNE_ROOT || link != 1);
 				if (evalPrune) {
-					// lanes 0..3: the slots' boxes (PruneRec), lanes 4..7: their planes (PlaneRec); both tests run on every lane's record
-					const RTX_AS1 f4v* pr = (const RTX_AS1 f4v*)(pruneRecs + ((((uint32_t)(link - 1) << 3) | (lane & 7u)) << 5));
+					// lanes [0, kWideSlots): the slots' boxes (PruneRec), [kWideSlots, 2 kWideSlots): their planes (PlaneRec); both tests run on every lane's record
+					const RTX_AS1 f4v* pr = (const RTX_AS1 f4v*)(pruneRecs + (((uint32_t)(link - 1) * (2u * kWideSlots) + (lane & (2u * kWideSlots - 1u))) << 5));
 					const f4v r0 = pr[0], r1 = pr[1];
 					const bool aliveBox = !BOXES || pruneAlive(r0, r1, pu, tmaxB);      // (BOXES: see the kernels' template parameter)
 #if RTX_PRUNE_PLANES
 					const bool alivePlane = planeAlive(r0, r1, B, pu[15], tmaxB);
-					const uint32_t bal = (uint32_t)ballot((lane & 4u) ? alivePlane : aliveBox);
-					aliveM = bal & (bal >> 4) & 0xfu;
+					const uint32_t bal = (uint32_t)ballot((lane & (uint32_t)kWideSlots) ? alivePlane : aliveBox);
+					aliveM = bal & (bal >> kWideSlots) & ((1u << kWideSlots) - 1u);
 #else
-					aliveM = (uint32_t)ballot(aliveBox) & 0xfu;
+					aliveM = (uint32_t)ballot(aliveBox) & ((1u << kWideSlots) - 1u);
 #endif
-					if (RTX_DBG) { cnt.wS4++; cnt.wLeafSkips += 4u - (uint32_t)__popc(aliveM); }
+					if (RTX_DBG) { cnt.wS4++; cnt.wLeafSkips += (uint32_t)kWideSlots - (uint32_t)__popc(aliveM); }
 				}
-				// slots 3..0, so that slot 0 ends up on top of the stack
+				// The node's slots four at a time (two s_load_dwordx16: the SGPR file holds no more), the last four first, slots 3..0 of every four in
+				// that order, so that slot 0 ends up on top of the stack; four slots none of which is alive are not fetched.
 #define RTX_SLOT(rec, base, k)                                                                                                     \
-				if ((int32_t)rec[base + 6] != 0 && ((aliveM >> k) & 1u)) {                                                           \
+				if ((int32_t)rec[base + 6] != 0 && ((aliveM >> (k)) & 1u)) {                                                         \
 					const bool fail = boxFailsRegular(F(rec[base]), F(rec[base + 1]), F(rec[base + 2]), F(rec[base + 3]), F(rec[base + 4]), F(rec[base + 5]), o, ix, iy, iz); \
 					const uint64_t mk_ = ballot(!fail) & inM;                                                                       \
 					if (RTX_DBG) cnt.wS3++;                                                                                         \
 					if (mk_ != 0) RTX_PUSH(rec[base + 6], rec[base + 7], mk_)                                                       \
 				}
-				RTX_SLOT(wb, 8, 3) RTX_SLOT(wb, 0, 2) RTX_SLOT(wa, 8, 1)
-				// slot 0 would be popped next: a leaf there is noted right away (no trip through the stack) while the batch has room
-				if ((int32_t)wa[6] != 0 && (aliveM & 1u)) {
-					const bool fail = boxFailsRegular(F(wa[0]), F(wa[1]), F(wa[2]), F(wa[3]), F(wa[4]), F(wa[5]), o, ix, iy, iz);
-					const uint64_t mk_ = ballot(!fail) & inM;
-					if (RTX_DBG) cnt.wS3++;
-					if (mk_ != 0) {
-						if ((int32_t)wa[6] < 0 && batch < kLeafBatch) noteLeaf((int32_t)wa[6], wa[7], mk_);
-						else RTX_PUSH(wa[6], wa[7], mk_)
+				// (the two touching loads write their registers when they land: the registers stay reserved until this wait -- by now long over)
+				if (kWideSlots == 8) asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(touch0), "s"(touch1));
+				if (kWideSlots == 8 && (aliveM >> 4) != 0) {
+					// slots 7..4 first (they are pushed first).  Their two lines were requested into the scalar cache when the node was popped; the
+					// registers of slots 3..0 are given up for them and loaded again afterwards (a hit in the scalar cache)
+					const u32x16 wc = sload16((const char*)w + 128), wd = sload16((const char*)w + 192);
+					RTX_SLOT(wd, 8, 7) RTX_SLOT(wd, 0, 6) RTX_SLOT(wc, 8, 5) RTX_SLOT(wc, 0, 4)
+					const char* w0 = (const char*)w;
+					asm volatile("" : "+s"(w0));      // (a fresh load, not the value from before kept in 32 more SGPRs)
+					wa = sload16(w0); wb = sload16(w0 + 64);
+				}
+				if ((aliveM & 0xfu) != 0) {
+					RTX_SLOT(wb, 8, 3) RTX_SLOT(wb, 0, 2) RTX_SLOT(wa, 8, 1)
+					// slot 0 would be popped next: a leaf there is noted right away (no trip through the stack) while the batch has room
+					if ((int32_t)wa[6] != 0 && (aliveM & 1u)) {
+						const bool fail = boxFailsRegular(F(wa[0]), F(wa[1]), F(wa[2]), F(wa[3]), F(wa[4]), F(wa[5]), o, ix, iy, iz);
+						const uint64_t mk_ = ballot(!fail) & inM;
+						if (RTX_DBG) cnt.wS3++;
+						if (mk_ != 0) {
+							if ((int32_t)wa[6] < 0 && batch < kLeafBatch) noteLeaf((int32_t)wa[6], wa[7], mk_);
+							else RTX_PUSH(wa[6], wa[7], mk_)
+						}
 					}
 				}
 #undef RTX_SLOT
@@ -1722,7 +1740,7 @@ __device__ __forceinline__ void primaryRay(const Params& P, float x, float y, V3
 #ifndef RTX_PARK_MORE
 #define RTX_PARK_MORE 1
 #endif
-constexpr int kParkFields = RTX_PARK_MORE ? 26 : 21;
+constexpr int kParkFields = RTX_PARK_MORE ? 25 : 21;      // (26 with nSpec until the eight-slot walk's stack needed the kilobyte: five blocks per CU hold 31 744 B each)
 __shared__ float parkedState[kParkFields][256];
 
 // The kernel's argument block, read afresh from the kernarg segment.  Every ray kernel takes `const Params P` as its only
@@ -1787,7 +1805,7 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 			parkedState[18][t] = s.I.x; parkedState[19][t] = s.I.y; parkedState[20][t] = s.I.z;
 			if (RTX_PARK_MORE) {
 				parkedState[21][t] = s.rd.x; parkedState[22][t] = s.rd.y; parkedState[23][t] = s.rd.z;
-				parkedState[24][t] = s.specCoef; parkedState[25][t] = s.nSpec;
+				parkedState[24][t] = s.specCoef;
 			}
 			asm volatile("" ::: "memory");
 		}
@@ -1804,7 +1822,7 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 			s.I = mk(parkedState[18][t], parkedState[19][t], parkedState[20][t]);
 			if (RTX_PARK_MORE) {
 				s.rd = mk(parkedState[21][t], parkedState[22][t], parkedState[23][t]);
-				s.specCoef = parkedState[24][t]; s.nSpec = parkedState[25][t];
+				s.specCoef = parkedState[24][t];
 			}
 		}
 #if RTX_DBG

@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) rtxSourceSlotKernel(const uint32_t* __res
                                                            rtxd::PruneBlock* __restrict__ copy)
 {
 	const uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-	if (slot >= nWide * 4) return;
+	if (slot >= nWide * rtxd::kWideSlots) return;
 	const uint32_t b = slotRange[2 * slot], e = slotRange[2 * slot + 1];
 	if (b >= e) return;
 	float mx = 0.0f;
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) rtxSourceSlotKernel(const uint32_t* __res
 	}
 	for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
 	if (lane == 0) {
-		rtxd::PruneRec& pr = copy[slot >> 2].box[slot & 3u];
+		rtxd::PruneRec& pr = copy[slot / rtxd::kWideSlots].box[slot % rtxd::kWideSlots];
 		const float pg = pr.Pgen;
 		if (pr.h[0] >= 0.0f && pg < __builtin_inff()) pr.P = mx < pg ? mx : pg;
 	}

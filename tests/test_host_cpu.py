@@ -176,13 +176,15 @@ def test_prune_records_enclose_what_they_stand_for(ra, scene, obj):
     """The prune blocks of the wide walk (rtx_mesh_flatten_probe, host only): for every slot of every wide node
     the box record encloses all vertices of all triangles referenced below it and P bounds their |e1|_1 |e2|_1, the plane
     record encloses their scaled normals and plane offsets; the records of a slot enclose those of the wide node below it;
-    the wide nodes hold exactly the reference's boxes (two levels apart) and reach every leaf reference once."""
+    the wide nodes hold exactly the reference's boxes (log2 S levels apart, S = rtx_wide_node_slots()) and reach every leaf reference once."""
     from rendering_amd import assets
     assets.ensure()
     g = ra.Scene(scene, 64, 48)
     b = g.bvh(obj)
     wide, box, plane, root = ra.mesh_flatten_probe(b)
     assert len(wide) > 0
+    S = wide.shape[1]
+    assert S in (4, 8)
     tris = b["tris"][:, 0:9].astype(np.float64)
     A, B, C_ = tris[:, 0:3], tris[:, 3:6], tris[:, 6:9]
     e1 = (tris[:, 3:6].astype(np.float32) - tris[:, 0:3].astype(np.float32)).astype(np.float64)      # the fp32 differences of the exact test
@@ -209,7 +211,7 @@ def test_prune_records_enclose_what_they_stand_for(ra, scene, obj):
             wv = (A[r][ok] * q).sum(1)
             span = (V.min(0), V.max(0), (s1[r] * s2[r]).max(), q.min(0) if len(q) else None, q.max(0) if len(q) else None, wv.min() if len(q) else None, wv.max() if len(q) else None)
         else:
-            parts = [p for p in (check_slot(l - 1, kk) for kk in range(4)) if p is not None]
+            parts = [p for p in (check_slot(l - 1, kk) for kk in range(S)) if p is not None]
             if not parts:
                 return None
             qs = [p for p in parts if p[3] is not None]
@@ -225,14 +227,14 @@ def test_prune_records_enclose_what_they_stand_for(ra, scene, obj):
             assert (np.abs(qc) + qr <= 1.0 + 1e-5).all()      # |q|_inf <= 1: what planeAlive's error terms assume
         return span
 
-    spans = [p for p in (check_slot(0, k) for k in range(4)) if p is not None]
+    spans = [p for p in (check_slot(0, k) for k in range(S)) if p is not None]
     assert (seen == 1).all(), "every leaf reference is reached through exactly one slot"
     lo = np.min([p[0] for p in spans], 0); hi = np.max([p[1] for p in spans], 0)
     assert (root[0:3] - root[4:7] <= lo).all() and (root[0:3] + root[4:7] >= hi).all() and root[3] >= max(p[2] for p in spans)
     # the slots are the reference's own boxes: every slot box is one of the node boxes of the binary tree
     nb = {tuple(x) for x in b["bounds"][:, [0, 3, 1, 4, 2, 5]].astype(np.float32).tolist()}
     for w in range(len(wide)):
-        for k in range(4):
+        for k in range(S):
             if link[w, k] != 0:
                 assert tuple(wide[w, k, 0:6].tolist()) in nb
 
