@@ -506,8 +506,10 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 				wide[it.wideIndex].slot[k] = sl;
 			}
 		}
-		// the walk's stack holds at most kWideSlots - 1 entries per wide level + 4
-		if (!nested || (kWideSlots - 1) * depthMax + 4 > kWideStackEntries - 4) wide.clear();      // (wideStack holds kWideStackEntries per wave)
+		// The walk's stack: while a node of wide level L is visited, every level above it has at most kWideSlots - 1 of its slots waiting and the node
+		// pushes at most kWideSlots -- (kWideSlots - 1) (L - 1) + kWideSlots entries.  A tree deeper than the stack allows is walked in the binary form
+		// (eight slots, 76 entries: ten wide levels = thirty binary ones; the 250 000-triangle mesh has 27).
+		if (!nested || (kWideSlots - 1) * depthMax + 1 > kWideStackEntries) wide.clear();      // (wideStack holds kWideStackEntries per wave)
 		if (!wide.empty() && pruneWanted) {
 			// Prune records (rtxd::PruneRec): per binary node the true box of the triangles its subtree references and the
 			// largest |e1|_1 |e2|_1 among them (bottom-up over the pre-order array), then one record per wide-node slot.

@@ -31,8 +31,9 @@ static_assert(sizeof(Node) == 32, "node must be one s_load_dwordx8");
 #endif
 constexpr int kWideLevels = RTX_WIDE_LEVELS;
 constexpr int kWideSlots = 1 << kWideLevels;
-// entries of the walk's per-wave stack in LDS (meshWalk): at most kWideSlots - 1 per wide level + 4 -- rtx_scene_create checks a mesh's depth against it
-// (a deeper tree is walked in the binary form).  56 x 16 B x 4 waves left a block 1.4 KB short of its 32 KB at five blocks per CU; 76 use them.
+// entries of the walk's per-wave stack in LDS (meshWalk): at most kWideSlots - 1 per wide level + 1 -- rtx_scene_create checks a mesh's depth against it
+// (a deeper tree is walked in the binary form).  Five blocks per CU hold 31 744 B of LDS each (the allocation granule): 76 entries x 16 B x 4 waves fit
+// beside 25 parked fields.
 constexpr int kWideStackEntries = kWideSlots == 4 ? 56 : 76;
 struct WideNode { Node slot[kWideSlots]; };
 static_assert(sizeof(WideNode) == 32 * kWideSlots && (kWideSlots == 4 || kWideSlots == 8), "wide node = two s_load_dwordx16 per four slots");

@@ -979,11 +979,8 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				}
 #endif
 				const WideNode* w = wideNodes + (uint32_t)(link - 1);
-				// slots 3..0 are requested at once (their fetch runs while the prune records are evaluated); of slots 7..4 only the two lines, into the
-				// scalar cache (the SGPR file does not hold eight slots: see below)
+				// slots 3..0 are requested at once (their fetch runs while the prune records are evaluated); the SGPR file does not hold eight slots: see below
 				u32x16 wa = sload16(w), wb = sload16((const char*)w + 64);
-				uint32_t touch0 = 0, touch1 = 0;
-				if (kWideSlots == 8) asm volatile("s_load_dword %0, %2, 0x80\n\ts_load_dword %1, %2, 0xc0" : "=s"(touch0), "=s"(touch1) : "s"(w));
 				// Which slots can contribute at all: of the first 2 kWideSlots lanes, lane k looks at record k (boxes, then planes: rtxd::PruneBlock).
 				uint32_t aliveM = (1u << kWideSlots) - 1u;
 				// (not at the root: its slots are as good as never pruned -- 7 of 259 in tools/research/pruned_walk_sim.py)
@@ -1011,11 +1008,9 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 					if (RTX_DBG) cnt.wS3++;                                                                                         \
 					if (mk_ != 0) RTX_PUSH(rec[base + 6], rec[base + 7], mk_)                                                       \
 				}
-				// (the two touching loads write their registers when they land: the registers stay reserved until this wait -- by now long over)
-				if (kWideSlots == 8) asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(touch0), "s"(touch1));
 				if (kWideSlots == 8 && (aliveM >> 4) != 0) {
-					// slots 7..4 first (they are pushed first).  Their two lines were requested into the scalar cache when the node was popped; the
-					// registers of slots 3..0 are given up for them and loaded again afterwards (a hit in the scalar cache)
+					// slots 7..4 first (they are pushed first): the registers of slots 3..0 are given up for them and loaded again afterwards (a hit in the
+					// scalar cache; touching the lines of slots 7..4 when the node is popped made no difference: profiles/r04_wide8.txt)
 					const u32x16 wc = sload16((const char*)w + 128), wd = sload16((const char*)w + 192);
 					RTX_SLOT(wd, 8, 7) RTX_SLOT(wd, 0, 6) RTX_SLOT(wc, 8, 5) RTX_SLOT(wc, 0, 4)
 					const char* w0 = (const char*)w;
