@@ -34,9 +34,9 @@ constexpr int kWideSlots = 1 << kWideLevels;
 // entries of the walk's per-wave stack in LDS (meshWalk): at most kWideSlots - 1 per wide level + 1 -- rtx_scene_create checks a mesh's depth against it
 // (a deeper tree is walked in the binary form).  Five blocks per CU hold 31 744 B of LDS each (the allocation granule): 76 entries x 16 B x 4 waves fit
 // beside 25 parked fields.
-constexpr int kWideStackEntries = kWideSlots == 4 ? 56 : 76;
+constexpr int kWideStackEntries = kWideSlots == 4 ? 56 : (kWideSlots == 8 ? 76 : 124);
 struct WideNode { Node slot[kWideSlots]; };
-static_assert(sizeof(WideNode) == 32 * kWideSlots && (kWideSlots == 4 || kWideSlots == 8), "wide node = two s_load_dwordx16 per four slots");
+static_assert(sizeof(WideNode) == 32 * kWideSlots && (kWideSlots == 4 || kWideSlots == 8 || kWideSlots == 16), "wide node = two s_load_dwordx16 per four slots");
 
 // Leaf references, duplicated per leaf in the reference's DFS-left-first order (objects.cpp:622-629): reference r of the
 // mesh (r = Node::first + position in the leaf) is one entry of three parallel arrays, so that LANE i of a wave reads

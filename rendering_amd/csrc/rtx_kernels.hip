@@ -1008,11 +1008,15 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 					if (RTX_DBG) cnt.wS3++;                                                                                         \
 					if (mk_ != 0) RTX_PUSH(rec[base + 6], rec[base + 7], mk_)                                                       \
 				}
-				if (kWideSlots == 8 && (aliveM >> 4) != 0) {
-					// slots 7..4 first (they are pushed first): the registers of slots 3..0 are given up for them and loaded again afterwards (a hit in the
-					// scalar cache; touching the lines of slots 7..4 when the node is popped made no difference: profiles/r04_wide8.txt)
-					const u32x16 wc = sload16((const char*)w + 128), wd = sload16((const char*)w + 192);
-					RTX_SLOT(wd, 8, 7) RTX_SLOT(wd, 0, 6) RTX_SLOT(wc, 8, 5) RTX_SLOT(wc, 0, 4)
+				if (kWideSlots > 4 && (aliveM >> 4) != 0) {
+					// the upper slots first, four at a time from the top (they are pushed first): the registers of slots 3..0 are given up for them and loaded
+					// again afterwards (a hit in the scalar cache; touching the lines of the upper slots when the node is popped made no difference: profiles/r04_wide8.txt)
+#pragma unroll
+					for (int q4 = kWideSlots / 4 - 1; q4 >= 1; --q4) {
+						if (((aliveM >> (4 * q4)) & 0xfu) == 0) continue;
+						const u32x16 wc = sload16((const char*)w + 128 * q4), wd = sload16((const char*)w + 128 * q4 + 64);
+						RTX_SLOT(wd, 8, 4 * q4 + 3) RTX_SLOT(wd, 0, 4 * q4 + 2) RTX_SLOT(wc, 8, 4 * q4 + 1) RTX_SLOT(wc, 0, 4 * q4)
+					}
 					const char* w0 = (const char*)w;
 					asm volatile("" : "+s"(w0));      // (a fresh load, not the value from before kept in 32 more SGPRs)
 					wa = sload16(w0); wb = sload16(w0 + 64);
@@ -1735,7 +1739,9 @@ __device__ __forceinline__ void primaryRay(const Params& P, float x, float y, V3
 #ifndef RTX_PARK_MORE
 #define RTX_PARK_MORE 1
 #endif
-constexpr int kParkFields = RTX_PARK_MORE ? 25 : 21;      // (26 with nSpec until the eight-slot walk's stack needed the kilobyte: five blocks per CU hold 31 744 B each)
+constexpr bool kParkColor = kWideSlots < 16;      // (sixteen-slot nodes: the stack takes the 3 KB of objColor's three fields)
+constexpr int kParkFields = (RTX_PARK_MORE ? 25 : 21) - (kParkColor ? 0 : 3);
+constexpr int kPk = kParkColor ? 0 : -3;          // index shift of the fields behind objColor      // (26 with nSpec until the eight-slot walk's stack needed the kilobyte: five blocks per CU hold 31 744 B each)
 __shared__ float parkedState[kParkFields][256];
 
 // The kernel's argument block, read afresh from the kernarg segment.  Every ray kernel takes `const Params P` as its only
@@ -1793,14 +1799,14 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 			const uint32_t t = threadIdx.x;
 			parkedState[0][t] = s.P.x; parkedState[1][t] = s.P.y; parkedState[2][t] = s.P.z;
 			parkedState[3][t] = s.N.x; parkedState[4][t] = s.N.y; parkedState[5][t] = s.N.z;
-			parkedState[6][t] = s.objColor.x; parkedState[7][t] = s.objColor.y; parkedState[8][t] = s.objColor.z;
-			parkedState[9][t] = s.diff.x; parkedState[10][t] = s.diff.y; parkedState[11][t] = s.diff.z;
-			parkedState[12][t] = s.spec.x; parkedState[13][t] = s.spec.y; parkedState[14][t] = s.spec.z;
-			parkedState[15][t] = s.L.x; parkedState[16][t] = s.L.y; parkedState[17][t] = s.L.z;
-			parkedState[18][t] = s.I.x; parkedState[19][t] = s.I.y; parkedState[20][t] = s.I.z;
+			if (kParkColor) { parkedState[6][t] = s.objColor.x; parkedState[7][t] = s.objColor.y; parkedState[8][t] = s.objColor.z; }
+			parkedState[9 + kPk][t] = s.diff.x; parkedState[10 + kPk][t] = s.diff.y; parkedState[11 + kPk][t] = s.diff.z;
+			parkedState[12 + kPk][t] = s.spec.x; parkedState[13 + kPk][t] = s.spec.y; parkedState[14 + kPk][t] = s.spec.z;
+			parkedState[15 + kPk][t] = s.L.x; parkedState[16 + kPk][t] = s.L.y; parkedState[17 + kPk][t] = s.L.z;
+			parkedState[18 + kPk][t] = s.I.x; parkedState[19 + kPk][t] = s.I.y; parkedState[20 + kPk][t] = s.I.z;
 			if (RTX_PARK_MORE) {
-				parkedState[21][t] = s.rd.x; parkedState[22][t] = s.rd.y; parkedState[23][t] = s.rd.z;
-				parkedState[24][t] = s.specCoef;
+				parkedState[21 + kPk][t] = s.rd.x; parkedState[22 + kPk][t] = s.rd.y; parkedState[23 + kPk][t] = s.rd.z;
+				parkedState[24 + kPk][t] = s.specCoef;
 			}
 			asm volatile("" ::: "memory");
 		}
@@ -1810,14 +1816,14 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 			const uint32_t t = threadIdx.x;
 			s.P = mk(parkedState[0][t], parkedState[1][t], parkedState[2][t]);
 			s.N = mk(parkedState[3][t], parkedState[4][t], parkedState[5][t]);
-			s.objColor = mk(parkedState[6][t], parkedState[7][t], parkedState[8][t]);
-			s.diff = mk(parkedState[9][t], parkedState[10][t], parkedState[11][t]);
-			s.spec = mk(parkedState[12][t], parkedState[13][t], parkedState[14][t]);
-			s.L = mk(parkedState[15][t], parkedState[16][t], parkedState[17][t]);
-			s.I = mk(parkedState[18][t], parkedState[19][t], parkedState[20][t]);
+			if (kParkColor) s.objColor = mk(parkedState[6][t], parkedState[7][t], parkedState[8][t]);
+			s.diff = mk(parkedState[9 + kPk][t], parkedState[10 + kPk][t], parkedState[11 + kPk][t]);
+			s.spec = mk(parkedState[12 + kPk][t], parkedState[13 + kPk][t], parkedState[14 + kPk][t]);
+			s.L = mk(parkedState[15 + kPk][t], parkedState[16 + kPk][t], parkedState[17 + kPk][t]);
+			s.I = mk(parkedState[18 + kPk][t], parkedState[19 + kPk][t], parkedState[20 + kPk][t]);
 			if (RTX_PARK_MORE) {
-				s.rd = mk(parkedState[21][t], parkedState[22][t], parkedState[23][t]);
-				s.specCoef = parkedState[24][t];
+				s.rd = mk(parkedState[21 + kPk][t], parkedState[22 + kPk][t], parkedState[23 + kPk][t]);
+				s.specCoef = parkedState[24 + kPk][t];
 			}
 		}
 #if RTX_DBG
