@@ -713,7 +713,7 @@ __shared__ float pruneUni[4][24];      // ([16..18] the sign bits that mirror a 
 #define RTX_PRUNE_RAYS 0      // per ray: the segment against the mesh's own PruneRec before the walk (measured: -1 %, the walk's first visit does it as well)
 #endif
 #ifndef RTX_PRUNE_ROOT
-#define RTX_PRUNE_ROOT 0      // 1: the prune records of the root's slots are evaluated too
+#define RTX_PRUNE_ROOT (RTX_WIDE_LEVELS >= 3)      // the prune records of the root's slots are evaluated too: +-0 with four slots (two levels down: as good as never pruned), -1.6 % with eight
 #endif
 #ifndef RTX_SRC
 #define RTX_SRC 1             // source copies of the prune records (rtxd::PruneRec): 0 = every walk uses copy 0
@@ -983,7 +983,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				u32x16 wa = sload16(w), wb = sload16((const char*)w + 64);
 				// Which slots can contribute at all: of the first 2 kWideSlots lanes, lane k looks at record k (boxes, then planes: rtxd::PruneBlock).
 				uint32_t aliveM = (1u << kWideSlots) - 1u;
-				// (not at the root: its slots are as good as never pruned -- 7 of 259 in tools/research/pruned_walk_sim.py)
+				// (four slots: not at the root, where they are as good as never pruned -- 7 of 259 in tools/research/pruned_walk_sim.py; eight: everywhere)
 				const bool evalPrune = RTX_PRUNE && pruneRecs != nullptr && (RTX_PRUNE_ROOT || link != 1);
 				if (evalPrune) {
 					// lanes [0, kWideSlots): the slots' boxes (PruneRec), [kWideSlots, 2 kWideSlots): their planes (PlaneRec); both tests run on every lane's record
