@@ -54,6 +54,7 @@ def main():
         if not is_leaf[i]:
             depth[i + 1] = depth[i] + 1; depth[skip[i + 1]] = depth[i] + 1
     hist_visit = np.zeros(40, int); hist_prune = np.zeros(40, int)
+    chunk_stat = [0, 0, 0, 0]      # chunks of 64 references in reached leaves, of which a chunk record would prune; the same for leaves of more than one chunk
     # round 4: nodes reached (some open ray passes their box) by binary depth, per mode -- the number of WIDE-node visits if g binary levels share a fetch is about the
     # sum over the depths that are multiples of g (the kernel walks g = 2 today; DESIGN.md section 7.1 asks what g = 3 / 4 would save)
     reached_by_depth = {}
@@ -186,6 +187,34 @@ def main():
                         continue
                     leaves += 1; nrefs += lcnt[i]; passes += (lcnt[i] + 63) // 64
                     r = refs[lbeg[i]:lbeg[i] + lcnt[i]]
+                    if mo == "mix_plane":
+                        # round 4: would a prune record per 64-reference CHUNK of the leaf skip the pass?  (same two tests as for a slot, the chunk's own aggregates)
+                        oo, dd = o[open_], d[open_]
+                        o6, d6 = oo.astype(np.float64), dd.astype(np.float64)
+                        tm = best[open_].max()
+                        for c0 in range(0, len(r), 64):
+                            rc = r[c0:c0 + 64]
+                            chunk_stat[0] += 1
+                            if len(r) > 64:
+                                chunk_stat[2] += 1
+                            cq_lo, cq_hi = q[rc].min(0), q[rc].max(0); cw_lo, cw_hi = w[rc].min(), w[rc].max()
+                            ct_lo, ct_hi = tlo_t[rc].min(0), thi_t[rc].max(0)
+                            dlo, dhi = d6.min(0), d6.max(0); olo, ohi = o6.min(0), o6.max(0)
+                            dmax = max(np.abs(dlo).max(), np.abs(dhi).max())
+                            def ival(xlo, xhi):
+                                cc = np.stack([xlo * cq_lo, xlo * cq_hi, xhi * cq_lo, xhi * cq_hi])
+                                return cc.min(0).sum(), cc.max(0).sum()
+                            dq_lo, dq_hi = ival(dlo, dhi); oq_lo, oq_hi = ival(olo, ohi)
+                            ainf = np.maximum(np.abs(olo - ct_lo), np.abs(ohi - ct_hi)).max() * 1.01
+                            dead = dq_hi + Kf * dmax < 0 or (cw_hi - oq_lo) + Kf * ainf < 0 or (tm < 1e30 and (cw_lo - oq_hi) - Kf * ainf >= tm * (dq_hi + Kf * dmax) * (1 + 2.0 ** -18))
+                            if not dead:
+                                ainf2 = np.maximum(np.abs(olo - ct_hi), np.abs(ohi - ct_lo)).max()
+                                rho = 212.0 * 1.05 * dmax * ainf2 * float(os.environ.get("CHUNK_PS", "1e-3")) * ps_t[rc].max() / max(ps_t[rc].max(), 1e-30) + 2.0 ** -18 * (np.abs(o6).max() + max(np.abs(ct_lo).max(), np.abs(ct_hi).max()))
+                                dead = not seg_box_rho(o6, (1.0 / d6), np.full(len(o6), tm), ct_lo, ct_hi, np.full(len(o6), rho)).any()
+                            if dead:
+                                chunk_stat[1] += 1
+                                if len(r) > 64:
+                                    chunk_stat[3] += 1
                     reach = np.zeros(len(o), bool); reach[np.nonzero(open_)[0][p]] = True
                     ok, t = mt_exact(o, d, A[r].astype(f32), E1[r].astype(f32), E2[r].astype(f32))
                     ok &= reach[:, None]
@@ -247,6 +276,8 @@ def main():
     print("unc_plane: by binary depth: tested / pruned:", [(int(a), int(b)) for a, b in zip(hist_visit, hist_prune)][:30])
     n = ntr[0]
     print("traces", n, "mismatching lanes vs today:", mism[0])
+    print("mix_plane: chunks of 64 references in reached leaves %d, a record per chunk would prune %d (%.0f %%); in leaves of more than one chunk: %d, pruned %d (%.0f %%)  [margin: rho with P = CHUNK_PS = %s]" % (
+        chunk_stat[0], chunk_stat[1], 100.0 * chunk_stat[1] / max(chunk_stat[0], 1), chunk_stat[2], chunk_stat[3], 100.0 * chunk_stat[3] / max(chunk_stat[2], 1), os.environ.get("CHUNK_PS", "1e-3")))
     for mo, h in reached_by_depth.items():
         print(mo, "nodes reached per trace at the depths that are multiples of g (~ wide-node visits with g levels per fetch): " + ", ".join("g=%d: %.1f" % (gg, h[::gg].sum() / n) for gg in (1, 2, 3, 4)))
     for mo in modes:
