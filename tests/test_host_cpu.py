@@ -248,3 +248,24 @@ def test_flatten_rejects_a_right_child_outside_the_array(ra):
                refs=np.array([0], np.uint32), tris=np.zeros((1, 30), np.float32))
     with pytest.raises(ra.RtxError):
         ra.mesh_flatten_probe(bvh)
+
+
+@pytest.mark.parametrize("depth,wide_expected", [(12, True), (29, True), (45, False)])
+def test_a_tree_deeper_than_the_walks_stack_takes_the_binary_form(ra, depth, wide_expected):
+    """The wide walk's stack in LDS holds kWideSlots - 1 entries per wide level + 1 (rtx_device.h: 76 entries for eight slots = ten wide levels = thirty
+    binary ones); flattenMesh must not hand out wide nodes for a deeper tree (rtx_scene_create then walks it in the binary form).  A chain: every inner
+    node has a leaf as its first child and the rest of the tree as its second."""
+    n = 2 * depth + 1                                   # inner nodes at 0, 2, 4, ...; leaves at 1, 3, ... and the last node
+    leaf_count = np.full(n, -1, np.int32); leaf_count[1::2] = 1; leaf_count[n - 1] = 1
+    skip = np.zeros(n, np.int32); skip[leaf_count < 0] = n
+    leaves = np.nonzero(leaf_count >= 0)[0]
+    leaf_begin = np.zeros(n, np.int32); leaf_begin[leaves] = np.arange(len(leaves))
+    tris = np.zeros((len(leaves), 30), np.float32)
+    tris[:, 0:9] = np.array([0.1, 0.1, 0.1, 0.9, 0.1, 0.1, 0.1, 0.9, 0.1], np.float32)
+    bvh = dict(bounds=np.tile(np.array([0, 0, 0, 1, 1, 1], np.float32), (n, 1)), skip=skip, leaf_begin=leaf_begin, leaf_count=leaf_count,
+               refs=np.arange(len(leaves), dtype=np.uint32), tris=tris)
+    wide, box, plane, root = ra.mesh_flatten_probe(bvh)
+    assert (len(wide) > 0) == wide_expected
+    if wide_expected:
+        link = wide[..., 6].view(np.int32)
+        assert (link < 0).sum() == len(leaves)          # every leaf sits in exactly one slot
