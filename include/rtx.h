@@ -160,30 +160,6 @@ int rtx_render_pass1(rtx_scene* scene, uint32_t row_begin, uint32_t row_end, flo
  * which = 3 in rtx_last_kernel_ms / rtx_kernel_time_stats: the frame, either way; 4: the single launch's kernel alone. */
 int rtx_render_frame(rtx_scene* scene, uint32_t row_begin, uint32_t row_end, float* fb_dev, uint8_t* mask_dev, void* stream);
 int rtx_frame_status(rtx_scene* scene, uint32_t* status);
-int rtx_frame_mode(rtx_scene* scene, int* mode, float* split_ms, float* fused_ms);
-int rtx_set_frame_mode(rtx_scene* scene, int mode); /* -1 measure and choose (default), 0 always three launches, 1 always one */
-/* Host only (no device is touched): what rtx_scene_create derives from a mesh before uploading it -- the tree with S = rtx_wide_node_slots()
- * descendants per node (log2 S binary levels per fetch; n_wide records of 32 S bytes: S slots of {lo.x hi.x lo.y hi.y lo.z hi.z, link,
- * first}; 0 when the boxes are not nested) and the prune blocks of its slots (n_wide records of 64 S bytes: S {c[3], P, h[3], Pgen} then S
- * {qc[3], wlo, qr[3], whi}; rtx_device.h), plus the record of the whole mesh.  For the CPU tests of their
- * invariants (tests/test_host_cpu.py); cap_wide = records the output arrays hold. */
-int rtx_mesh_flatten_probe(const rtx_mesh* mesh, uint32_t* n_wide, void* wide_out, void* prune_out, uint32_t cap_wide, float* root_rec8);
-int rtx_wide_node_slots(void);      /* slots of a wide node in this build: 4 or 8 */
-/* Host only: the P of the source copies of the prune records (rtx_device.h PruneRec, csrc/rtx_source.hip sourceP)
- * for n triangles given as (v0, e1, e2) = 9 floats each, the source point S3, its radius sigma and cam != 0 when the rays start
- * at S (the camera) rather than pass through it (a point light).  The function the device kernels run, for the CPU tests of the
- * bound (tests/test_prune_bound_cpu.py). */
-int rtx_source_p_probe(const float* tris9, uint32_t n, const double* S3, double sigma, int cam, float* out);
-/* First-frame cost estimate (rtx_scene_create / rtx_scene_set_view project every leaf box of the meshes through the camera;
- * the reference renders one frame per process, main.cpp:15, so there is no previous frame to learn the tile costs from):
- * per cell of 2 x 2 tiles (16 x 16 pixels) the references and the leaves whose boxes cover it, interleaved (refs, leaves),
- * grid_w x grid_h cells.  out == NULL: only the dimensions.  Diagnostic (tools/cost_fit.py); no pixel depends on the estimate. */
-int rtx_cost_grid_read(rtx_scene* scene, uint32_t* out, size_t n, uint32_t* grid_w, uint32_t* grid_h);
-/* Experiment / test knobs of a live scene.  Their environment variables (RTX_STRIP_LIMIT, RTX_SSAA_HEAVY_TICKS,
- * RTX_SSAA_SPREAD_SLOTS, RTX_SPLIT_PERCENT, RTX_SSAA_LOCAL_BELOW, RTX_SSAA_SPARSE_BELOW, RTX_FRAME_QUEUE_CAP, RTX_DEBUG_ITEMS, ...) are read
- * once, by rtx_scene_create; names here: strip_limit, ssaa_heavy_ticks, ssaa_spread_slots, split_percent,
- * ssaa_local_below, ssaa_sparse_below, frame_queue_cap, debug_items.  No knob changes a pixel. */
-int rtx_set_knob(rtx_scene* scene, const char* name, double value);
 
 /* Sobel edge mask of Scene::launchSSAA (scene.cpp:547-568) for rows [row_begin,row_end); reads the
  * 3x3 neighbourhood from fb_dev; border entries (row 0, H-1, column 0, W-1) are written as 0. */
@@ -215,8 +191,6 @@ int rtx_counters_read(rtx_scene* scene, rtx_counters* out); /* synchronises the 
  * rtx_kernel_time_stats: number of launches and their summed duration since rtx_kernel_time_reset
  * (synchronises on the recorded events; call it after the timed region). */
 int rtx_last_kernel_ms(rtx_scene* scene, int which, float* ms);
-int rtx_kernel_time_reset(rtx_scene* scene);
-int rtx_kernel_time_stats(rtx_scene* scene, int which, uint32_t* launches, double* total_ms);
 
 /* Acceleration-structure build on the device.  Replaces Mesh::loadModel's
  * `ac = make_unique<AccelerationStructure>(...); ac->setup(...)` (objects.cpp:385-392) and the recursive builder
@@ -231,12 +205,6 @@ int rtx_bvh_build(const float* tri_pos, uint32_t n_tris, const float* root_lo, c
 int rtx_bvh_info(const rtx_bvh* bvh, uint32_t* n_nodes, uint32_t* n_refs, uint32_t* max_depth, float* build_ms);
 int rtx_bvh_read(const rtx_bvh* bvh, float* node_bounds, int32_t* node_skip, int32_t* leaf_begin, int32_t* leaf_count, uint32_t* refs);
 void rtx_bvh_destroy(rtx_bvh* bvh);
-
-/* Per-tile cost of the most recent rtx_render_pass1 (profiling aid; also what orders the SSAA work list):
- * out[ty * ceil(width/8) + tx] = wall-clock ticks (100 MHz) one wave spent on the 8x8 pixel tile (tx, ty).
- * n must be ceil(width/8) * ceil(height/8) -- or twice that: the second half then holds, per tile, the slowest SSAA
- * work item of the most recent rtx_render_ssaa (ticks, scaled to a 16-pixel item).  Synchronises the device. */
-int rtx_tile_cost_read(rtx_scene* scene, uint32_t* out, size_t n);
 
 /* Pixel sharding across the GPUs of a node: bands of band_height rows are dealt round-robin
  * to n_parts devices; this device renders / masks / re-renders only rows y with (y / band_height) % n_parts
@@ -279,16 +247,6 @@ int rtx_gather_plan(uint32_t height, uint32_t band_height, uint32_t n_parts, siz
  * hits: n x 8 floats = [hit 0/1, object index, triangle index (-1 unless mesh), tNear, u, v, 0, 0];
  * colours: n x 3.  Used by the per-ray parity tests. */
 int rtx_cast_rays(rtx_scene* scene, uint32_t n, const float* rays_host, float* hits_host, float* colours_host);
-
-/* Self-check of the device math the parity contract depends on: evaluates powf / normalize / division /
- * sqrt on `n` inputs on the device so tests can compare with the host.  op: 0 powf(x,y), 1 1/x,
- * 2 sqrtf(x), 3 (float)(1/sqrt((double)x)), 4 x/y. */
-int rtx_math_probe(int device, int op, uint32_t n, const float* x, const float* y, float* out);
-
-/* The shading path's vector helpers on the device, n inputs at a time (host buffers, n x 3 floats; unit tests against the
- * reference's vectors).  op: 0 Render::reflect(a, b) (scene.cpp:672-675), 1 Render::refract(a, b, ior) (677-696),
- * 2 Render::fresnel(a, b, ior) in out[3 i] (698-722), 3 Vec3::normalize(a) (geometry.h:104-112; b may be NULL). */
-int rtx_vec_probe(int device, int op, uint32_t n, const float* a, const float* b, float ior, float* out);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ class Counters(C.Structure):
 _rtx = None
 _host = None
 
-# every entry point declared in include/rtx.h
+# every entry point declared in include/rtx.h (the boundary) and include/rtx_debug.h (probes, diagnostics, tuning hooks)
 RTX_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_set_view", "rtx_scene_bytes",
     "rtx_render_pass1", "rtx_sobel", "rtx_render_ssaa", "rtx_render_frame", "rtx_frame_status", "rtx_frame_mode", "rtx_set_frame_mode", "rtx_set_knob", "rtx_cost_grid_read", "rtx_mesh_flatten_probe", "rtx_wide_node_slots", "rtx_source_p_probe", "rtx_quantize_bgr8", "rtx_render_frame_host",

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/rtx.h"
+#include "../../include/rtx_debug.h"
 #include "rtx_device.h"
 
 using namespace rtxd;
@@ -115,6 +116,8 @@ struct Knobs {
 	long long localBelow = -1;           // RTX_SSAA_LOCAL_BELOW: tile-local SSAA list below this many flagged pixels; -1 = by device size
 	long long sparseBelow = -1;          // RTX_SSAA_SPARSE_BELOW: one-step-finer SSAA items below this many flagged pixels (rtxSsaaCountKernel); -1 = by device size, 0 = never
 	int frameMode = -1;                  // RTX_FRAME_MODE=split|fused
+	uint32_t frameRuleTiles = 65536u, frameRuleTilesAnalytic = 8192u;   // knobs frame_rule_tiles / frame_rule_tiles_analytic: frames with more listed tiles take three launches
+	                                     // without probing (measured on one MI355X: rtx_render_frame); 0xffffffff = always measure
 	uint32_t frameQueueCap = 0;          // RTX_FRAME_QUEUE_CAP: entries per SSAA item queue of the frame kernel; 0 = sized from the frame
 	bool debugItems = false;             // RTX_DEBUG_ITEMS: rtx_counters_read prints the wave-level counters
 	uint32_t dbgTile = 0;                // RTX_DBG_TILE=tx,ty (RTX_DBG builds): only this tile
@@ -175,7 +178,7 @@ struct rtx_scene {
 	// source copies of the prune records (rtxd::PruneRec, rtx_source.hip): per mesh the copies' base, the reference arrays and the
 	// slots' reference ranges; the point lights that have a copy; what the copies were last built for
 	struct SrcMesh { PruneBlock* base = nullptr; uint32_t nWide = 0, nRefs = 0; const RefA* refA = nullptr; const RefB* refB = nullptr; const RefC* refC = nullptr;
-	                 const uint32_t* slotRange = nullptr; float* refP = nullptr; float* blockP = nullptr; float vmax = 0; uint32_t meshIndex = 0; float rootPgen = 0; };
+	                 const uint32_t* slotRange = nullptr; float* refP = nullptr; float* blockP = nullptr; float vmax = 0; uint32_t meshIndex = 0; };
 	std::vector<SrcMesh> srcMeshes;
 	std::vector<std::array<float, 3>> srcLightPos;      // [l]: position of light l (point lights only count below nSrcLights)
 	std::vector<uint8_t> srcLightIsPoint;
@@ -183,7 +186,7 @@ struct rtx_scene {
 	float srcBuiltBias = -1.0f; bool srcLightsBuilt = false;
 	float srcBuiltCam[3] = { 0, 0, 0 }; bool srcCamBuilt = false;
 	// rtx_render_frame: event pairs around the last few frames, read back (without waiting) by later calls
-	struct FrameProbe { hipEvent_t a = nullptr, b = nullptr; int mode = -1; size_t queue = 0; uint32_t generation = 0; bool pending = false; };
+	struct FrameProbe { hipEvent_t a = nullptr, b = nullptr; int mode = -1; size_t queue = 0; uint32_t generation = 0; bool pending = false, refresh = false; };
 	FrameProbe probes[8];
 	unsigned probeNext = 0;
 	int lastFrameMode = -1, frameModeForced = -1;
@@ -202,9 +205,14 @@ struct rtx_scene {
 
 namespace {
 
+// The product ignores RTX_* environment variables: a stray RTX_NO_PRUNE / RTX_FRAME_MODE in a caller's environment must not change what
+// is launched.  RTX_ALLOW_ENV_KNOBS=1 (the A/B tools under tools/) lets them through; tests use rtx_set_knob (include/rtx_debug.h).
 void readKnobs(Knobs& k)
 {
-	auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? strtoll(e, nullptr, 10) : dflt; };
+	const char* allow = ::getenv("RTX_ALLOW_ENV_KNOBS");
+	if (!(allow && allow[0] == '1')) return;
+	auto getenv = [](const char* name) { return ::getenv(name); };
+	auto num = [](const char* name, long long dflt) { const char* e = ::getenv(name); return e ? strtoll(e, nullptr, 10) : dflt; };
 	k.pass1BlocksPerCU = (int)num("RTX_PASS1_BLOCKS_PER_CU", 0); k.ssaaBlocksPerCU = (int)num("RTX_SSAA_BLOCKS_PER_CU", 0); k.frameBlocksPerCU = (int)num("RTX_FRAME_BLOCKS_PER_CU", 0);
 	k.prune = !getenv("RTX_NO_PRUNE");
 	k.sources = !getenv("RTX_NO_SRC");
@@ -325,19 +333,17 @@ int buildSources(rtx_scene* s)
 	if (!any) return RTX_OK;
 	HIPCHK(hipDeviceSynchronize());      // (a launch may still be reading the copies)
 	const uint32_t nLights = std::min<uint32_t>((uint32_t)s->srcLightPos.size(), kMaxSrcLights);
+	bool failed = false;      // (a copy that could not be reset must not be marked as built: it may hold an older camera's P)
 	for (const auto& sm : s->srcMeshes) {
 		if (!sm.base) continue;
 		auto build = [&](uint32_t copy, const float* S, double sigma, bool cam) {
 			PruneBlock* dst = sm.base + (size_t)copy * sm.nWide;
 			// (back to copy 0 first: a slot the kernel leaves alone must not keep the P of an earlier camera)
-			(void)hipMemcpyAsync(dst, sm.base, (size_t)sm.nWide * sizeof(PruneBlock), hipMemcpyDeviceToDevice, nullptr);
+			if (hipMemcpyAsync(dst, sm.base, (size_t)sm.nWide * sizeof(PruneBlock), hipMemcpyDeviceToDevice, nullptr) != hipSuccess) { failed = true; return; }
 			if (!(sigma >= 0.0) || !std::isfinite(sigma) || !std::isfinite((double)S[0] + S[1] + S[2])) return;      // no certificate: the copy stays generic
 			hipLaunchKernelGGL(rtxsrc::rtxSourceRefKernel, dim3((sm.nRefs + 255) / 256), dim3(256), 0, nullptr, sm.refA, sm.refB, sm.refC, sm.nRefs,
 			                   (double)S[0], (double)S[1], (double)S[2], sigma, cam ? 1 : 0, sm.refP, sm.blockP);
 			hipLaunchKernelGGL(rtxsrc::rtxSourceSlotKernel, dim3(sm.nWide * (kWideSlots / 4)), dim3(256), 0, nullptr, sm.slotRange, sm.nWide, (const float*)sm.refP, (const float*)sm.blockP, dst);
-			if (copy < 8 && std::isfinite(sm.rootPgen))      // the whole mesh's P for this source (the per-ray test before the walk: traceWave)
-				hipLaunchKernelGGL(rtxsrc::rtxSourceRootKernel, dim3(1), dim3(256), 0, nullptr, (const float*)sm.blockP, (sm.nRefs + 63) / 64, sm.rootPgen,
-				                   (float*)((char*)const_cast<Mesh*>(s->params.meshes + sm.meshIndex) + offsetof(Mesh, rootPS)) + copy);
 		};
 		if (!camSame) build(1, v.camPos, 0.0, true);
 		if (!lightsSame)
@@ -355,6 +361,7 @@ int buildSources(rtx_scene* s)
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipDeviceSynchronize());
+	if (failed) { s->srcCamBuilt = false; s->srcLightsBuilt = false; return fail(RTX_ERR_DEVICE, "buildSources: a source copy of the prune records could not be reset"); }
 	memcpy(s->srcBuiltCam, v.camPos, 12); s->srcCamBuilt = true;
 	s->srcBuiltBias = v.bias; s->srcLightsBuilt = true;
 	return RTX_OK;
@@ -707,13 +714,12 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		}
 		dm.vmax = vmaxMesh;
 		dm.rootRec = rootRec;
-		for (int k = 0; k < 8; k++) dm.rootPS[k] = rootRec.P;
 		if (!(vmaxMesh < 0x1p40f)) { dm.prune = nullptr; dm.rootRec.h[0] = dm.rootRec.h[1] = dm.rootRec.h[2] = INFINITY; }      // (huge or non-finite coordinates: nothing is pruned)
 		if ((rc = upload(s->owned, refA.data(), refA.size(), &dm.refA))) return bail(rc);
 		if ((rc = upload(s->owned, refB.data(), refB.size(), &dm.refB))) return bail(rc);
 		if ((rc = upload(s->owned, refC.data(), refC.size(), &dm.refC))) return bail(rc);
 		if (sm.base && vmaxMesh < 0x1p40f && m.n_refs) {
-			sm.nRefs = m.n_refs; sm.refA = dm.refA; sm.refB = dm.refB; sm.refC = dm.refC; sm.vmax = vmaxMesh; sm.meshIndex = mi; sm.rootPgen = rootRec.P;
+			sm.nRefs = m.n_refs; sm.refA = dm.refA; sm.refB = dm.refB; sm.refC = dm.refC; sm.vmax = vmaxMesh; sm.meshIndex = mi;
 			if ((rc = upload(s->owned, flat.slotRange.data(), flat.slotRange.size(), &sm.slotRange))) return bail(rc);
 			if (hipMalloc((void**)&sm.refP, ((size_t)m.n_refs + m.n_refs / 64 + 2) * sizeof(float)) != hipSuccess) return bail(fail(RTX_ERR_DEVICE, "hipMalloc (source scratch)"));
 			s->owned.push_back(sm.refP);
@@ -820,6 +826,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 	if ((rc = upload(s->owned, lights.data(), lights.size(), &s->params.lights))) return bail(rc);
 	s->params.nObjects = desc->n_objects; s->params.nLights = desc->n_lights;
 	s->params.nSrcLights = s->knobs.sources ? std::min<uint32_t>(desc->n_lights, kMaxSrcLights) : 0u;
+	s->params.srcNmax2 = s->srcNmax * s->srcNmax * 1.00001f;      // (srcNmax is final here: every object has been looked at)
 	if (desc->sky_w && desc->sky_h && desc->sky[0]) {
 		const float* faces[6];
 		for (int k = 0; k < 6; k++) {
@@ -1246,7 +1253,8 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 		{
 			// (the best of the samples: the first frame of either way carries one-off work -- buffers, the first ordered list)
 			rtx_scene::TileQueues& q = s->tileQueues[pr.queue];
-			q.frameMs[pr.mode] = q.frameSamples[pr.mode] ? std::min(q.frameMs[pr.mode], ms) : ms;
+			// a re-probe REPLACES what was known (a view's costs shift during a sequence: an old loss must not pin the choice for ever)
+			q.frameMs[pr.mode] = (q.frameSamples[pr.mode] && !pr.refresh) ? std::min(q.frameMs[pr.mode], ms) : ms;
 			q.frameSamples[pr.mode]++;
 		}
 	}
@@ -1254,26 +1262,29 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	int mode;
 	const int forced = s->frameModeForced >= 0 ? s->frameModeForced : s->knobs.frameMode;
 	const bool warm = tq && tq->costValid;
+	const uint32_t ruleTiles = s->analytic ? s->knobs.frameRuleTilesAnalytic : s->knobs.frameRuleTiles;
+	bool reprobe = false;
 	if (forced >= 0) mode = forced;
 	else if (!tq || tq->fusedGaveUp) mode = 0;
 	// By rule, not by measurement, where the single launch has never won: frames of more than 65 536 listed tiles
 	// (8 192 without meshes) are throughput-bound over cheap tiles -- 4096^2: 4.5 ms in one launch against 4.0 in three, 8192^2 18.1
 	// against 15.2 -- and probing there cost the headline two slow frames at the start and one in every 64.
-	else if (tq->listed > (s->analytic ? 8192u : 65536u)) mode = 0;
+	else if (tq->listed > ruleTiles) mode = 0;
 	// no measured costs yet: by size -- the single launch where the frame is bounded by its slowest tiles; without meshes (cheap,
 	// even tiles: cfg3 at 1080p 2.0 ms in one launch, 1.1 in three) only for small frames
-	else if (!warm) mode = tq->listed <= (s->analytic ? 8192u : 65536u) ? 1 : 0;
+	else if (!warm) mode = tq->listed <= ruleTiles ? 1 : 0;
 	// not measured twice each yet: in turn
 	else if (tq->frameSamples[0] < 2 || tq->frameSamples[1] < 2) mode = (int)(tq->framesSeen & 1u);
 	else {
 		mode = tq->frameMs[1] <= tq->frameMs[0] ? 1 : 0;
-		// (the other way is tried again every 64 frames -- unless it lost by more than a fifth)
+		// (the other way is tried again every 64 frames -- every 1024 when it lost by more than a fifth)
 		const float lo = std::min(tq->frameMs[0], tq->frameMs[1]), hi = std::max(tq->frameMs[0], tq->frameMs[1]);
-		if ((tq->framesSeen & 63u) == 63u && hi <= 1.2f * lo) mode ^= 1;
+		if (((tq->framesSeen & 63u) == 63u && hi <= 1.2f * lo) || (tq->framesSeen & 1023u) == 1023u) { mode ^= 1; reprobe = true; }
+		else if ((tq->framesSeen & 63u) == 62u) reprobe = true;      // (the frame before: the current way's time is refreshed as well)
 	}
 	// The frame is bracketed by its own pair of events only while the choice is being made or re-examined (the frame that
 	// tries the other way every 64 frames and the one before it): an event costs the queue ~5 us.
-	const bool byRule = tq && tq->listed > (s->analytic ? 8192u : 65536u);
+	const bool byRule = tq && tq->listed > ruleTiles;
 	const bool probing = forced < 0 && tq && !byRule && (!warm || tq->frameSamples[0] < 2 || tq->frameSamples[1] < 2 || (tq->framesSeen & 63u) >= 62u);
 	rtx_scene::FrameProbe* pr = nullptr;
 	if (probing) {
@@ -1295,7 +1306,7 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	if (pr) {
 		HIPCHK(hipEventRecord(pr->b, st));
 		// (a cold frame is not a sample: it is slower either way)
-		pr->mode = warm ? mode : -1; pr->queue = (size_t)(tq - s->tileQueues.data()); pr->generation = tq->generation; pr->pending = true;
+		pr->mode = warm ? mode : -1; pr->queue = (size_t)(tq - s->tileQueues.data()); pr->generation = tq->generation; pr->pending = true; pr->refresh = reprobe;
 	}
 	if (tq) tq->framesSeen++;
 	if (tq) tq->costValid = true;      // (either way the tile costs of this view are now known)
@@ -1316,6 +1327,8 @@ int rtx_set_knob(rtx_scene* s, const char* name, double value)
 	else if (n == "ssaa_local_below") k.localBelow = (long long)value;
 	else if (n == "ssaa_sparse_below") k.sparseBelow = (long long)value;
 	else if (n == "frame_queue_cap") k.frameQueueCap = (uint32_t)value;
+	else if (n == "frame_rule_tiles") k.frameRuleTiles = value >= 4294967295.0 ? 0xffffffffu : (uint32_t)value;
+	else if (n == "frame_rule_tiles_analytic") k.frameRuleTilesAnalytic = value >= 4294967295.0 ? 0xffffffffu : (uint32_t)value;
 	else if (n == "debug_items") k.debugItems = value != 0;
 	else return fail(RTX_ERR_ARG, "unknown knob: " + n);
 	return RTX_OK;

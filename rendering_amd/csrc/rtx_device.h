@@ -105,8 +105,7 @@ struct Mesh {
 	uint32_t nWide, padw;
 	const PruneBlock* prune;   // one per wide node, or null
 	float vmax, padv;          // largest |vertex coordinate| of the mesh
-	PruneRec rootRec;          // the PruneRec of the whole mesh (h = +inf: none): a ray whose segment misses it takes no part in the walk
-	float rootPS[8];           // its P per source (rtxd::PruneRec: [0] = Pgen, [1] the camera's, [2 + l] point light l's; buildSources)
+	PruneRec rootRec;          // the PruneRec of the whole mesh (h = +inf: none); rtx_scene_create decides from its P whether the box test can prune at all (Object::pruneBoxes)
 	// bundle splitting (rtx_kernels.hip, traceWave): a wave's rays are walked as ONE bundle unless the bundle is wider than
 	// fatRadius at this mesh (a few mean triangle edges); centre / radius = bounding sphere of the root box
 	float fatRadius, centre[3], radius;
@@ -190,7 +189,7 @@ struct Params {
 	float* probeHits;
 	float* probeColours;
 	uint32_t nProbe;
-	uint32_t pad1;
+	float srcNmax2;                 // (1 + 1e-5) x the square of the longest shading normal the source copies of the point lights were built for (rtx_api.hip, buildSources: sigma ~ |N| bias)
 	unsigned long long* counters;   // rays, boxTests, triTests
 	// whole frame in one launch (rtxFrameKernel): per-tile dependency counters, the SSAA item queue
 	uint32_t* tileReady;            // [tile] pass-1 completions seen among the listed tiles of the tile's 3x3 neighbourhood

@@ -25,62 +25,24 @@
 #include <stdint.h>
 
 #include "rtx_device.h"
+#include "rtx_tuning.h"
 
 #pragma clang fp contract(off)
 
 using namespace rtxd;
 
-#ifndef RTX_WAVE_TRACE
-#define RTX_WAVE_TRACE 0      // 1: the per-wave timeline of pass 1 (first pop, end of the last tile, busy ticks) in a product build: tools/wave_tail.py
-#endif
-#ifndef RTX_BURN
-#define RTX_BURN 0         // (experiment: extra VALU instructions per node visit)
-#endif
-#ifndef RTX_POP_MANY
-#define RTX_POP_MANY 4     // pass 1: tiles taken per atomic in the cheap half of a queue (0: one everywhere).  Headline pass 1 3.366 -> 3.271 ms, cfg5 11.70 -> 11.38;
-                           // 8 or 16 per atomic, and helpings that shrink towards the end of the queue, lost to 4 at 4096^2 (profiles/r04_ab_pop.txt)
-#endif
-#ifndef RTX_POP_NUM
-#define RTX_POP_NUM 1u     // ... from this fraction of the queue on
-#define RTX_POP_DEN 2u
-#endif
-#ifndef RTX_POP_NOPRIO
-#define RTX_POP_NOPRIO 1   // ... and there no look at the tile's previous cost for the wave priority (one dependent load less per tile)
-#endif
-#ifndef RTX_FB_STORE
-#define RTX_FB_STORE 1     // pass 1: 1 = plain framebuffer stores; 0 / 2: the write-traffic experiments of profiles/r04_write_traffic.txt
-#endif
-#ifndef RTX_WAVES_SSAA
-#define RTX_WAVES_SSAA 4   // the SSAA launch lasts as long as its slowest wave: fewer, barely spilled waves (128 VGPRs)
-#endif
-#ifndef RTX_WAVES_FRAME
-#define RTX_WAVES_FRAME 4  // rtxFrameKernel runs where the frame is bounded by its slowest work items: likewise
-#endif
-#ifndef RTX_SSAA_VERY
-#define RTX_SSAA_VERY 2u   // x the "heavy" threshold of pass-1 time (knob ssaa_heavy_ticks, 0.18 ms): tiles above get 4-pixel SSAA waves
-#endif
-#ifndef RTX_DBG
-#define RTX_DBG 0     // 1: wave-level stage counters + per-wave pass-1 timeline, 2: + sampled certificate outcomes / leaf-size histograms (slow) (RTX_DEBUG_ITEMS=1 prints them)
-#endif
-#ifndef RTX_WAVES_ANALYTIC
-#define RTX_WAVES_ANALYTIC 4   // scenes without meshes: the whole castRay state in registers (128 VGPRs)
-#endif
-#ifndef RTX_WAVES
-#define RTX_WAVES 5   // target waves per SIMD of the pass-1 kernel (register budget = 512 / RTX_WAVES VGPRs): 6 (80 VGPRs, 240 B of
-                      // scratch per lane) is as fast at 4096^2 and 3-5 % slower on the other configurations
-#endif
+// the cheap half of a pass-1 queue (tiles from this fraction of the queue on) is popped RTX_POP_MANY tiles per atomic
+constexpr uint32_t kPopNum = 1u, kPopDen = 2u;
 
 namespace {
 
-#ifndef RTX_RAY_MAJOR
-#define RTX_RAY_MAJOR 1       // exact tests one step per ray where the rays are fewer than the surviving triangles (kernels whose work items can be parts of tiles)
+// diagnostics that exist only in the instrumented build (RTX_DBG, rtx_tuning.h)
+#if RTX_DBG
+#define RTX_DBG_ONLY(...) __VA_ARGS__
+#else
+#define RTX_DBG_ONLY(...)
 #endif
-#ifndef RTX_TRI_BPERMUTE
-#define RTX_TRI_BPERMUTE 1
-#endif
-#ifndef RTX_RO_EXACT
-#define RTX_RO_EXACT 1        // bundle filter: the origin box weighted by |dc x e| per axis instead of dmax |e|_1 (bundleRejects2)
-#endif
+
 #define RTX_AS4 __attribute__((address_space(4)))
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -200,17 +162,12 @@ __device__ const uint64_t kExp2Tab[32] = {
 // DEPENDENT (the exp2 entry's index comes out of the logarithm) -- from global memory two round trips of a microsecond or two in
 // every Phong / mirror / glass shading step, the longest part of a trace round of a scene of spheres (RTX_DBG=3: 12 000 of a
 // round's 17 000 cycles).
-#ifndef RTX_POW_LDS
-#define RTX_POW_LDS 1
-#endif
 __shared__ unsigned long long powTab[64];      // [0, 32): kLog2Tab as bits, [32, 64): kExp2Tab
 __device__ __forceinline__ void fillPowTab()
 {
-#if RTX_POW_LDS
 	if (threadIdx.x < 32) powTab[threadIdx.x] = (unsigned long long)__double_as_longlong(kLog2Tab[threadIdx.x]);
 	else if (threadIdx.x < 64) powTab[threadIdx.x] = kExp2Tab[threadIdx.x - 32];
 	__syncthreads();
-#endif
 }
 
 __device__ __forceinline__ int powfCheckInt(uint32_t iy)
@@ -259,11 +216,7 @@ __device__ __noinline__ float powfRef(float x, float y)
 	uint32_t top = tmp & 0xff800000;
 	uint32_t iz = ix - top;
 	int k = (int32_t)top >> 23;
-#if RTX_POW_LDS
 	double invc = __longlong_as_double((long long)powTab[2 * i]), logc = __longlong_as_double((long long)powTab[2 * i + 1]);
-#else
-	double invc = kLog2Tab[2 * i], logc = kLog2Tab[2 * i + 1];
-#endif
 	double z = (double)__uint_as_float(iz);
 	double r = __builtin_fma(z, invc, -1.0);
 	double y0 = logc + (double)k;
@@ -284,11 +237,7 @@ __device__ __noinline__ float powfRef(float x, float y)
 	uint64_t ki = (uint64_t)__double_as_longlong(kd);
 	kd -= 0x1.8p+47;
 	double rr = ylogx - kd;
-#if RTX_POW_LDS
 	uint64_t t = powTab[32 + ki % 32];
-#else
-	uint64_t t = kExp2Tab[ki % 32];
-#endif
 	t += (ki + signBias) << (52 - 5);
 	double s = __longlong_as_double((long long)t);
 	double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
@@ -387,13 +336,11 @@ __device__ __forceinline__ float attenuation(float intensity, float l2)
 // Render::trace for a whole wave (scene.cpp:724-756)
 // ------------------------------------------------------------------------------------------------
 struct Hit { int obj; float t; uint32_t tri; float u, v; };
-#if RTX_DBG || RTX_WAVE_TRACE
-__device__ unsigned long long gDbgWave[3 * 16384];   // per wave of the last pass 1: first pop, last tile end, busy ticks
-#endif
-#if RTX_DBG
+RTX_DBG_ONLY(__device__ unsigned long long gDbgWave[3 * 16384];)   // per wave of the last pass 1: first pop, last tile end, busy ticks
+RTX_DBG_ONLY(
 __device__ unsigned long long gDbgTimeline[3 * 8192 * 160];   // frame kernel: per wave up to 160 work items (start, duration, kind << 32 | item); start 0 = unused
 __device__ unsigned long long gDbgHist[64];   // [0,8) certificate outcomes (one sampled lane per evaluation), [16,64) by log2(leaf size)
-#endif
+)
 #if RTX_DBG >= 3      // per-block timers of the castRay state machine (their atomics disturb a full launch: use on small frames)
 #define RTX_T0 const unsigned long long dbgB0 = __builtin_readcyclecounter();
 #define RTX_ACC(k) { const unsigned long long dbgE = __builtin_readcyclecounter() - dbgB0; if (__lane_id() == (uint32_t)__ffsll((long long)ballot(true)) - 1u) { atomicAdd(&gDbgHist[16 + 2 * (k)], dbgE); atomicAdd(&gDbgHist[17 + 2 * (k)], 1ull); } }
@@ -474,7 +421,8 @@ __device__ __forceinline__ Bundle makeBundle(bool active, const V3& o, const V3&
 	const float ninf = -__builtin_inff();
 	Bundle B;
 	float lo, hi;
-#if RTX_BUNDLE_ASM
+	// (RTX_BUNDLE_PAIRS: max and min of a coordinate as one pair of interleaved DPP chains, waveMaxMin -- rtx_tuning.h)
+#if RTX_BUNDLE_PAIRS
 #define RTX_RANGE(x, c, r) hi = active ? (x) : ninf; lo = active ? (x) : -ninf; waveMaxMin(hi, lo); centreRadius(lo, hi, c, r)
 #else
 #define RTX_RANGE(x, c, r) hi = waveMax(active ? (x) : ninf); lo = -waveMax(active ? -(x) : ninf); centreRadius(lo, hi, c, r)
@@ -563,7 +511,6 @@ __device__ __forceinline__ bool bundleRejects2(const Bundle& B, const RefA& ra, 
 	// u: Nu = d . (e2 x a)
 	const float wux = __builtin_fmaf(e2y, az, -(e2z * ay)), wuy = __builtin_fmaf(e2z, ax, -(e2x * az)), wuz = __builtin_fmaf(e2x, ay, -(e2y * ax));
 	float nuc = __builtin_fmaf(B.dcz, wuz, __builtin_fmaf(B.dcy, wuy, B.dcx * wux));
-#if RTX_RO_EXACT
 	// The origin box's part of the radius.  Nu = (a + do) . ((dc + dd) x e2) = Nu(centre) + dd . wu + do . (dc x e2) + do . (dd x e2): the third
 	// term is bounded by sum ro_k |(dc x e2)_k| -- not by dmax |e2|_1 sum ro_k, which is what a box of origins costs a bundle of
 	// SHADOW rays (a tilted patch of surface points; primary rays share their origin: nothing changes for them): 41 % fewer
@@ -571,21 +518,14 @@ __device__ __forceinline__ bool bundleRejects2(const Bundle& B, const RefA& ra, 
 	// the last by (sum ro_k) max rd |e2|_1.
 	const float cux = __builtin_fmaf(B.dcy, e2z, -(B.dcz * e2y)), cuy = __builtin_fmaf(B.dcz, e2x, -(B.dcx * e2z)), cuz = __builtin_fmaf(B.dcx, e2y, -(B.dcy * e2x));
 	const float nurO = __builtin_fmaf(B.roRd, s2, __builtin_fmaf(B.roz, fabsf(cuz), __builtin_fmaf(B.roy, fabsf(cuy), B.rox * fabsf(cux))));
-#else
-	const float nurO = B.kdRoSum * s2;
-#endif
 	const float nur = (nurO + __builtin_fmaf(B.rdz, fabsf(wuz), __builtin_fmaf(B.rdy, fabsf(wuy), B.rdx * fabsf(wux)))) * (1.0f + 0x1p-19f);
 	const float Eu = __builtin_fmaf(f.kda, s2, kFilterEta);
 	// v: Nv = d . (a x e1)
 	const float wvx = __builtin_fmaf(ay, e1z, -(az * e1y)), wvy = __builtin_fmaf(az, e1x, -(ax * e1z)), wvz = __builtin_fmaf(ax, e1y, -(ay * e1x));
 	float nvc = __builtin_fmaf(B.dcz, wvz, __builtin_fmaf(B.dcy, wvy, B.dcx * wvx));
-#if RTX_RO_EXACT
 	// (Nv = (dc + dd) . ((a + do) x e1): do . (e1 x dc))
 	const float cvx = __builtin_fmaf(e1y, B.dcz, -(e1z * B.dcy)), cvy = __builtin_fmaf(e1z, B.dcx, -(e1x * B.dcz)), cvz = __builtin_fmaf(e1x, B.dcy, -(e1y * B.dcx));
 	const float nvrO = __builtin_fmaf(B.roRd, s1, __builtin_fmaf(B.roz, fabsf(cvz), __builtin_fmaf(B.roy, fabsf(cvy), B.rox * fabsf(cvx))));
-#else
-	const float nvrO = B.kdRoSum * s1;
-#endif
 	const float nvr = (nvrO + __builtin_fmaf(B.rdz, fabsf(wvz), __builtin_fmaf(B.rdy, fabsf(wvy), B.rdx * fabsf(wvx)))) * (1.0f + 0x1p-19f);
 	const float Ev = __builtin_fmaf(f.kda, s1, kFilterEta);
 	if (!CULL) { nuc *= f.sg; nvc *= f.sg; }
@@ -658,40 +598,10 @@ __device__ __forceinline__ void triTestLane(const RefA& ra, const RefB& rb, cons
 // order (phase 2: bundle filter with the lanes acting as triangles, exact test of the survivors with the lanes acting as
 // rays).  The two phases alternate every RTX_LEAF_BATCH leaves so that any-hit shadow rays still stop early.
 // A hit exists iff bt < FLT_MAX on return (the first accepted t is < FLT_MAX by objects.cpp:598,623).
-#ifndef RTX_PRIO
-#define RTX_PRIO 1            // raised wave priority for work items known to be slow
-#endif
-#ifndef RTX_PRIO_TICKS
-#define RTX_PRIO_TICKS 50000u // pass 1: tiles that took more than 0.5 ms (100 MHz ticks) in the previous launch
-#endif
-#ifndef RTX_NODE_PACKED
-#define RTX_NODE_PACKED 0         // packed fp32 box test (6 instructions, 12 VGPRs of duplicated operands) or plain (12 instructions)
-#endif
-#ifndef RTX_BUNDLE_ASM
-#define RTX_BUNDLE_ASM 1
-#endif
-#ifndef RTX_WIDE
-#define RTX_WIDE 1                // walk the tree two levels at a time where that is exact (rtxd::WideNode)
-#endif
-#ifndef RTX_MAX_SPLITS
-#define RTX_MAX_SPLITS 4          // halvings of a wide bundle
-#endif
 // Leaves noted before their references are processed (meshWalk): ONE where a launch is bound by throughput (pass 1: a hit found in a
 // leaf tightens the bundle's limit / ends a shadow ray before the next node is visited -- headline pass 1 3.275 -> 3.176 ms, cfg5 11.40 ->
 // 11.01 against the 4 of round 3), TWO where it lasts as long as its slowest wave's chain of fetches (SSAA items, the frame kernel: FEWRAYS;
 // cfg2 at 1080p 1.306 (4) / 1.292 (2) / 1.353 (1) ms).  profiles/r04_ab_leaf_batch.txt
-#ifndef RTX_LEAF_BATCH
-#define RTX_LEAF_BATCH 1
-#endif
-#ifndef RTX_PRUNE_UNI2
-#define RTX_PRUNE_UNI2 1    // pruneAlive: the mirror / usability flags of the walk as operands (XOR, a third min / max operand) instead of tests: -18 VALU per evaluation (headline pass 1 -1.8 %)
-#endif
-#ifndef RTX_ONE_PASS
-#define RTX_ONE_PASS 1      // pass-1 kernel (one leaf per batch): one pass of 64 references per round trip instead of two (cfg4 -0.8 %, cfg5 -0.5 %, scratch 80 -> 64 B)
-#endif
-#ifndef RTX_LEAF_BATCH_FEW
-#define RTX_LEAF_BATCH_FEW 2
-#endif
 #define RTX_LEAF_BATCH_MAX (RTX_LEAF_BATCH > RTX_LEAF_BATCH_FEW ? RTX_LEAF_BATCH : RTX_LEAF_BATCH_FEW)
 // one reached leaf: first reference, number of references, the lanes (rays) that passed its box, start in the batch's stream
 struct LeafEntry { uint32_t start, count, first, pad0, maskLo, maskHi, pad1, pad2; };      // (what the assignment of a pass needs arrives with one 16-byte read)
@@ -705,22 +615,9 @@ __shared__ WideItem wideStack[4][kWideStackEntries];      // (kWideSlots - 1 ent
 // walk: [0..5] the range of 1 / dir over the rays per axis (lo, hi; mirrored so that it is positive), [6..11] the range of
 // the origins per axis in the same mirrored coordinates (lo, hi), [12] 216 dmax, [13] the largest |origin| coordinate,
 // [14] bits 0-2: axis mirrored, bits 3-5: axis usable (1 / dir of one sign over the wave).
-__shared__ float pruneUni[4][24];      // ([16..18] the sign bits that mirror a record's centre, [19..21] per axis +inf (usable) / -inf (not): RTX_PRUNE_UNI2)
-#ifndef RTX_PRUNE
-#define RTX_PRUNE 1
-#endif
-#ifndef RTX_PRUNE_RAYS
-#define RTX_PRUNE_RAYS 0      // per ray: the segment against the mesh's own PruneRec before the walk (measured: -1 %, the walk's first visit does it as well)
-#endif
-#ifndef RTX_PRUNE_ROOT
-#define RTX_PRUNE_ROOT (RTX_WIDE_LEVELS >= 3)      // the prune records of the root's slots are evaluated too: +-0 with four slots (two levels down: as good as never pruned), -1.6 % with eight
-#endif
-#ifndef RTX_SRC
-#define RTX_SRC 1             // source copies of the prune records (rtxd::PruneRec): 0 = every walk uses copy 0
-#endif
-#ifndef RTX_PRUNE_RCP
-#define RTX_PRUNE_RCP 1       // the range of 1 / dir from the bundle's direction box (six v_rcp_f32) instead of three wave-wide min / max reductions
-#endif
+__shared__ float pruneUni[4][24];      // ([16..18] the sign bits that mirror a record's centre, [19..21] per axis +inf (usable) / -inf (not))
+// the prune records of the root's slots are evaluated too: +-0 with four slots (two levels down: as good as never pruned), -1.6 % with eight
+constexpr bool kPruneRoot = kWideLevels >= 3;
 // 36 u / 1e-8 (u = 2^-24) = 214.6: see pruneSlots
 constexpr float kPruneC = 216.0f;
 // the reference's box test in its min / max form (exact when no NaN can arise, see meshWalk) against a box in SGPRs
@@ -756,7 +653,6 @@ __device__ __forceinline__ bool boxFailsRegular(float blox, float bhix, float bl
 __device__ __forceinline__ bool pruneAlive(const f4v& r0, const f4v& r1, const float* pu, float tmaxB)
 {
 	const f4v ua = *(const f4v*)(pu + 0), ub = *(const f4v*)(pu + 4), uc = *(const f4v*)(pu + 8), ue = *(const f4v*)(pu + 12);
-#if RTX_PRUNE_UNI2
 	// The walk's mirror and usability flags as operands instead of tests: the centre is mirrored by an XOR with the axis' sign bit, and an axis that is
 	// not usable (1 / dir changes sign over the bundle) drops out through one more operand of the min / max: cap = -inf gives entry -inf, exit +inf --
 	// whatever the products are, NaN included (v_min / v_max return the other operand); on a usable axis cap = +inf changes nothing (the products of
@@ -765,10 +661,6 @@ __device__ __forceinline__ bool pruneAlive(const f4v& r0, const f4v& r1, const f
 	const float cx = __uint_as_float(__float_as_uint(r0.x) ^ __float_as_uint(uf.x)), cy = __uint_as_float(__float_as_uint(r0.y) ^ __float_as_uint(uf.y));
 	const float cz = __uint_as_float(__float_as_uint(r0.z) ^ __float_as_uint(uf.z));
 	const float capX = uf.w, capY = ug.x, capZ = ug.y;
-#else
-	const uint32_t fl = __float_as_uint(ue.z);
-	const float cx = (fl & 1u) ? -r0.x : r0.x, cy = (fl & 2u) ? -r0.y : r0.y, cz = (fl & 4u) ? -r0.z : r0.z;
-#endif
 	// largest |orig - vertex| coordinate over the bundle and the box
 	const float ainf = fmaxf(fmaxf(fmaxf(cx - ub.z, ub.w - cx) + r1.x, fmaxf(cy - uc.x, uc.y - cy) + r1.y), fmaxf(cz - uc.z, uc.w - cz) + r1.z);
 	// P of the walk's source copy (rtxd::PruneRec: the camera's, a point light's) holds for origins within kSrcAinfMax of the box;
@@ -781,26 +673,14 @@ __device__ __forceinline__ bool pruneAlive(const f4v& r0, const f4v& r1, const f
 	const float ax = (cx - hx) - ub.w, bx = (cx + hx) - ub.z;
 	const float ay = (cy - hy) - uc.y, by = (cy + hy) - uc.x;
 	const float az = (cz - hz) - uc.w, bz = (cz + hz) - uc.z;
-#if RTX_PRUNE_UNI2
 	(void)inf;
 	const float ex = fminf(fminf(ax * ua.x, ax * ua.y), capX), fx = fmaxf(fmaxf(bx * ua.x, bx * ua.y), -capX);
 	const float ey = fminf(fminf(ay * ua.z, ay * ua.w), capY), fy = fmaxf(fmaxf(by * ua.z, by * ua.w), -capY);
 	const float ez = fminf(fminf(az * ub.x, az * ub.y), capZ), fz = fmaxf(fmaxf(bz * ub.x, bz * ub.y), -capZ);
-#else
-	float ex = fminf(ax * ua.x, ax * ua.y), fx = fmaxf(bx * ua.x, bx * ua.y);
-	float ey = fminf(ay * ua.z, ay * ua.w), fy = fmaxf(by * ua.z, by * ua.w);
-	float ez = fminf(az * ub.x, az * ub.y), fz = fmaxf(bz * ub.x, bz * ub.y);
-	if (!(fl & 8u)) { ex = -inf; fx = inf; }
-	if (!(fl & 16u)) { ey = -inf; fy = inf; }
-	if (!(fl & 32u)) { ez = -inf; fz = inf; }
-#endif
 	const float ent = fmaxf(fmaxf(ex, ey), ez), ext = fminf(fminf(fx, fy), fz);
 	return !(ent > ext || ext < 0.0f || ent > tmaxB * (1.0f + 0x1p-18f));
 }
 
-#ifndef RTX_PRUNE_PLANES
-#define RTX_PRUNE_PLANES 1
-#endif
 
 // The first stage of the bundle filter (bundleRejects1) for ALL triangles below a wide-node slot at once.  r0 / r1 = the slot's
 // rtxd::PlaneRec: every triangle's scaled plane normal q = (e2 x e1) / (s1 s2) lies in the box qc +- qr and its plane offset
@@ -862,7 +742,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 	uint32_t sp = 0;
 	const RTX_AS1 char* pruneRecs = nullptr;
 	float* pu = pruneUni[threadIdx.x >> 6];
-	if (WIDE && RTX_PRUNE) {
+	if (WIDE) {
 		pruneRecs = (const RTX_AS1 char*)(uintptr_t)RTX_MP(5);
 #undef RTX_MP
 		if (pruneRecs != nullptr) {
@@ -872,7 +752,6 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 			// 1 / x is monotone on either side of 0, so every lane's RN(1 / d) lies between the reciprocals of the box's ends --
 			// v_rcp_f32 (1 ulp) widened by 2^-21 covers its own error, the rounding of the ends and the lane's own rounding.
 			// An axis whose box touches 0 is not usable (flag), one with an end beyond 2^-100 neither (the reciprocal may be inf).
-#if RTX_PRUNE_RCP
 			const float dlx = B.dcx - B.rdx, dhx = B.dcx + B.rdx, dly = B.dcy - B.rdy, dhy = B.dcy + B.rdy, dlz = B.dcz - B.rdz, dhz = B.dcz + B.rdz;
 			const float wide = 1.0f + 0x1p-21f, narrow = 1.0f - 0x1p-21f;
 			// (1 / x falls on either side of 0: the smaller reciprocal belongs to the upper end of the box, whatever the sign)
@@ -882,12 +761,6 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 			ly *= ly > 0 ? narrow : wide; hy *= hy > 0 ? wide : narrow;
 			lz *= lz > 0 ? narrow : wide; hz *= hz > 0 ? wide : narrow;
 			const bool usx = (dlx > 0x1p-100f || dhx < -0x1p-100f), usy = (dly > 0x1p-100f || dhy < -0x1p-100f), usz = (dlz > 0x1p-100f || dhz < -0x1p-100f);
-#else
-			const float inf = __builtin_inff();
-			float hx = consider ? ix : -inf, lx = consider ? ix : inf, hy = consider ? iy : -inf, ly = consider ? iy : inf, hz = consider ? iz : -inf, lz = consider ? iz : inf;
-			waveMaxMin(hx, lx); waveMaxMin(hy, ly); waveMaxMin(hz, lz);
-			const bool usx = true, usy = true, usz = true;
-#endif
 			if (laneNow() == 0) {
 				const bool nx = hx < 0, ny = hy < 0, nz = hz < 0;
 				const bool okx = usx && (lx > 0 || nx), oky = usy && (ly > 0 || ny), okz = usz && (lz > 0 || nz);
@@ -902,13 +775,11 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				e.z = __uint_as_float((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u) | (okx ? 8u : 0u) | (oky ? 16u : 0u) | (okz ? 32u : 0u));
 				e.w = kFilterK * (e.y + F(mp[13])) * (1.0f + 0x1p-20f) + 1e-30f;      // K (|orig| + |vertex|): see planeAlive
 				*(f4v*)(pu + 0) = a; *(f4v*)(pu + 4) = b; *(f4v*)(pu + 8) = c; *(f4v*)(pu + 12) = e;
-#if RTX_PRUNE_UNI2
 				f4v f, g;
 				f.x = __uint_as_float(nx ? 0x80000000u : 0u); f.y = __uint_as_float(ny ? 0x80000000u : 0u); f.z = __uint_as_float(nz ? 0x80000000u : 0u);
 				f.w = okx ? __builtin_inff() : -__builtin_inff();
 				g.x = oky ? __builtin_inff() : -__builtin_inff(); g.y = okz ? __builtin_inff() : -__builtin_inff(); g.z = 0; g.w = 0;
 				*(f4v*)(pu + 16) = f; *(f4v*)(pu + 20) = g;
-#endif
 			}
 			if (!B.sane) pruneRecs = nullptr;      // NaN / inf / huge coordinates somewhere in the bundle: nothing is pruned
 		}
@@ -921,9 +792,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 		sp = 1;
 	}
 	for (;;) {
-#if RTX_DBG
-		const unsigned long long dbgP1 = __builtin_readcyclecounter();
-#endif
+		RTX_DBG_ONLY(const unsigned long long dbgP1 = __builtin_readcyclecounter();)
 		// ---- phase 1: nodes.  The reached leaves are noted in a small per-wave table in LDS.
 		uint32_t batch = 0, total = 0;      // total = references of the batch: its leaves form ONE stream, entry k starts at entries[k].start
 		uint32_t soleFirst = 0;             // kLeafBatch == 1: the first reference of the batch's only leaf
@@ -968,35 +837,21 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				}
 				if (inM == 0) continue;
 				if (RTX_DBG) { cnt.wNodes++; if (shadow) cnt.sVisits++; }
-#if RTX_BURN
-				// (experiment, profiles/r04_burn.txt: RTX_BURN extra VALU instructions per node visit on four independent registers -- does the launch get
-				// longer by their issue time (the VALU port is the bound) or not (the waves wait for something else)?)
-				{
-					float b0 = o.x, b1 = o.y, b2 = o.z, b3 = ix;
-#pragma unroll
-					for (int k = 0; k < RTX_BURN / 4; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
-					asm volatile("" :: "v"(b0), "v"(b1), "v"(b2), "v"(b3));
-				}
-#endif
 				const WideNode* w = wideNodes + (uint32_t)(link - 1);
 				// slots 3..0 are requested at once (their fetch runs while the prune records are evaluated); the SGPR file does not hold eight slots: see below
 				u32x16 wa = sload16(w), wb = sload16((const char*)w + 64);
 				// Which slots can contribute at all: of the first 2 kWideSlots lanes, lane k looks at record k (boxes, then planes: rtxd::PruneBlock).
 				uint32_t aliveM = (1u << kWideSlots) - 1u;
 				// (four slots: not at the root, where they are as good as never pruned -- 7 of 259 in tools/research/pruned_walk_sim.py; eight: everywhere)
-				const bool evalPrune = RTX_PRUNE && pruneRecs != nullptr && (RTX_PRUNE_ROOT || link != 1);
+				const bool evalPrune = pruneRecs != nullptr && (kPruneRoot || link != 1);
 				if (evalPrune) {
 					// lanes [0, kWideSlots): the slots' boxes (PruneRec), [kWideSlots, 2 kWideSlots): their planes (PlaneRec); both tests run on every lane's record
 					const RTX_AS1 f4v* pr = (const RTX_AS1 f4v*)(pruneRecs + (((uint32_t)(link - 1) * (2u * kWideSlots) + (lane & (2u * kWideSlots - 1u))) << 5));
 					const f4v r0 = pr[0], r1 = pr[1];
 					const bool aliveBox = !BOXES || pruneAlive(r0, r1, pu, tmaxB);      // (BOXES: see the kernels' template parameter)
-#if RTX_PRUNE_PLANES
 					const bool alivePlane = planeAlive(r0, r1, B, pu[15], tmaxB);
 					const uint32_t bal = (uint32_t)ballot((lane & (uint32_t)kWideSlots) ? alivePlane : aliveBox);
 					aliveM = bal & (bal >> kWideSlots) & ((1u << kWideSlots) - 1u);
-#else
-					aliveM = (uint32_t)ballot(aliveBox) & ((1u << kWideSlots) - 1u);
-#endif
 					if (RTX_DBG) { cnt.wS4++; cnt.wLeafSkips += (uint32_t)kWideSlots - (uint32_t)__popc(aliveM); }
 				}
 				// The node's slots four at a time (two s_load_dwordx16: the SGPR file holds no more), the last four first, slots 3..0 of every four in
@@ -1039,9 +894,6 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 			}
 		}
 		else {
-#if RTX_NODE_PACKED
-			const f2 oxx = { o.x, o.x }, oyy = { o.y, o.y }, ozz = { o.z, o.z }, ixx = { ix, ix }, iyy = { iy, iy }, izz = { iz, iz };
-#endif
 			while (i < nN && batch < kLeafBatch) {
 				const int32_t link = (int32_t)nd[6];
 				const uint32_t next = uni(i + 1);
@@ -1055,15 +907,8 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				const bool act = i >= resume;
 				// slab test, objects.cpp:546-567: (bounds[sign] - orig) * invdir per axis, sequential compares.
 				// ((lo_i, hi_i) - orig_i) * invdir_i as one packed subtract + one packed multiply per axis
-#if RTX_NODE_PACKED
-				const f2 bx = (f2{ F(nd[0]), F(nd[1]) } - oxx) * ixx;
-				const f2 by = (f2{ F(nd[2]), F(nd[3]) } - oyy) * iyy;
-				const f2 bz = (f2{ F(nd[4]), F(nd[5]) } - ozz) * izz;
-				const float xlo = bx.x, xhi = bx.y, ylo = by.x, yhi = by.y, zlo = bz.x, zhi = bz.y;
-#else
 				const float xlo = (F(nd[0]) - o.x) * ix, xhi = (F(nd[1]) - o.x) * ix, ylo = (F(nd[2]) - o.y) * iy, yhi = (F(nd[3]) - o.y) * iy;
 				const float zlo = (F(nd[4]) - o.z) * iz, zhi = (F(nd[5]) - o.z) * iz;
-#endif
 				bool fail;
 				if (REGULAR) {
 					// no NaN can arise (finite boxes with lo <= hi, finite origin, finite 1/dir): the sign-selected entry / exit values
@@ -1122,11 +967,11 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 		// classifies reference k of the pass against the bundle; the survivors are then tested exactly, in stream order,
 		// by the lanes that passed the box of the survivor's leaf.
 		const uint32_t lane = laneNow();
-#if RTX_DBG
+		RTX_DBG_ONLY(
 		const unsigned long long dbgP2 = __builtin_readcyclecounter();
 		cnt.cNodes += dbgP2 - dbgP1;
 		unsigned long long dbgExact = 0;
-#endif
+		)
 		uint32_t ecur = 0;                 // first entry that is not finished yet
 		// which reference, of which entry, a lane holds in the pass that starts at p0: later entries overwrite earlier ones
 		// from their start on
@@ -1160,10 +1005,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 			if (RTX_DBG) { cnt.wTri += __popcll(cand); if (shadow) cnt.sExact += __popcll(cand); if (cand == 0) cnt.wS2++; }
 			if (cand == 0) return false;
 			bool improved = false;
-#if RTX_DBG
-			const unsigned long long dbgE0 = __builtin_readcyclecounter();
-#endif
-#if RTX_RAY_MAJOR
+			RTX_DBG_ONLY(const unsigned long long dbgE0 = __builtin_readcyclecounter();)
 			// Few rays, many survivors (a part of a slow tile, an SSAA item of one pixel, at a pole where hundreds of sliver
 			// triangles pass every filter): one step per RAY instead of one per survivor -- the ray is broadcast, every
 			// surviving lane tests its own triangle against it, and the nearest hit is the wave minimum; among equal t the
@@ -1196,7 +1038,6 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				}
 				cand = 0;
 			}
-#endif
 			while (cand != 0) {
 				const int c = __builtin_ctzll(cand);
 				cand &= cand - 1;
@@ -1204,31 +1045,20 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				// SGPR source issues in ~4.2 cycles instead of ~2.4 (tools/ubench/valu_rate.hip): ~40 such instructions per test.
 				// Through the LDS crossbar (ds_bpermute) it arrives in VGPRs without a VALU instruction: pass 1 at 4096^2
 				// 5.77 -> 5.58 ms, cfg2 at 1080p 2.29 -> 2.17 (RTX_TRI_BPERMUTE=0: the v_readlane form).
-#if RTX_TRI_BPERMUTE
 #define RTX_RL(x) __int_as_float(__builtin_amdgcn_ds_bpermute(c << 2, __float_as_int(x)))
-#else
-#define RTX_RL(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), c))
-#endif
 				const float v0x = RTX_RL(ra.v0x), v0y = RTX_RL(ra.v0y), v0z = RTX_RL(ra.v0z);
 				const float e1x = RTX_RL(rb.e1x), e1y = RTX_RL(rb.e1y), e1z = RTX_RL(rb.e1z);
 				const float e2x = RTX_RL(rb.e2x), e2y = RTX_RL(rc.e2y), e2z = RTX_RL(rc.e2z);
 #undef RTX_RL
-#if RTX_TRI_BPERMUTE
 				const uint32_t tri = (uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)ra.tri);
 				// the rays that reached the survivor's leaf
 				const uint32_t ent = (kLeafBatch == 1 && !FEWRAYS) ? 0u : (uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)myEnt);
-#else
-				const uint32_t tri = (uint32_t)__builtin_amdgcn_readlane((int)ra.tri, c);
-				const uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)myEnt, c);
-#endif
 				const bool pass = ((myReach >> ent) & 1u) != 0;      // (no dependent LDS read of the table's mask per survivor)
 				const float before = bt;
 				if (pass) triTestOne<CULL, STATS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, tri, o, d, bt, bu, bv, btri);
 				improved = improved || bt < before;
 			}
-#if RTX_DBG
-			dbgExact += __builtin_readcyclecounter() - dbgE0;
-#endif
+			RTX_DBG_ONLY(dbgExact += __builtin_readcyclecounter() - dbgE0;)
 			if (ballot(improved) != 0) {
 				// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is true
 				// for this lane no later triangle or object can change the answer.
@@ -1240,7 +1070,6 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 			}
 			return false;
 		};
-#if RTX_ONE_PASS
 		// one leaf per batch: a second pass is rare (a leaf of more than 64 references) -- one pass per round trip, no idle loads of a pass B
 		if (kLeafBatch == 1 && !FEWRAYS) {
 			for (uint32_t p0 = 0; p0 < total; p0 = uni(p0 + 64)) {
@@ -1252,7 +1081,6 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 			}
 		}
 		else
-#endif
 		// two passes are requested together: one memory round trip per 128 references
 		for (uint32_t p0 = 0; p0 < total; p0 = uni(p0 + 128)) {
 			uint32_t rA, entA, rB = 0, entB = 0;
@@ -1266,9 +1094,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 			if (process(p0, vaA, vbA, vcA, entA)) return;
 			if (two && process(p0 + 64, vaB, vbB, vcB, entB)) return;
 		}
-#if RTX_DBG
-		cnt.cExact += dbgExact; cnt.cFilter += __builtin_readcyclecounter() - dbgP2 - dbgExact;
-#endif
+		RTX_DBG_ONLY(cnt.cExact += dbgExact; cnt.cFilter += __builtin_readcyclecounter() - dbgP2 - dbgExact;)
 		if (WIDE ? sp == 0 : i >= nN) break;
 	}
 }
@@ -1315,7 +1141,7 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 			const bool regular = (mflags & 2u) != 0 &&
 			                     ballot(consider && !(fabsf(ix) < __builtin_inff() && fabsf(iy) < __builtin_inff() && fabsf(iz) < __builtin_inff() &&
 			                                          fabsf(o.x) < 0x1p100f && fabsf(o.y) < 0x1p100f && fabsf(o.z) < 0x1p100f)) == 0;
-			const bool wideOk = RTX_WIDE && (mflags & 4u) != 0;
+			const bool wideOk = (mflags & 4u) != 0;
 			if ((mflags & 1u) != 0) {
 				const float xlo = (F(rec2[2]) - o.x) * ix, xhi = (F(rec2[3]) - o.x) * ix, ylo = (F(rec2[4]) - o.y) * iy, yhi = (F(rec2[5]) - o.y) * iy;
 				const float zlo = (F(rec2[6]) - o.z) * iz, zhi = (F(rec2[7]) - o.z) * iz;
@@ -1328,37 +1154,6 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 				fail = fail || (tmin > tzmax) || (tzmin > tmx);
 				if (STATS) cnt.box += __popcll(ballot(consider && fail));       // (their root-box test is still a test of the reference)
 				pending = consider && !fail;
-#if RTX_PRUNE && RTX_PRUNE_RAYS
-				// A ray whose SEGMENT [0, limit] stays clear of the mesh's true box (inflated by how far the reference's accepted hit
-				// can lie from its triangle: pruneAlive, here per ray with the ray's own dmax / ainf) cannot be given a hit by this
-				// mesh: it takes no part in the walk.  Most shadow rays that start on the floor in front of the mesh end here --
-				// their LINE meets the root box, which is all the reference's test asks (objects.cpp:534-570) -- and with the P of the
-				// rays' source (rtxd::PruneRec; round 3 had only Pgen: a margin of 0.4 at the headline, nearly every ray passed) the
-				// inflation is 1e-3: a tile of the floor costs no bundle and no walk.
-				if (!STATS && cull) {
-					const u32x8 rr = sload8(&M->rootRec);      // c.xyz, P, h.xyz, -
-					const u32x8 rp = sload8(M->rootPS);
-					const float ainf = fmaxf(fmaxf(fabsf(o.x - F(rr[0])) + F(rr[4]), fabsf(o.y - F(rr[1])) + F(rr[5])), fabsf(o.z - F(rr[2])) + F(rr[6]));
-					const float dmx = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), omx = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-					// the ray's own source (0: none), valid under sourceP's side conditions: |dir|_2 in [0.99, 1.001], origin within kSrcAinfMax of the box
-					const float l2 = len2(d);
-					const bool srcOk = RTX_SRC && src != 0 && src < 8u && l2 >= 0.9802f && l2 <= 1.002f && ainf <= kSrcAinfMax;
-					float Pr = F(rr[3]);
-					if (srcOk) Pr = src == 1u ? F(rp[1]) : (src == 2u ? F(rp[2]) : (src == 3u ? F(rp[3]) : (src == 4u ? F(rp[4]) : (src == 5u ? F(rp[5]) : (src == 6u ? F(rp[6]) : F(rp[7]))))));
-					const float rho = __builtin_fmaf(kPruneC * dmx * ainf, Pr, 0x1p-17f * (ainf + omx)) * (1.0f + 0x1p-20f) + 1e-30f;
-					const float hx = F(rr[4]) + rho, hy = F(rr[5]) + rho, hz = F(rr[6]) + rho;
-					const float ax = ((F(rr[0]) - hx) - o.x) * ix, bx = ((F(rr[0]) + hx) - o.x) * ix;
-					const float ay = ((F(rr[1]) - hy) - o.y) * iy, by = ((F(rr[1]) + hy) - o.y) * iy;
-					const float az = ((F(rr[2]) - hz) - o.z) * iz, bz = ((F(rr[2]) + hz) - o.z) * iz;
-					// (fminf / fmaxf drop a NaN operand -- 0 * inf on an axis the ray does not move along: that axis does not constrain)
-					const float ent = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), ext = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-					// (only rays with three finite 1 / dir: with a zero component an origin exactly on a face of the inflated box would
-					// make 0 * inf of one face and +-inf of the other, and the dropped NaN would leave the wrong one)
-					const bool tameRay = omx < 0x1p40f && dmx < 0x1p20f && fabsf(ix) < __builtin_inff() && fabsf(iy) < __builtin_inff() && fabsf(iz) < __builtin_inff();
-					const bool clear = ent > ext || ext < 0.0f || ent > h.t * (1.0f + 0x1p-18f);
-					pending = pending && !(clear && tameRay);
-				}
-#endif
 			}
 			while (ballot(pending) != 0) {
 				bool cl = pending;
@@ -1379,7 +1174,7 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 				// The walk may use a source copy of the prune records when ALL its rays pass through that source and have a direction
 				// of length 0.99 .. 1.001 (what sourceP assumes; origins further than kSrcAinfMax from a box fall back per record)
 				uint32_t srcSel = 0;
-				if (RTX_SRC && !STATS) {
+				if (!STATS) {
 					const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)src, __builtin_ctzll(ballot(cl)));
 					if (s0 != 0) {
 						const float l2 = len2(d);
@@ -1594,7 +1389,9 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 			// ray cannot influence the pixel ("moot"), and the product kernels do not walk it (castRayWave).
 			s.qmoot = s.mat == 0 && fmaxRef(0.f, dot(s.N, -s.L)) == 0.f;
 			s.qarea = lt == 3;
-			s.qsrc = (lt == 2 && s.li < P.nSrcLights) ? 2u + s.li : 0u;
+			// (a light's source copy was derived for shadow-ray origins within srcNmax |bias| of the surface: a shading normal longer than the host
+			// looked at -- a caller's un-normalised tri_nrm, a future object type -- or NaN falls back to copy 0 instead of pruning with too small a sigma)
+			s.qsrc = (lt == 2 && s.li < P.nSrcLights && len2(s.N) <= P.srcNmax2) ? 2u + s.li : 0u;
 			s.qtmax = dist;               // the ray itself: Ray{P + N*bias, -L, ShadowRay} (scene.cpp:787), built in castRayWave
 			s.state = ST_WAIT_SHADOW;
 			RTX_ACC(1)
@@ -1733,34 +1530,25 @@ __device__ __forceinline__ void primaryRay(const Params& P, float x, float y, V3
 // parked in LDS around every trace so that the walk has the registers.  Left to the compiler it goes to scratch, i.e.
 // through L2 into HBM and back (round 1 / 2: 5.9 GB of writes per launch for a 0.2-GB framebuffer); the kernels use
 // 5-10 KB of the 32-40 KB of LDS their occupancy leaves a block.
-#ifndef RTX_PARK
-#define RTX_PARK 1
-#endif
-#ifndef RTX_PARK_MORE
-#define RTX_PARK_MORE 1
-#endif
 constexpr bool kParkColor = kWideSlots < 16;      // (sixteen-slot nodes: the stack takes the 3 KB of objColor's three fields)
-constexpr int kParkFields = (RTX_PARK_MORE ? 25 : 21) - (kParkColor ? 0 : 3);
+constexpr int kParkFields = 25 - (kParkColor ? 0 : 3);
 constexpr int kPk = kParkColor ? 0 : -3;          // index shift of the fields behind objColor      // (26 with nSpec until the eight-slot walk's stack needed the kilobyte: five blocks per CU hold 31 744 B each)
 __shared__ float parkedState[kParkFields][256];
+// Five blocks per CU hold 31 744 B of LDS each (160 KB / 5, rounded down to the allocation granule): one array over the edge and the pass-1 kernel silently
+// runs four blocks per CU (-3 ... -20 %).  sobelStage belongs to the frame kernel only (four blocks per CU: 40 960 B each).
+static_assert(sizeof(powTab) + sizeof(leafBatch) + sizeof(wideStack) + sizeof(pruneUni) + sizeof(parkedState) <= (RTX_WAVES >= 5 ? 31744 : 40960),
+              "the ray kernels' LDS no longer fits the blocks per CU that RTX_WAVES asks for");
 
 // The kernel's argument block, read afresh from the kernarg segment.  Every ray kernel takes `const Params P` as its only
 // argument, so the segment starts with it.  The empty asm makes the pointer opaque: fields read through it are loaded where
 // they are used (s_load from the kernarg segment: scalar memory, no VALU slot) instead of being kept in SGPRs across the
 // walk -- where the register allocator parks them in lanes of a VGPR (v_writelane / v_readlane: ~100 VALU instructions per
 // trace round of a kernel that is bound by VALU issue).
-#ifndef RTX_KARGS
-#define RTX_KARGS 1
-#endif
 __device__ __forceinline__ const Params& freshParams(const Params& P)
 {
-#if RTX_KARGS
 	uint64_t p = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
 	asm volatile("" : "+s"(p));
 	return *(const Params*)(const RTX_AS4 Params*)p;      // (the loads are still selected as s_load: the address space is inferred back)
-#else
-	return P;
-#endif
 }
 
 // CAM: the rays handed in start at the camera (o == view.camPos bit for bit: pass 1, SSAA, the frame kernel -- not the probe rays)
@@ -1776,14 +1564,10 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 	s.specCoef = s.nSpec = s.dsum = s.ssum = 0;
 	s.qtmax = kFltMax; s.qmoot = false; s.qarea = false; s.qsrc = 0;
 	advance(P, s, gl);
-#if RTX_DBG
-	unsigned long long dbgRounds = 0, dbgTrace = 0, dbgState = 0;
-#endif
+	RTX_DBG_ONLY(unsigned long long dbgRounds = 0, dbgTrace = 0, dbgState = 0;)
 	while (ballot(s.state != ST_DONE) != 0) {
 		Hit h;
-#if RTX_DBG
-		const unsigned long long dbgT0 = __builtin_readcyclecounter();
-#endif
+		RTX_DBG_ONLY(const unsigned long long dbgT0 = __builtin_readcyclecounter();)
 		// moot shadow rays (see advance): only the instrumented variant walks them -- the reference's statistics count
 		// them; here the lane just sits the trace out and consumes "not occluded", which gives the same +0 product
 		const bool moot = s.state == ST_WAIT_SHADOW && s.qmoot;
@@ -1795,7 +1579,7 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 		const float qtmax = s.qtmax;
 		// (a ray of recursion depth 0 is the one handed in; reflected / refracted rays pass through no known point)
 		const uint32_t qsrc = qshadow ? s.qsrc : ((CAM && s.sp == 0) ? 1u : 0u);
-		if (MESH && RTX_PARK) {
+		if (MESH) {
 			const uint32_t t = threadIdx.x;
 			parkedState[0][t] = s.P.x; parkedState[1][t] = s.P.y; parkedState[2][t] = s.P.z;
 			parkedState[3][t] = s.N.x; parkedState[4][t] = s.N.y; parkedState[5][t] = s.N.z;
@@ -1804,14 +1588,12 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 			parkedState[12 + kPk][t] = s.spec.x; parkedState[13 + kPk][t] = s.spec.y; parkedState[14 + kPk][t] = s.spec.z;
 			parkedState[15 + kPk][t] = s.L.x; parkedState[16 + kPk][t] = s.L.y; parkedState[17 + kPk][t] = s.L.z;
 			parkedState[18 + kPk][t] = s.I.x; parkedState[19 + kPk][t] = s.I.y; parkedState[20 + kPk][t] = s.I.z;
-			if (RTX_PARK_MORE) {
-				parkedState[21 + kPk][t] = s.rd.x; parkedState[22 + kPk][t] = s.rd.y; parkedState[23 + kPk][t] = s.rd.z;
-				parkedState[24 + kPk][t] = s.specCoef;
-			}
+			parkedState[21 + kPk][t] = s.rd.x; parkedState[22 + kPk][t] = s.rd.y; parkedState[23 + kPk][t] = s.rd.z;
+			parkedState[24 + kPk][t] = s.specCoef;
 			asm volatile("" ::: "memory");
 		}
 		traceWave<STATS, MESH, FEWRAYS, BOXES>(freshParams(P0), qactive, qshadow, qo, qd, qtmax, h, cnt, qsrc);
-		if (MESH && RTX_PARK) {
+		if (MESH) {
 			asm volatile("" ::: "memory");
 			const uint32_t t = threadIdx.x;
 			s.P = mk(parkedState[0][t], parkedState[1][t], parkedState[2][t]);
@@ -1821,31 +1603,25 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 			s.spec = mk(parkedState[12 + kPk][t], parkedState[13 + kPk][t], parkedState[14 + kPk][t]);
 			s.L = mk(parkedState[15 + kPk][t], parkedState[16 + kPk][t], parkedState[17 + kPk][t]);
 			s.I = mk(parkedState[18 + kPk][t], parkedState[19 + kPk][t], parkedState[20 + kPk][t]);
-			if (RTX_PARK_MORE) {
-				s.rd = mk(parkedState[21 + kPk][t], parkedState[22 + kPk][t], parkedState[23 + kPk][t]);
-				s.specCoef = parkedState[24 + kPk][t];
-			}
+			s.rd = mk(parkedState[21 + kPk][t], parkedState[22 + kPk][t], parkedState[23 + kPk][t]);
+			s.specCoef = parkedState[24 + kPk][t];
 		}
-#if RTX_DBG
-		const unsigned long long dbgT1 = __builtin_readcyclecounter();
-#endif
+		RTX_DBG_ONLY(const unsigned long long dbgT1 = __builtin_readcyclecounter();)
 		if (s.state != ST_DONE) {
 			const Params& Pa = freshParams(P0);
 			consume(Pa, s, h);
 			advance(Pa, s, gl);
 		}
-#if RTX_DBG
-		dbgRounds++; dbgTrace += dbgT1 - dbgT0; dbgState += __builtin_readcyclecounter() - dbgT1;
-#endif
+		RTX_DBG_ONLY(dbgRounds++; dbgTrace += dbgT1 - dbgT0; dbgState += __builtin_readcyclecounter() - dbgT1;)
 	}
-#if RTX_DBG
+	RTX_DBG_ONLY(
 	// trace rounds of one work item, and where its cycles went (s_memtime): slowest item and sums
 	if (__lane_id() == 0) {
 		const unsigned long long before = atomicMax(&gDbgHist[8], dbgTrace + dbgState);
 		if (dbgTrace + dbgState > before) { gDbgHist[9] = dbgRounds; gDbgHist[10] = dbgTrace; gDbgHist[11] = dbgState; }
 		atomicAdd(&gDbgHist[12], dbgRounds); atomicAdd(&gDbgHist[13], dbgTrace); atomicAdd(&gDbgHist[14], dbgState); atomicAdd(&gDbgHist[15], 1ull);
 	}
-#endif
+	)
 	return s.col;
 }
 
@@ -1881,10 +1657,10 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 		atomicAdd(P.counters + 10, c.wLeaves); atomicAdd(P.counters + 11, c.wLeafSkips);
 		atomicAdd(P.counters + 12, c.wChunks); atomicAdd(P.counters + 13, c.wChunkSkips); atomicAdd(P.counters + 14, c.triLanes);
 		atomicAdd(P.counters + 15, c.moot);
-#if RTX_DBG
+		RTX_DBG_ONLY(
 		atomicAdd(&gDbgHist[32], c.cNodes); atomicAdd(&gDbgHist[33], c.cFilter); atomicAdd(&gDbgHist[34], c.cExact);
 		atomicAdd(&gDbgHist[40], c.aWalks); atomicAdd(&gDbgHist[41], c.sWalks); atomicAdd(&gDbgHist[42], c.sVisits); atomicAdd(&gDbgHist[43], c.sLeaves); atomicAdd(&gDbgHist[44], c.sPasses); atomicAdd(&gDbgHist[45], c.sExact);
-#endif
+		)
 	}
 }
 
@@ -1910,14 +1686,13 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 	// any wave may render any tile).  The queues are explicit tile lists built by the host (rtx_api.hip,
 	// buildTileList): tiles that can see a mesh come first, so the tail of the launch consists of cheap tiles.
 	const uint32_t xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
-#if RTX_DBG || RTX_WAVE_TRACE
+	RTX_DBG_ONLY(
 	const unsigned long long dbgStart = wall_clock64();
 	unsigned long long dbgEnd = dbgStart, dbgBusy = 0;
-#endif
+	)
 	for (uint32_t attempt = 0; attempt < 8; attempt = uni(attempt + 1)) {
 		const uint32_t q = (xcd + attempt) & 7u;
 		const uint32_t qBase = sload1(P.tileList + q), qSize = sload1(P.tileList + 8 + q);
-#if RTX_POP_MANY
 		// The queues are ordered heaviest-first: from the middle of a queue on the tiles are the cheap ones (sky, floor: 10-20 us), where the
 		// returning atomic and the dependent read of the list are a sizeable part of a tile -- there a wave takes RTX_POP_MANY tiles per atomic.
 		uint32_t take = 1, jEnd = 0, j = 0;
@@ -1928,19 +1703,11 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 				j = __builtin_amdgcn_readfirstlane(w);
 				if (j >= qSize) break;
 				jEnd = j + take < qSize ? j + take : qSize;
-				if (RTX_POP_DEN * j >= RTX_POP_NUM * qSize) take = RTX_POP_MANY;
+				if (kPopDen * j >= kPopNum * qSize) take = RTX_POP_MANY;
 			}
 			const uint32_t tile = sload1(P.tileList + qBase + j);
 			j = uni(j + 1);
-#else
-		for (;;) {
-			const uint32_t j = nextWork(P.workCounter + q * 16);
-			if (j >= qSize) break;
-			const uint32_t tile = sload1(P.tileList + qBase + j);
-#endif
-#if RTX_DBG
-			if (P.pad3 != 0 && tile != P.pad3 - 1) continue;      // RTX_DBG_TILE=tx,ty: only this tile (counters of one work item)
-#endif
+			RTX_DBG_ONLY(if (P.pad3 != 0 && tile != P.pad3 - 1) continue;)   // RTX_DBG_TILE=tx,ty: only this tile (counters of one work item)
 			// a tile (ty << 16 | tx), or a 64 x 1 strip of a halo row (0x10000000 | strip << 16 | y: rtx_api.hip, buildTileList),
 			// which is accounted to the first of the eight tiles it runs through
 			const bool strip = (tile & P.stripBit) != 0;      // (stripBit = 0 when the list holds no strips: tile rows from 4096 on use bit 28 themselves)
@@ -1951,45 +1718,28 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 			if (ballot(valid) == 0) continue;
 			V3 o, d;
 			primaryRay(P, (float)x + 0.5f, (float)y + 0.5f, o, d);
-#if RTX_PRIO
 			// a tile that was slow in the previous launch of this view (a pole, a silhouette) runs at raised priority: the
 			// launch ends when its slowest wave does, and such a wave otherwise gets one issue slot in RTX_WAVES
-#if RTX_POP_MANY && RTX_POP_NOPRIO
 			if (take > 1) __builtin_amdgcn_s_setprio(0);      // (the cheap part of the queue: no look at the tile's cost)
 			else
-#endif
 			if (sload1(P.tileCost + ty * P.tilesXFull + tx) > RTX_PRIO_TICKS) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#endif
 			const unsigned long long t0 = wall_clock64();
 			const V3 c = castRayWave<STATS, MESH, false, BOXES>(P, valid, o, d, gl, cnt);
 			const unsigned long long dt = wall_clock64() - t0;
-#if RTX_DBG || RTX_WAVE_TRACE
-			dbgEnd = t0 + dt; dbgBusy += dt;
-#endif
+			RTX_DBG_ONLY(dbgEnd = t0 + dt; dbgBusy += dt;)
 			if (lane == 0) {
 				// remembered per tile: the SSAA pass starts with the tiles that were expensive here (longest job first)
 				if (!strip) P.tileCost[ty * P.tilesXFull + tx] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
 				if (STATS) { atomicMax(P.counters + 3, dt); atomicAdd(P.counters + 4, dt); }
 			}
 			if (strip && lane < 8 && tx + lane < P.tilesX) P.tileCost[ty * P.tilesXFull + tx + lane] = (uint32_t)((dt > 0xffffffffull ? 0xffffffffull : dt) / 8);
-#if RTX_FB_STORE == 1
 			if (valid) {
 				float* px = P.fb + ((size_t)y * W + x) * 3;
 				px[0] = c.x; px[1] = c.y; px[2] = c.z;
 			}
-#elif RTX_FB_STORE == 2      // (experiment: non-temporal stores)
-			if (valid) {
-				float* px = P.fb + ((size_t)y * W + x) * 3;
-				__builtin_nontemporal_store(c.x, px); __builtin_nontemporal_store(c.y, px + 1); __builtin_nontemporal_store(c.z, px + 2);
-			}
-#else                        // (experiment: no framebuffer store at all -- what is left of WRITE_SIZE is scratch: profiles/r04_write_traffic.txt)
-			if (valid && c.x == 123456.0f) P.fb[0] = c.y + c.z;
-#endif
 		}
 	}
-#if RTX_DBG || RTX_WAVE_TRACE
-	if (lane == 0 && (gl >> 6) < 16384) { gDbgWave[3 * (gl >> 6)] = dbgStart; gDbgWave[3 * (gl >> 6) + 1] = dbgEnd; gDbgWave[3 * (gl >> 6) + 2] = dbgBusy; }
-#endif
+	RTX_DBG_ONLY(if (lane == 0 && (gl >> 6) < 16384) { gDbgWave[3 * (gl >> 6)] = dbgStart; gDbgWave[3 * (gl >> 6) + 1] = dbgEnd; gDbgWave[3 * (gl >> 6) + 2] = dbgBusy; })
 	if (STATS || RTX_DBG) flushCounts(P, cnt);
 }
 
@@ -2010,9 +1760,6 @@ __device__ __forceinline__ uint32_t nthSetBit(uint64_t m, uint32_t n)   // posit
 	return pos;
 }
 
-#ifndef RTX_SSAA_SPREAD_PX
-#define RTX_SSAA_SPREAD_PX 4u      // pixels per wave for the tiles that were very slow in pass 1 (rtxSsaaCountKernel)
-#endif
 template <bool STATS, bool MESH = true, bool BOXES = true>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTIC) rtxSsaaKernel(const Params P)
 {
@@ -2021,9 +1768,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
 	Counts cnt = {};
-#if RTX_DBG
-	uint32_t dbgItems = 0;
-#endif
+	RTX_DBG_ONLY(uint32_t dbgItems = 0;)
 	for (;;) {
 		// work item = 16 consecutive entries of the flagged-pixel list (rtxSsaaCountKernel / rtxSsaaScatterKernel):
 		// full waves even where a tile has only a few flagged pixels; the pixels of tiles that were expensive in pass 1
@@ -2032,10 +1777,8 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 		const uint32_t total = sload1(P.ssaaScan + 2 * (size_t)P.nTiles);
 		const uint32_t first = work * 16;
 		if (first >= total) break;
-#if RTX_PRIO
 		// the items of the tiles that were slow in pass 1 come first in the list: they run at raised priority
 		if (first < sload1(P.ssaaScan + P.nTiles)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#endif
 		const uint32_t g = first + (lane >> 2), sub = lane & 3;
 		const uint32_t pxy = P.ssaaPixels[g < total ? g : first];
 		const bool valid = g < total && pxy != 0xffffffffu;
@@ -2054,13 +1797,13 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 			const unsigned long long dt16 = (wall_clock64() - t0) * (npx <= 4u ? 4u : (npx <= 8u ? 2u : 1u));
 			if (lane == 0 && pxy != 0xffffffffu) atomicMax(P.tileCost + P.nTiles + (y >> 3) * P.tilesXFull + (x >> 3), (uint32_t)(dt16 > 0xffffffffull ? 0xffffffffull : dt16));
 		}
-#if RTX_DBG
+		RTX_DBG_ONLY(
 		if (!STATS && lane == 0 && (gl >> 6) < 8192 && dbgItems < 160) {      // (tools/ssaa_timeline.py)
 			const size_t e = (size_t)(gl >> 6) * 160 + dbgItems;
 			gDbgTimeline[3 * e] = t0; gDbgTimeline[3 * e + 1] = wall_clock64() - t0; gDbgTimeline[3 * e + 2] = 2ull << 32 | pxy;
 		}
 		dbgItems++;
-#endif
+		)
 		if (STATS && lane == 0) { atomicMax(P.counters + 3, wall_clock64() - t0); atomicAdd(P.counters + 4, wall_clock64() - t0); }
 		// color = 0; color += c0; += c1; += c2; += c3; fb = color / 4
 		const int base = (int)(lane & ~3u);
@@ -2515,9 +2258,6 @@ __global__ void __launch_bounds__(256) rtxSobelKernel(const float* __restrict__ 
 // The picture does not depend on any of the scheduling: every pixel is a pure function of the scene.
 // ------------------------------------------------------------------------------------------------
 #define RTX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-#ifndef RTX_FRAME_CUT
-#define RTX_FRAME_CUT 0       // experiment: 1 no SSAA items, 2 no Sobel either, 3 no dependency counting (pass 1 only)
-#endif
 __device__ __forceinline__ void storesAcknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __shared__ float sobelStage[4][304];      // per wave: the 10 x 10 pixels around a tile
@@ -2588,9 +2328,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 	const uint32_t wave = gl >> 6;
 	uint32_t attempt = 0;                       // pass-1 queues found empty so far (see rtxPass1Kernel)
 	uint32_t rot = wave * 5u;                   // where this wave's next SSAA item goes
-#if RTX_DBG
-	uint32_t dbgItems = 0;
-#endif
+	RTX_DBG_ONLY(uint32_t dbgItems = 0;)
 	const unsigned long long started = wall_clock64();
 	// a wave never waits for another one except on a queue entry that is being written; the watchdog (10 s) only turns a
 	// bug into an error code instead of a hung device
@@ -2668,9 +2406,6 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 		// the first wave of every block also looks into four others (all of them at the end), so that nothing is left
 		// behind in a queue whose own waves are busy or gone.
 		if (kind == 0) {
-#if RTX_FRAME_CUT
-			break;
-#endif
 			const bool helper = (threadIdx.x >> 6) == 0;
 			const uint32_t all = __hip_atomic_load(ctl + FC_ALL + 16 * (wave & 63u), RTX_AGENT);
 			if (!helper && all) {
@@ -2740,19 +2475,17 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 		}
 		V3 o, d;
 		primaryRay(P, fx, fy, o, d);
-#if RTX_PRIO
 		if (slow) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#endif
 		const unsigned long long t0 = wall_clock64();
 		const V3 c = castRayWave<false, MESH, true, BOXES>(P, valid, o, d, gl, cnt);
 		const unsigned long long dt = wall_clock64() - t0;
-#if RTX_DBG
+		RTX_DBG_ONLY(
 		if (lane == 0 && wave < 8192 && dbgItems < 160) {
 			const size_t e = (size_t)wave * 160 + dbgItems;
 			gDbgTimeline[3 * e] = t0; gDbgTimeline[3 * e + 1] = dt; gDbgTimeline[3 * e + 2] = (unsigned long long)kind << 32 | item;
 		}
 		dbgItems++;
-#endif
+		)
 		if (kind == 2) {
 			// color = 0; color += c0; += c1; += c2; += c3; fb = color / 4
 			const int base = (int)(lane & ~3u);
@@ -2786,9 +2519,6 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 		}
 		if (lane == 0) __hip_atomic_store(P.tileCost + ty * P.tilesXFull + tx, cost, RTX_AGENT);
 		storesAcknowledged();
-#if RTX_FRAME_CUT >= 3
-		continue;
-#endif
 		// count the tile in; Sobel for the tiles whose surroundings are now complete
 		uint32_t nIdx;
 		uint64_t todo = ballot(frameCountIn(P, P.tileReady, tx, ty, lane, nIdx));
@@ -2797,9 +2527,6 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 			todo &= todo - 1;
 			const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)nIdx, (int)l);
 			const uint32_t ny = n / P.tilesXFull, nx = n - ny * P.tilesXFull;
-#if RTX_FRAME_CUT >= 2
-			continue;
-#endif
 			const uint64_t flags = frameSobelTile(P, nx, ny, lane);
 			if (lane == 0) __hip_atomic_store(P.tileFlags + n, (unsigned long long)flags, RTX_AGENT);
 			storesAcknowledged();
@@ -2812,9 +2539,6 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 				const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mIdx, (int)l2);
 				const uint32_t nf = (uint32_t)__popcll(__hip_atomic_load(P.tileFlags + m, RTX_AGENT));
 				uint32_t mode = 0, items = (nf + 15u) >> 4;
-#if RTX_FRAME_CUT >= 1
-				items = 0;
-#endif
 				// A tile that was slow in pass 1 (a silhouette, a pole) gets 4-pixel or 1-pixel items: what matters is when its
 				// last ray returns.  Limits: as for splitting the tile in pass 1, and 4 x heavyTicks whatever the frame.
 				if (items) {

@@ -132,16 +132,4 @@ __global__ void __launch_bounds__(256) rtxSourceSlotKernel(const uint32_t* __res
 	}
 }
 
-// The P of the whole mesh for one source (rtxd::Mesh::rootPS): the largest P_S of any reference, never above Pgen.  One block.
-__global__ void __launch_bounds__(256) rtxSourceRootKernel(const float* __restrict__ blockP, uint32_t nBlocks, float pgen, float* __restrict__ out)
-{
-	__shared__ float part[4];
-	float mx = 0.0f;
-	for (uint32_t j = threadIdx.x; j < nBlocks; j += 256) mx = fmaxf(mx, blockP[j]);
-	for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-	if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = mx;
-	__syncthreads();
-	if (threadIdx.x == 0) { mx = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])); *out = mx < pgen ? mx : pgen; }
-}
-
 } // namespace rtxsrc

@@ -1,0 +1,45 @@
+// Compile-time tunables of the ray kernels (rtx_kernels.hip), all in one place.  Each can be overridden on the hipcc command
+// line (-DRTX_WAVES=6: tools/build_variants.sh builds such variants for A/B runs); the defaults are what the product ships.
+// Everything that used to be an experiment SWITCH (alternative walks, filters, stores ...) has been retired: the losing
+// branches are kept as a patch (tools/research/r04_experiment_branches.patch).
+#pragma once
+
+#ifndef RTX_DBG
+#define RTX_DBG 0               // 1: wave-level stage counters + per-wave pass-1 timeline, 2: + sampled outcomes / histograms (slow), 3: state-machine timers
+#endif
+#ifndef RTX_WAVES
+#define RTX_WAVES 5             // waves per SIMD of the pass-1 kernel (512 / RTX_WAVES VGPRs): 6 = 80 VGPRs spills the round loop (+8 %), 4 loses 20 %
+#endif
+#ifndef RTX_WAVES_SSAA
+#define RTX_WAVES_SSAA 4        // the SSAA launch lasts as long as its slowest wave: fewer, unspilled waves (128 VGPRs)
+#endif
+#ifndef RTX_WAVES_FRAME
+#define RTX_WAVES_FRAME 4       // rtxFrameKernel runs where the frame is bounded by its slowest work items: likewise
+#endif
+#ifndef RTX_WAVES_ANALYTIC
+#define RTX_WAVES_ANALYTIC 4    // scenes without meshes: the whole castRay state in registers (128 VGPRs)
+#endif
+#ifndef RTX_POP_MANY
+#define RTX_POP_MANY 4u         // pass 1: tiles taken per atomic in the cheap half of a queue (profiles/r04_ab_pop.txt: 8 / 16 / guided helpings lost)
+#endif
+#ifndef RTX_PRIO_TICKS
+#define RTX_PRIO_TICKS 50000u   // pass 1: tiles that took more than 0.5 ms (100 MHz ticks) in the previous launch run at raised wave priority
+#endif
+#ifndef RTX_MAX_SPLITS
+#define RTX_MAX_SPLITS 4        // halvings of a wide bundle (traceWave)
+#endif
+#ifndef RTX_LEAF_BATCH
+#define RTX_LEAF_BATCH 1        // leaves noted before their references are processed: ONE where a launch is bound by throughput (pass 1) ...
+#endif
+#ifndef RTX_LEAF_BATCH_FEW
+#define RTX_LEAF_BATCH_FEW 2    // ... TWO where it lasts as long as its slowest wave's chain of fetches (SSAA items, frame kernel): profiles/r04_ab_leaf_batch.txt
+#endif
+#ifndef RTX_SSAA_VERY
+#define RTX_SSAA_VERY 2u        // x the "heavy" threshold of pass-1 time (knob ssaa_heavy_ticks): tiles above get 4-pixel SSAA waves
+#endif
+#ifndef RTX_SSAA_SPREAD_PX
+#define RTX_SSAA_SPREAD_PX 4u   // pixels per wave for the tiles that were very slow in pass 1 (rtxSsaaCountKernel)
+#endif
+#ifndef RTX_BUNDLE_PAIRS
+#define RTX_BUNDLE_PAIRS 0      // makeBundle: 1 = waveMaxMin (two interleaved DPP chains per coordinate).  Rounds 2-4 shipped 0 without meaning to: the switch was
+#endif                          // tested (line 477) before it was defined (line 671) -- found when the switches were retired in round 5; A/B in profiles/r05_ab_*.txt

@@ -93,7 +93,12 @@ class FrameGather:
     k + 1 waits (on the device, an event) until the exchange of frame k has left / filled img -- long after it ended, as
     a frame renders several times longer than it travels.  wait() makes the current stream wait for the last exchange:
     rank `root`'s img then holds the last frame submitted.  A consumer that needs every frame calls wait() per frame (and
-    gives up the overlap) or hands in a different img per frame."""
+    gives up the overlap) or hands in a different img per frame.
+
+    A frame rendered through rtx_render_frame must be CONFIRMED before its image is used: submit() quantises and sends what the
+    frame's launches wrote, before the host has seen rtx_frame_status.  If the single launch gave up, scene.frame_status() renders
+    the frame again -- into fb only; the caller must then submit(fb) again (bench.py checks the status after its timed region and
+    voids the run).  Callers that cannot re-submit force three launches first: scene.set_frame_mode(0)."""
 
     def __init__(self, scene, comm, img, root=0):
         import torch

@@ -1,4 +1,6 @@
 """GPU box, RTX_DBG build: per-wave timeline summary of one pass 1 (RTX_DEBUG_ITEMS=1 python tools/dbg_pass1.py)."""
+import os as _os
+_os.environ.setdefault("RTX_ALLOW_ENV_KNOBS", "1")      # (the product ignores RTX_* environment knobs without it)
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))

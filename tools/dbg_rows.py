@@ -1,5 +1,7 @@
 """GPU box, RTX_DBG build: wave-level counters of pass 1 restricted to image rows [y0, y1) (product variant unless
 DBG_STATS=1).  RTX_DEBUG_ITEMS=1 python tools/dbg_rows.py y0 y1 [scene] [W] [H]"""
+import os as _os
+_os.environ.setdefault("RTX_ALLOW_ENV_KNOBS", "1")      # (the product ignores RTX_* environment knobs without it)
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))

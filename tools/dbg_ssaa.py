@@ -1,5 +1,7 @@
 """GPU box: slowest SSAA work item and the sum over the items (instrumented variant) next to the product launch time.
 RTX_DEBUG_ITEMS=1 python tools/dbg_ssaa.py [scene] [W] [H]"""
+import os as _os
+_os.environ.setdefault("RTX_ALLOW_ENV_KNOBS", "1")      # (the product ignores RTX_* environment knobs without it)
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))

@@ -1,5 +1,7 @@
 """GPU box, RTX_DBG build: what the frame kernel (rtx_render_frame) is doing when.
 RTX_DBG_TIMELINE=/tmp/tl.bin python tools/frame_timeline.py [scene W H]"""
+import os as _os
+_os.environ.setdefault("RTX_ALLOW_ENV_KNOBS", "1")      # (the product ignores RTX_* environment knobs without it)
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))

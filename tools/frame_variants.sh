@@ -1,4 +1,5 @@
 #!/bin/bash
+export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs without it (rtx_api.hip readKnobs)
 # GPU box: every variant under rendering_amd/_variants, the frame in one launch, on several workloads (twice, interleaved)
 cd ${GRAFT_REPO_ROOT:-.}
 cp rendering_amd/librtx_hip.so /tmp/librtx_orig.so

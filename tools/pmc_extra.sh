@@ -1,4 +1,5 @@
 #!/bin/bash
+export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs without it (rtx_api.hip readKnobs)
 # GPU box: a look at counters outside the committed set (instruction cache, scalar cache, LDS, waits) for the headline's pass 1.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_extra

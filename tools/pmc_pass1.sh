@@ -1,4 +1,5 @@
 #!/bin/bash
+export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs without it (rtx_api.hip readKnobs)
 # GPU box: regenerates profiles/<round>_pass1_pmc.json -- hardware counters of the ray kernels of the CURRENT sources,
 # stamped with the source hash (tools/srchash.py) so that bench.py only quotes them for the kernels they were measured on.
 # Two workloads: the headline (three launches: rtxPass1Kernel / rtxSsaaKernel) and cfg2 at 1920x1080 (one launch:

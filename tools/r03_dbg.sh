@@ -1,4 +1,5 @@
 #!/bin/bash
+export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs without it (rtx_api.hip readKnobs)
 # GPU box: RTX_DBG build -> wave-level counters of the product pass 1 at the headline, with and without the prune records
 cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out/r03; mkdir -p $O

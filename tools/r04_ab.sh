@@ -1,4 +1,5 @@
 #!/bin/bash
+export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs without it (rtx_api.hip readKnobs)
 # GPU box: parity suite (quick subset or all) + A/B of rendering_amd/_variants + RTX_DBG counts of the default build
 cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out/r04; mkdir -p $O

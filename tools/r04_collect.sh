@@ -1,4 +1,5 @@
 #!/bin/bash
+export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs without it (rtx_api.hip readKnobs)
 # GPU box: the round's profiles for the CURRENT sources -- PMC counters (tools/pmc_pass1.sh), bench lines plain and under
 # rocprofv3 --kernel-trace --stats (headline + cfg2), all BASELINE configs, RTX_DBG wave-level counts with and without the
 # prune records, shard emulation.  Results under gpurun_out/r04/ (copied to profiles/ by tools/r04_copy.sh).

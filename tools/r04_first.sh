@@ -1,4 +1,5 @@
 #!/bin/bash
+export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs without it (rtx_api.hip readKnobs)
 # GPU box: first look at a change -- the GPU suite, the headline bench with and without the source copies, RTX_DBG wave-level counts.
 cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out/r04; mkdir -p $O

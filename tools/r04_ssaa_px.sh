@@ -1,4 +1,5 @@
 #!/bin/bash
+export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs without it (rtx_api.hip readKnobs)
 # GPU box: SSAA stage with 4 / 2 / 1 pixels per wave on the slow tiles, whole frame and one-eighth parts
 cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out/r04; mkdir -p $O

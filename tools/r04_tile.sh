@@ -1,4 +1,5 @@
 #!/bin/bash
+export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs without it (rtx_api.hip readKnobs)
 # GPU box: wave-level counters of ONE pass-1 tile in RTX_DBG builds with the given extra defines: tools/r04_tile.sh tx,ty "defsA" "defsB" ...
 cd ${GRAFT_REPO_ROOT:-.}
 t=$1; shift

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs without it (rtx_api.hip readKnobs)
 # GPU box: where the cycles of a node visit go (RTX_DBG): the whole headline pass 1 (5 waves per SIMD) and one tile alone
 cd ${GRAFT_REPO_ROOT:-.}
 RTX_DEFS="-DRTX_DBG=1 $DBG_DEFS" ./build.sh > gpurun_out/build_dbg.log 2>&1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs without it (rtx_api.hip readKnobs)
 cd ${GRAFT_REPO_ROOT:-.}
 RTX_DEFS="-DRTX_DBG=1 $DBG_DEFS" ./build.sh > gpurun_out/build_dbg.log 2>&1
 for cfg in "scenes/cfg2_smooth_250k.scene 4096 4096" "scenes/cfg2_smooth_250k.scene 1920 1080" "scenes/cfg4_textured_1024.scene 4096 4096"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs without it (rtx_api.hip readKnobs)
 # GPU box: RTX_DBG build -> SSAA timeline, then the product build again
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out

@@ -1,5 +1,7 @@
 """GPU box, RTX_DBG build: the work items of the SSAA launch (three-launch path) -- when each started, how long it took.
 python tools/ssaa_timeline.py [scene W H [parts part]]"""
+import os as _os
+_os.environ.setdefault("RTX_ALLOW_ENV_KNOBS", "1")      # (the product ignores RTX_* environment knobs without it)
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))

@@ -1,5 +1,7 @@
-"""GPU box, build with -DRTX_WAVE_TRACE=1 (or RTX_DBG): how the waves of a pass 1 end -- the launch lasts as long as its last wave.
+"""GPU box, build with -DRTX_DBG=1: how the waves of a pass 1 end -- the launch lasts as long as its last wave.
 RTX_DEBUG_ITEMS=1 python tools/wave_tail.py [scene W H]"""
+import os as _os
+_os.environ.setdefault("RTX_ALLOW_ENV_KNOBS", "1")      # (the product ignores RTX_* environment knobs without it)
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
