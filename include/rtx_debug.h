@@ -58,6 +58,11 @@ int rtx_math_probe(int device, int op, uint32_t n, const float* x, const float* 
  * 2 Render::fresnel(a, b, ior) in out[3 i] (698-722), 3 Vec3::normalize(a) (geometry.h:104-112; b may be NULL). */
 int rtx_vec_probe(int device, int op, uint32_t n, const float* a, const float* b, float ior, float* out);
 
+/* Host only: the description as one canonical byte string (every scalar and the contents of every array rtx_scene_create reads, in declaration
+ * order; no pointers, no padding).  *need = its length; written to out when cap >= *need (out may be NULL to ask for the length).  The parity
+ * check of the reference-side binding (oracle/ref_binding.cpp) against this repo's host: tests/test_ref_binding.py. */
+int rtx_desc_serialize(const rtx_scene_desc* desc, void* out, size_t cap, size_t* need);
+
 #ifdef __cplusplus
 }
 #endif

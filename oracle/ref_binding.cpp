@@ -1,37 +1,25 @@
-# INTEGRATION — wiring `librtx_hip.so` into holoskii/Rendering
+// TEST INFRASTRUCTURE (build container only) -- never shipped, never on the product path.
+//
+// The binding of INTEGRATION.md, COMPILED AGAINST THE REAL REFERENCE: this file includes the reference's own headers
+// (/root/reference/include/scene.h:68-100, objects.h:24-200, lights.h:21-73, options.h:9-37), is linked with the reference's own
+// translation units (oracle/_ref/*.o, built by oracle/Makefile from the sources where they lie) and with this repo's
+// librtx_hip.so, and fills an rtx_scene_desc from a Scene the REFERENCE's loader produced.  Nothing of the reference is copied:
+// only its public members are read.  What a maintainer pastes into src/scene.cpp is the part between the two BINDING markers;
+// INTEGRATION.md quotes it from here.
+//
+//   oracle/_ref/ref_binding dump <cwd> <scene> <width> <height> <out.bin>
+//       loads the scene with the reference's Scene(path), fills the description exactly as uploadScene() does and writes its
+//       canonical bytes (rtx_desc_serialize, include/rtx_debug.h).  tests/test_ref_binding.py compares them with the bytes of
+//       the description this repo's own host builds for the same file (rendering_amd/host/src/scene.cpp, flattenScene).
+//   oracle/_ref/ref_binding render <cwd> <scene> <width> <height> <out.bmp>      (needs a GPU: the box never has /root/reference,
+//       so this mode is for a maintainer's machine; it is compiled here to prove the calls type-check against both sides)
+#include "scene.h"
+#include "stats.h"
+#include "timer.h"
+#include "options.h"
+#include "util.h"
 
-The reference has no plugin/FFI layer; its seam is the public `Scene` API (`include/scene.h:68-100`).  A
-maintainer keeps every loader, `Scene`, `Options`, `Object`, `Mesh`, `AccelerationStructure` exactly as they are
-and replaces the bodies of the two worker launchers with calls into the C ABI of `include/rtx.h`.  All members
-the flattener needs are already public (`objects.h:69-164`).
-
-| reference symbol | replaced by |
-|---|---|
-| `Scene::launchWorkers(Vec3f*)` `scene.cpp:470-506` (+ `renderWorker` 444-468) | `rtx_render_pass1` |
-| `Scene::launchSSAA(Vec3f*)` `scene.cpp:542-593` (+ `SSAAworker` 508-540) | `rtx_sobel` + `rtx_render_ssaa` |
-| `Scene::render` `scene.cpp:595-606` calling both in turn | `rtx_render_frame` (both launchers as ONE call: the stages overlap on the device where that is faster, `rtx.h`) |
-| `Render::castRay` / `Render::trace` `scene.cpp:724-946` (single rays, tests) | `rtx_cast_rays` |
-| `saveImage` quantiser `util.cpp:46-58` (optional) | `rtx_quantize_bgr8` |
-| `stats::` counters `stats.h:11-16` | `rtx_counters_*` (64-bit) |
-| `AccelerationStructure::setup` + recursive build `objects.cpp:385-392, 470-526, 633-763` (optional) | `rtx_bvh_build` / `rtx_bvh_read` |
-| — (`Scene::render` `scene.cpp:595-606` runs in one address space) frame of N GPUs, one process each | `rtx_set_row_ownership` + `rtx_comm_unique_id` / `rtx_comm_create` + `rtx_gather` |
-
-## The binding (C++17, drops into `src/scene.cpp` of the reference)
-
-This is not a sketch: the block below is `oracle/ref_binding.cpp` between its `BINDING` markers (copied here by
-`tools/sync_integration_md.py`; `tests/test_ref_binding.py` fails when the two differ).  In the build container that file is
-compiled against the reference's own headers (`/root/reference/include/scene.h:68-100`, `objects.h:24-200`, `lights.h:21-73`,
-`options.h:9-37`), linked with the reference's own translation units (`oracle/_ref/*.o`) and with `librtx_hip.so`, and the
-`rtx_scene_desc` it fills from a `Scene` **the reference's loader produced** is compared byte for byte
-(`rtx_desc_serialize`: every scalar and every array `rtx_scene_create` reads) with the one this repo's own host builds for the
-same file -- nine scenes: every object / material / light type, the three texture maps, the skybox, area-light sample points,
-the flattened acceleration structure of the 4k / 25k meshes in the reference's visiting order.  `rtxLaunchWorkers` /
-`rtxLaunchSSAA` are the new bodies of `Scene::launchWorkers(Vec3f*)` (`scene.cpp:470-506`) and `Scene::launchSSAA(Vec3f*)`
-(`scene.cpp:542-593`) with `g = uploadScene(*this)` kept in a member; `rtxRender` is `Scene::render()` (`scene.cpp:595-657`) where
-that is under the maintainer's control as well -- both launchers as one call, the frame never leaves the device between them.
-
-<!-- BINDING:BEGIN -->
-```cpp
+// ---- BINDING (begin) -----------------------------------------------------------------------------------------------------
 #include "rtx.h"            // this repo: include/rtx.h ; link with -lrtx_hip
 #include <hip/hip_runtime_api.h>
 #include <cmath>
@@ -204,85 +192,53 @@ static void rtxRender(Scene& s, rtx_scene* g, std::vector<uint8_t>& bgrBottomUp)
 	if (hipMemcpy(bgrBottomUp.data(), bgr, px * 3, hipMemcpyDeviceToHost) != hipSuccess) LOG_ERROR();
 	(void)hipFree(fb); (void)hipFree(mask); (void)hipFree(bgr);
 }
-```
-<!-- BINDING:END -->
+// ---- BINDING (end) -------------------------------------------------------------------------------------------------------
 
-`rtx_render_frame` renders the frame in one launch or in three, whichever it measured to be faster for this view on its
-first warm frames (`rtx_frame_mode` tells; `rtx_set_frame_mode` forces); the pixels and the mask are the same either way.
+#include "rtx_debug.h"      // rtx_desc_serialize
+#include <cstdio>
+#include <cstring>
+#include <unistd.h>
 
-`rendering_amd/host/src/scene.cpp` (`flattenScene`, `Scene::launchWorkers`, `Scene::launchSSAA`) is this binding
-written out in full against this repo's own host classes, which mirror the reference's names and members; a
-framebuffer that stays on the device between the two passes avoids the PCIe round trips: this repo's `Scene::render()`
-keeps one device frame per `Scene` (fp32 framebuffer, Sobel mask, BGR8 image), runs `rtx_render_frame` (or, with
-statistics on, pass 1, `rtx_sobel`, `rtx_render_ssaa`) and `rtx_quantize_bgr8` on it and copies back the
-3-bytes-per-pixel image `saveImage` writes.
-
-## N GPUs of one node: `rtx_gather` (one process per GPU)
-
-```cpp
-// every rank: same scene file, its own GPU.  Bootstrap: rank 0 makes the id, the others get its 128 bytes by any means
-// (render_amd --gpus N forks before HIP is touched and uses pipes; MPI_Bcast / a file work as well).
-unsigned char id[RTX_COMM_ID_BYTES];
-if (rank == 0) rtx_comm_unique_id(id);
-/* ... hand id to the other ranks ... */
-rtx_comm* comm; rtx_comm_create(id, nRanks, rank, /*device*/rank, &comm);
-
-// in Scene::render(), between launchSSAA and saveImage (scene.cpp:601-606), frame resident on the device:
-rtx_set_row_ownership(g, 64, nRanks, rank, /*halo*/1);     // this rank renders / masks / re-renders its 64-row bands only
-rtx_render_frame(g, 0, H, fb, mask, 0);                    // = rtx_render_pass1 ; rtx_sobel ; rtx_render_ssaa of this rank's rows
-rtx_quantize_bgr8(g, fb, bgr, 0);                          // saveImage's bytes, 3 per pixel
-int all_ok; rtx_comm_agree(comm, /*this rank's frame is fine*/1, &all_ok, 0);   // a failed rank must not leave the others waiting for its bands
-if (!all_ok) LOG_ERROR();
-rtx_gather(g, comm, bgr, W * 3, /*bottom_up*/1, /*root*/0, 0);   // grouped ncclSend / ncclRecv of whole bands over xGMI
-if (rank == 0) { hipMemcpy(host, bgr, W * H * 3, hipMemcpyDeviceToHost); /* write the BMP */ }
-```
-
-`rendering_amd/host/src/scene.cpp` (`Scene::attachComm`, `Scene::render`) and `host/src/main.cpp` (`render_amd --gpus N`)
-are this binding; `rendering_amd/parallel.py:make_comm` is the same bootstrap over a torch.distributed group.
-
-## Optional: building the acceleration structure on the device
-
-```cpp
-// in Mesh::loadModel, instead of  ac->setup(allTris, options)  (objects.cpp:385-392):
-std::vector<float> pos(allTris.size() * 9);                 // a, b, c of every Triangle
-/* fill pos */
-rtx_bvh* b = nullptr;
-if (rtx_bvh_build(pos.data(), (uint32_t)allTris.size(), &ac->bounds[0].x, &ac->bounds[1].x, options.acPenalty, 0, &b) != RTX_OK) LOG_ERROR();
-uint32_t nn, nr, depth; float ms;
-rtx_bvh_info(b, &nn, &nr, &depth, &ms);
-/* rtx_bvh_read(b, bounds, skip, leafBegin, leafCount, refs) yields exactly the arrays flattenAC() above produces from
-   the pointer tree, so the pointer tree is no longer needed by the render path */
-rtx_bvh_destroy(b);
-```
-
-`rendering_amd/host/src/objects.cpp` (`AccelerationStructure::setup`) is this binding in this repo's host classes.
-
-## Python (ctypes) binding used by the tests and `bench.py`
-
-```python
-import rendering_amd as RA, torch
-g = RA.Scene("scenes/cfg2_smooth_250k.scene", 4096, 4096)       # C++ loader + BVH build (librendering_host.so)
-fb = torch.zeros((4096, 4096, 3), dtype=torch.float32, device="cuda")
-mask = torch.zeros((4096, 4096), dtype=torch.uint8, device="cuda")
-g.render_pass1(fb); g.sobel(fb, mask); g.render_ssaa(mask, fb)     # rtx_render_pass1 / rtx_sobel / rtx_render_ssaa
-```
-
-## Behavioural notes for the maintainer
-
-* Results are bit-identical to the CPU path built with `-ffp-contract=off` and no `-march` (the reference's own
-  CMake default).  A CPU build with FMA contraction differs from BOTH.
-* `powf` on the device reproduces glibc 2.35's x86-64 FMA variant.  A host with a different libm may round
-  `std::pow` differently in ~7e-4 of calls (1 ULP).
-* The Sobel border mask is 0 (the reference reads uninitialised heap for row 0 / column 0).
-* `width` must be a multiple of 4 for `saveImage` (the reference writes out of bounds otherwise).
-* Debug modes `showAC`, `showNormals`, `useAC=0` stay on the CPU path.
-* Multi-GPU: one process per GPU, `rtx_set_row_ownership(scene, 64, nGPUs, rank, 1)` before the three calls, then
-  `rtx_gather` (above).  RCCL needs one GPU per rank.
-* Errors: every `rtx_*` call returns a status (message in `rtx_last_error`); nothing in `librtx_hip.so` exits the process.
-* `rtx_scene_create` / `rtx_scene_set_view` also prepare the first frame of the view (cost estimate of every tile from the projected leaf boxes,
-  tile lists, buffers of the single launch): scene-loading work, outside the reference's "Render scene" timer like its own loader.
-* The library ignores `RTX_*` environment variables unless `RTX_ALLOW_ENV_KNOBS=1` is set (the A/B tools under `tools/` set it); they are then read once, by `rtx_scene_create`.  `rtx_set_knob` (`include/rtx_debug.h`: probes, diagnostics and tuning hooks, none of which a reference-side caller binds) changes one of a live scene.  No knob changes a pixel.
-* A sequence of frames on N GPUs: the exchange of frame k may run on a second stream while frame k + 1 is rendered (`rtx_quantize_bgr8` on the render stream, an event,
-  `rtx_gather` on the other stream: `rendering_amd/parallel.py:FrameGather`, `bench.py --gpus N`); under row ownership `rtx_sobel` and `rtx_quantize_bgr8` touch the owned rows only.
-* A device's share of a frame has few SSAA work items per wave; the SSAA pixel list is then cut finer by itself (`ssaa_sparse_below`) -- nothing for the caller to do.
-* The OBJ loader reads the file in one piece (`host/src/objects.cpp`); a maintainer keeping the reference's `getline` / `sscanf` loop gets the same triangles, ~0.3 s later for 250 000 of them.
+int main(int argc, char** argv)
+{
+	if (argc != 7 || (strcmp(argv[1], "dump") && strcmp(argv[1], "render"))) {
+		fprintf(stderr, "usage: ref_binding dump|render <cwd> <scene> <width|0> <height|0> <out>\n");
+		return 2;
+	}
+	// options.h:23-37 defaults, quiet, no image pop-up
+	options::outputProgress = false; options::useBackfaceCulling = true; options::collectStatistics = false; options::enableOutput = false;
+	options::imageOutput = false; options::useAC = true; options::showAC = false; options::useSkybox = false; options::useTextures = true;
+	options::showNormals = false; options::enableSSAA = true;
+	char back[4096];
+	if (!getcwd(back, sizeof(back))) return 3;
+	const std::string out = argv[6][0] == '/' ? std::string(argv[6]) : std::string(back) + "/" + argv[6];
+	if (argv[2][0] && chdir(argv[2]) != 0) { fprintf(stderr, "cannot chdir to %s\n", argv[2]); return 3; }
+	Scene scene(argv[3]);
+	if (!scene.sceneLoadSuccess) { fprintf(stderr, "the reference's loader rejected %s\n", argv[3]); return 4; }
+	if (atoi(argv[4]) > 0) scene.options.width = (size_t)atoi(argv[4]);
+	if (atoi(argv[5]) > 0) scene.options.height = (size_t)atoi(argv[5]);
+	if (!strcmp(argv[1], "dump")) {
+		RtxUpload u;
+		fillDesc(scene, u);
+		size_t need = 0;
+		if (rtx_desc_serialize(&u.d, nullptr, 0, &need) != RTX_OK) { fprintf(stderr, "%s\n", rtx_last_error()); return 5; }
+		std::vector<char> buf(need);
+		if (rtx_desc_serialize(&u.d, buf.data(), buf.size(), &need) != RTX_OK) return 5;
+		FILE* f = fopen(out.c_str(), "wb");
+		if (!f || fwrite(buf.data(), 1, buf.size(), f) != buf.size()) { fprintf(stderr, "cannot write %s\n", out.c_str()); return 6; }
+		fclose(f);
+		return 0;
+	}
+	rtx_scene* g = uploadScene(scene);
+	std::vector<Vec3f> fbHost(scene.options.width * scene.options.height);
+	rtxLaunchWorkers(scene, g, fbHost.data());
+	rtxLaunchSSAA(scene, g, fbHost.data());
+	std::vector<uint8_t> bgr;
+	rtxRender(scene, g, bgr);
+	FILE* f = fopen(out.c_str(), "wb");
+	if (!f) return 6;
+	fwrite(bgr.data(), 1, bgr.size(), f);
+	fclose(f);
+	rtx_scene_destroy(g);
+	return 0;
+}

@@ -38,7 +38,7 @@ RTX_SYMBOLS = [
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
     "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
     "rtx_bvh_build", "rtx_bvh_info", "rtx_bvh_read", "rtx_bvh_destroy",
-    "rtx_vec_probe", "rtx_comm_unique_id", "rtx_comm_create", "rtx_comm_info", "rtx_comm_destroy", "rtx_comm_agree", "rtx_gather", "rtx_gather_plan",
+    "rtx_vec_probe", "rtx_desc_serialize", "rtx_comm_unique_id", "rtx_comm_create", "rtx_comm_info", "rtx_comm_destroy", "rtx_comm_agree", "rtx_gather", "rtx_gather_plan",
 ]
 
 
@@ -180,6 +180,24 @@ def bvh_build(tri_pos, root_lo, root_hi, ac_penalty=1, device=0):
         return d
     finally:
         rtx.rtx_bvh_destroy(b)
+
+
+def bvh_build_host(tri_pos, root_lo, root_hi, ac_penalty=1):
+    """The HOST builder (rendering_amd/host/src/objects.cpp) on a bare triangle array, in the dump layout of Scene.bvh(); no GPU."""
+    _, host = load()
+    pos = np.ascontiguousarray(tri_pos, np.float32).reshape(-1, 9)
+    lo = np.ascontiguousarray(root_lo, np.float32); hi = np.ascontiguousarray(root_hi, np.float32)
+    cnt = np.zeros(4, np.int64)
+    host.rah_bvh_from_tris.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 5
+    if host.rah_bvh_from_tris(_np_ptr(pos), pos.shape[0], _np_ptr(lo), _np_ptr(hi), ac_penalty, _np_ptr(cnt), None, None, None, None, None) != 0:
+        raise RtxError("rah_bvh_from_tris: %s" % host.rah_last_error().decode(errors="replace"))
+    nn, nl, nr, md = [int(x) for x in cnt]
+    d = dict(bounds=np.zeros((nn, 6), np.float32), skip=np.zeros(nn, np.int32), leaf_begin=np.zeros(nn, np.int32), leaf_count=np.zeros(nn, np.int32),
+             refs=np.zeros(max(nr, 1), np.uint32)[:nr])
+    host.rah_bvh_from_tris(_np_ptr(pos), pos.shape[0], _np_ptr(lo), _np_ptr(hi), ac_penalty, _np_ptr(cnt), _np_ptr(d["bounds"]), _np_ptr(d["skip"]),
+                           _np_ptr(d["leaf_begin"]), _np_ptr(d["leaf_count"]), _np_ptr(d["refs"]))
+    d.update(n_nodes=nn, n_leaves=nl, n_refs=nr, max_depth=md)
+    return d
 
 
 def gather_plan(height, band_height, n_parts, row_bytes, bottom_up=False):

@@ -1666,6 +1666,59 @@ int rtx_source_p_probe(const float* tris9, uint32_t n, const double* S3, double 
 
 int rtx_wide_node_slots(void) { return kWideSlots; }
 
+// Host only: the description as ONE canonical byte string -- every scalar and the contents of every array rtx_scene_create would read,
+// in declaration order, no pointers, no padding.  Two producers of descriptions (this repo's host, rendering_amd/host/src/scene.cpp flattenScene,
+// and the binding a maintainer adds to the reference, oracle/ref_binding.cpp = INTEGRATION.md) are compared through it byte for byte.
+int rtx_desc_serialize(const rtx_scene_desc* d, void* out, size_t cap, size_t* need)
+{
+	if (!d || !need) return fail(RTX_ERR_ARG, "desc/need is NULL");
+	size_t at = 0;
+	auto put = [&](const void* src, size_t bytes) {
+		if (out && src && at + bytes <= cap) memcpy((char*)out + at, src, bytes);
+		at += bytes;
+	};
+	auto put32 = [&](uint32_t v) { put(&v, 4); };
+	auto arr = [&](const void* p, size_t n, size_t elem) {      // presence, element count, contents
+		put32(p ? 1u : 0u);
+		const unsigned long long cnt = p ? n : 0;
+		put(&cnt, 8);
+		if (p) put(p, n * elem);
+	};
+	put("RTXD0001", 8);
+	static_assert(sizeof(rtx_view) == 4 * 29, "rtx_view has no padding");
+	put(&d->view, sizeof(rtx_view));
+	put32(d->n_objects);
+	static_assert(sizeof(rtx_object) == 4 * 18, "rtx_object has no padding");
+	if (d->n_objects && !d->objects) return fail(RTX_ERR_ARG, "objects is NULL");
+	put(d->objects, (size_t)d->n_objects * sizeof(rtx_object));
+	put32(d->n_meshes);
+	if (d->n_meshes && !d->meshes) return fail(RTX_ERR_ARG, "meshes is NULL");
+	for (uint32_t i = 0; i < d->n_meshes; i++) {
+		const rtx_mesh& m = d->meshes[i];
+		put32(m.n_nodes); put32(m.n_refs); put32(m.n_tris);
+		arr(m.node_bounds, (size_t)m.n_nodes * 6, 4); arr(m.node_skip, m.n_nodes, 4); arr(m.leaf_begin, m.n_nodes, 4); arr(m.leaf_count, m.n_nodes, 4);
+		arr(m.refs, m.n_refs, 4);
+		arr(m.tri_pos, (size_t)m.n_tris * 9, 4); arr(m.tri_nrm, (size_t)m.n_tris * 9, 4); arr(m.tri_uv, (size_t)m.n_tris * 6, 4);
+		// (tangent / bitangent are read only with a normal map: rtx_scene_create uploads them only then)
+		arr(m.normal_map ? m.tri_tb : nullptr, (size_t)m.n_tris * 6, 4);
+		put32(m.diffuse_map ? m.diffuse_w : 0u); put32(m.diffuse_map ? m.diffuse_h : 0u); arr(m.diffuse_map, (size_t)m.diffuse_w * m.diffuse_h * 3, 4);
+		put32(m.normal_map ? m.normal_w : 0u); put32(m.normal_map ? m.normal_h : 0u); arr(m.normal_map, (size_t)m.normal_w * m.normal_h * 3, 4);
+		put32(m.specular_map ? m.specular_w : 0u); put32(m.specular_map ? m.specular_h : 0u); arr(m.specular_map, (size_t)m.specular_w * m.specular_h, 4);
+	}
+	put32(d->n_lights);
+	if (d->n_lights && !d->lights) return fail(RTX_ERR_ARG, "lights is NULL");
+	for (uint32_t i = 0; i < d->n_lights; i++) {
+		const rtx_light& l = d->lights[i];
+		put32((uint32_t)l.type); put(l.color, 12); put(&l.intensity, 4); put(l.dir, 12); put(l.pos, 12);
+		arr(l.type == RTX_LIGHT_AREA ? l.points : nullptr, (size_t)l.n_points * 3, 4);
+	}
+	const bool sky = d->sky_w && d->sky_h && d->sky[0];
+	put32(sky ? d->sky_w : 0u); put32(sky ? d->sky_h : 0u);
+	for (int k = 0; k < 6; k++) arr(sky ? d->sky[k] : nullptr, (size_t)d->sky_w * d->sky_h * 3, 4);
+	*need = at;
+	return RTX_OK;
+}
+
 int rtx_mesh_flatten_probe(const rtx_mesh* m, uint32_t* n_wide, void* wide_out, void* prune_out, uint32_t cap_wide, float* root_rec8)
 {
 	if (!m || !n_wide) return fail(RTX_ERR_ARG, "mesh/n_wide is NULL");

@@ -116,6 +116,42 @@ int rah_bvh_dump(void* h, int obj, float* bounds, int32_t* skip, int32_t* leafBe
 	return 0;
 }
 
+// The host builder (AccelerationStructure::setup, objects.cpp:385-392 + 470-526 + 633-763 of the reference restated) on a bare triangle array:
+// pos = n x 9 floats (a, b, c), lo / hi = the root box, in the dump layout of rah_bvh_dump.  counts = {nodes, leaves, refs, maxDepth};
+// the arrays may be NULL to ask for the counts only (the structure is built twice then).  For the parity tests on the reference's own models
+// where the OBJ files are not at hand (tests/test_ref_models.py: the golden file keeps the triangles the reference's loader produced).
+int rah_bvh_from_tris(const float* pos, int n, const float* lo, const float* hi, int acPenalty, long long* counts,
+                      float* bounds, int32_t* skip, int32_t* leafBegin, int32_t* leafCount, uint32_t* refs)
+{
+	return guarded<int>(-1, [&]() -> int {
+		std::vector<Triangle> tris((size_t)n);
+		for (int i = 0; i < n; ++i) {
+			tris[i].a = Vec3f(pos[i * 9], pos[i * 9 + 1], pos[i * 9 + 2]); tris[i].b = Vec3f(pos[i * 9 + 3], pos[i * 9 + 4], pos[i * 9 + 5]);
+			tris[i].c = Vec3f(pos[i * 9 + 6], pos[i * 9 + 7], pos[i * 9 + 8]);
+		}
+		Options o; o.acPenalty = acPenalty;
+		const int keep = options::acBuildOnDevice;
+		options::acBuildOnDevice = 0;                       // the host builder
+		const bool quiet = options::enableOutput;
+		options::enableOutput = false;
+		AccelerationStructure ac;
+		ac.setBounds(Vec3f(lo[0], lo[1], lo[2]), Vec3f(hi[0], hi[1], hi[2]));
+		const bool ok = ac.setup(tris, o);
+		options::acBuildOnDevice = keep; options::enableOutput = quiet;
+		if (!ok) return -1;
+		counts[0] = (long long)ac.nodes.size(); counts[1] = (long long)ac.leafCount(); counts[2] = (long long)ac.refs.size(); counts[3] = ac.maxDepth;
+		if (!bounds) return 0;
+		for (size_t i = 0; i < ac.nodes.size(); ++i) {
+			const auto& nd = ac.nodes[i];
+			float* b = bounds + i * 6;
+			b[0] = nd.bounds[0].x; b[1] = nd.bounds[0].y; b[2] = nd.bounds[0].z; b[3] = nd.bounds[1].x; b[4] = nd.bounds[1].y; b[5] = nd.bounds[1].z;
+			skip[i] = nd.skip; leafBegin[i] = nd.leafBegin; leafCount[i] = nd.leafCount;
+		}
+		memcpy(refs, ac.refs.data(), ac.refs.size() * sizeof(uint32_t));
+		return 0;
+	});
+}
+
 // 30 floats per triangle: a b c n_a n_b n_c | t_a t_b t_c | tangent bitangent
 int rah_tris(void* h, int obj, float* out)
 {
