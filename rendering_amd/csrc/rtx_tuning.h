@@ -41,5 +41,5 @@
 #define RTX_SSAA_SPREAD_PX 4u   // pixels per wave for the tiles that were very slow in pass 1 (rtxSsaaCountKernel)
 #endif
 #ifndef RTX_BUNDLE_PAIRS
-#define RTX_BUNDLE_PAIRS 0      // makeBundle: 1 = waveMaxMin (two interleaved DPP chains per coordinate).  Rounds 2-4 shipped 0 without meaning to: the switch was
+#define RTX_BUNDLE_PAIRS 1      // makeBundle: 1 = waveMaxMin (two interleaved DPP chains per coordinate).  Rounds 2-4 shipped 0 without meaning to: the switch was
 #endif                          // tested (line 477) before it was defined (line 671) -- found when the switches were retired in round 5; A/B in profiles/r05_ab_*.txt
