@@ -344,6 +344,19 @@ class Scene:
         self.host.rah_scene_resize(self.h, width, height)
         self._dims()
 
+    def camera_pose(self):
+        """(position, rotation in degrees) of the camera (Camera::pos / Camera::rot)."""
+        pos, rot = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self.host.rah_camera_get.argtypes = [C.c_void_p] * 3
+        self.host.rah_camera_get(self.h, _np_ptr(pos), _np_ptr(rot))
+        return pos, rot
+
+    def set_camera(self, pos, rot):
+        """Moves the camera; the next render re-applies the view (rtx_scene_set_view: queued on the device, the host does not wait)."""
+        pos = np.ascontiguousarray(pos, np.float32); rot = np.ascontiguousarray(rot, np.float32)
+        self.host.rah_camera_set.argtypes = [C.c_void_p] * 3
+        self.host.rah_camera_set(self.h, _np_ptr(pos), _np_ptr(rot))
+
     def set_flag(self, name, value):
         self.host.rah_set_flag(self.h, name.encode(), int(value))
 

@@ -173,6 +173,8 @@ struct rtx_scene {
 	struct MeshLeaves { const float* boxes; uint32_t n; };      // 8 floats per non-empty leaf: true box lo, hi, reference count, -
 	std::vector<MeshLeaves> meshLeaves;
 	uint32_t* costGrid = nullptr; size_t costGridCap = 0;
+	uint8_t* needSlab = nullptr; size_t needStride = 0;           // rtx_render_frame in one launch: neighbour counts + completion counters of the cached lists
+	uint32_t* listSlab = nullptr; size_t listStride = 0;         // the buffers of the 16 cached tile lists: ONE allocation (a hipMalloc per new view cost the host 3 ms)
 	uint32_t* orderedList = nullptr; size_t orderedCap = 0;      // the tile list of the next launch in the order of rtxTileOrderKernel
 	bool costsUsable = false;
 	// source copies of the prune records (rtxd::PruneRec, rtx_source.hip): per mesh the copies' base, the reference arrays and the
@@ -186,6 +188,16 @@ struct rtx_scene {
 	float srcBuiltBias = -1.0f; bool srcLightsBuilt = false;
 	float srcBuiltCam[3] = { 0, 0, 0 }; bool srcCamBuilt = false;
 	// rtx_render_frame: event pairs around the last few frames, read back (without waiting) by later calls
+	// Preparing a view (source copies of the prune records, the cost estimate, the tile lists) is queued on the NULL stream and never waits for the
+	// device (ADVICE r3 A5 / VERDICT r4 item 2).  The legacy null stream orders itself against the caller's blocking streams; for a non-blocking render
+	// stream the two events below carry the order both ways: the preparation waits for the last render call, the next render call for the preparation.
+	hipStream_t lastRenderStream = nullptr; bool rendered = false;
+	hipEvent_t evRenderDone = nullptr, evPrepDone = nullptr; bool prepRecorded = false; hipStream_t prepSeenBy = nullptr;
+	// tile-list plans travel through a ring of pinned host buffers read by rtxTileListKernel (no staging copy, no synchronisation)
+	struct PlanSlot { uint32_t* host = nullptr; uint32_t* dev = nullptr; size_t capWords = 0; hipEvent_t done = nullptr; bool used = false, shared = false; };
+	uint32_t* planRingBase = nullptr;
+	PlanSlot planRing[8]; unsigned planNext = 0;
+	bool verifyLists = false;             // knob verify_lists: every list built on the device is read back and compared with the host's construction (tests)
 	struct FrameProbe { hipEvent_t a = nullptr, b = nullptr; int mode = -1; size_t queue = 0; uint32_t generation = 0; bool pending = false, refresh = false; };
 	FrameProbe probes[8];
 	unsigned probeNext = 0;
@@ -318,6 +330,31 @@ int ensureWork(rtx_scene* s)
 
 int prepareView(rtx_scene* s);
 
+// Order of the null-stream preparation work against the caller's render stream (see rtx_scene::lastRenderStream).
+int prepBegin(rtx_scene* s)
+{
+	if (s->rendered && s->lastRenderStream != nullptr) {
+		if (!s->evRenderDone) HIPCHK(hipEventCreateWithFlags(&s->evRenderDone, hipEventDisableTiming));
+		HIPCHK(hipEventRecord(s->evRenderDone, s->lastRenderStream));
+		HIPCHK(hipStreamWaitEvent(nullptr, s->evRenderDone, 0));
+	}
+	return RTX_OK;
+}
+int prepEnd(rtx_scene* s)
+{
+	if (!s->evPrepDone) HIPCHK(hipEventCreateWithFlags(&s->evPrepDone, hipEventDisableTiming));
+	HIPCHK(hipEventRecord(s->evPrepDone, nullptr));
+	s->prepRecorded = true; s->prepSeenBy = nullptr;
+	return RTX_OK;
+}
+// every entry point that launches on the caller's stream calls this first
+int renderOn(rtx_scene* s, hipStream_t st)
+{
+	if (st != nullptr && s->prepRecorded && s->prepSeenBy != st) { HIPCHK(hipStreamWaitEvent(st, s->evPrepDone, 0)); s->prepSeenBy = st; }
+	s->lastRenderStream = st; s->rendered = true;
+	return RTX_OK;
+}
+
 // The source copies of every mesh's prune records (rtx_source.hip): copy 1 for the camera of the current view, copy 2 + l for point
 // light l.  The camera's is rebuilt when the camera moved, the lights' when the bias changed (a shadow ray starts bias along the
 // shading normal off the surface, so it passes the light at that distance: sigma).  Part of setting the view, like the tile lists.
@@ -331,7 +368,7 @@ int buildSources(rtx_scene* s)
 	bool any = false;
 	for (const auto& sm : s->srcMeshes) any = any || sm.base;
 	if (!any) return RTX_OK;
-	HIPCHK(hipDeviceSynchronize());      // (a launch may still be reading the copies)
+	// (a launch may still be reading the copies: the null stream is ordered behind it -- prepBegin)
 	const uint32_t nLights = std::min<uint32_t>((uint32_t)s->srcLightPos.size(), kMaxSrcLights);
 	bool failed = false;      // (a copy that could not be reset must not be marked as built: it may hold an older camera's P)
 	for (const auto& sm : s->srcMeshes) {
@@ -360,7 +397,6 @@ int buildSources(rtx_scene* s)
 			}
 	}
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipDeviceSynchronize());
 	if (failed) { s->srcCamBuilt = false; s->srcLightsBuilt = false; return fail(RTX_ERR_DEVICE, "buildSources: a source copy of the prune records could not be reset"); }
 	memcpy(s->srcBuiltCam, v.camPos, 12); s->srcCamBuilt = true;
 	s->srcBuiltBias = v.bias; s->srcLightsBuilt = true;
@@ -390,7 +426,6 @@ int estimateCosts(rtx_scene* s)
 	hipLaunchKernelGGL(rtxCostFillKernel, dim3((tiles + 255) / 256), dim3(256), 0, nullptr, (const uint32_t*)s->costGrid, gridW, txFull, tyFull, s->tileCost,
 	                   s->knobs.costPerRef, s->knobs.costPerLeaf, s->knobs.costBase);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipDeviceSynchronize());
 	s->costsUsable = true;
 	return RTX_OK;
 }
@@ -839,6 +874,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 	if ((rc = setView(s, &desc->view))) return bail(rc);
 	if ((rc = ensureWork(s))) return bail(rc);
 	if ((rc = prepareView(s))) return bail(rc);
+	if ((rc = prepEnd(s))) return bail(rc);
 	s->sceneBytes = gUploadedBytes;
 	*out = s;
 	return RTX_OK;
@@ -852,11 +888,16 @@ void rtx_scene_destroy(rtx_scene* s)
 	for (void* p : s->owned) (void)hipFree(p);
 	if (s->frames) (void)hipFree(s->frames);
 	if (s->tileCost) { (void)hipFree(s->tileCost); (void)hipFree(s->items); }
-	for (auto& q : s->tileQueues) { if (q.list) (void)hipFree(q.list); if (q.need) (void)hipFree(q.need); if (q.countExpect) (void)hipFree(q.countExpect); }
+	if (s->needSlab) (void)hipFree(s->needSlab);
+	if (s->listSlab) (void)hipFree(s->listSlab);
 	if (s->tileDeps) (void)hipFree(s->tileDeps);
 	if (s->tileFlags) (void)hipFree(s->tileFlags);
 	if (s->tileClass) (void)hipFree(s->tileClass);
 	for (auto& pr : s->probes) { if (pr.a) (void)hipEventDestroy(pr.a); if (pr.b) (void)hipEventDestroy(pr.b); }
+	for (auto& sl : s->planRing) { if (sl.done) (void)hipEventDestroy(sl.done); if (sl.host && !sl.shared) (void)hipHostFree(sl.host); }
+	if (s->planRingBase) (void)hipHostFree(s->planRingBase);
+	if (s->evRenderDone) (void)hipEventDestroy(s->evRenderDone);
+	if (s->evPrepDone) (void)hipEventDestroy(s->evPrepDone);
 	if (s->ssaaQueue) (void)hipFree(s->ssaaQueue);
 	if (s->costGrid) (void)hipFree(s->costGrid);
 	if (s->orderedList) (void)hipFree(s->orderedList);
@@ -877,7 +918,9 @@ int rtx_scene_set_view(rtx_scene* s, const rtx_view* v)
 	s->viewSerial++;
 	s->lastFused.valid = false;
 	if ((rc = ensureWork(s))) return rc;
-	return prepareView(s);
+	if ((rc = prepBegin(s))) return rc;
+	if ((rc = prepareView(s))) return rc;
+	return prepEnd(s);
 }
 
 namespace {
@@ -918,7 +961,7 @@ bool stripsFit(const View& v) { return v.height <= 32768u && v.width <= 262144u;
 // that belongs to another device -- is listed as 64 x 1 pixel strips (0x10000000 | strip << 16 | y) instead of 8 x 8
 // tiles with one live row each: a wave's time goes into walking its bundle whatever the number of live lanes, and the
 // halo rows are a quarter of the tile rows of a 64-row band.
-int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t tilesX, uint32_t tileRow0, uint32_t tilesY, rtx_scene::TileQueues** out, bool strips = false)
+int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t tilesX, uint32_t tileRow0, uint32_t tilesY, rtx_scene::TileQueues** out, bool strips = false, hipStream_t st = nullptr)
 {
 	const Params& p = s->params;
 	if (!stripsFit(p.view)) strips = false;
@@ -945,7 +988,19 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 	};
 	uint32_t rect[4];
 	meshTileRect(s, tilesX, (H + 7) / 8, rect);
-	std::vector<uint32_t> q[8][2];
+	// The plan: per tile row what it is listed as, its queue and class bases (rtx_kernels.hip, rtxTileListKernel).  O(rows) here, the entries are written
+	// on the device -- a new view used to cost the host a loop over every tile (262 144 at 4096^2) and a synchronous 1-MB copy.
+	const uint32_t W1 = p.view.width - 1;                        // (the last column is never rendered)
+	const uint32_t nStrips = (W1 + 63) / 64;
+	const uint32_t in0 = std::min(rect[0], tilesX), in1 = std::min(rect[1], tilesX);
+	uint32_t sIn0 = nStrips, sIn1 = 0;                            // strips sx with min(sx * 8 + 8, tilesX) > rect[0] && sx * 8 < rect[1]: a contiguous range
+	for (uint32_t sx = 0; sx < nStrips; sx++) {
+		const uint32_t tx0 = sx * 8, tx1 = std::min(tx0 + 8, tilesX);
+		if (tx1 > rect[0] && tx0 < rect[1]) { sIn0 = std::min(sIn0, sx); sIn1 = std::max(sIn1, sx + 1); }
+	}
+	std::vector<uint32_t> plan(16 + 4 * (size_t)tilesY, 0u);
+	uint32_t cnt[8][2] = {};
+	std::vector<uint8_t> rowQueue(tilesY);
 	for (uint32_t t = 0; t < tilesY; t++) {
 		const uint32_t ty = tileRow0 + t;
 		uint32_t live = 0, only = 0;
@@ -962,40 +1017,107 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 			xq = ((b / p.nParts) * (p.bandH / 64 ? p.bandH / 64 : 1) + (only % p.bandH) / 64) & 7u;
 		}
 		const bool inY = ty >= rect[2] && ty < rect[3];
-		if (strips && live == 1) {
-			const uint32_t W1 = p.view.width - 1;      // (the last column is never rendered)
-			for (uint32_t sx = 0; sx * 64 < W1; sx++) {
-				const uint32_t tx0 = sx * 8, tx1 = std::min(tx0 + 8, tilesX);
-				q[xq][(inY && tx1 > rect[0] && tx0 < rect[1]) ? 0 : 1].push_back(0x10000000u | sx << 16 | only);
-			}
-			continue;
-		}
-		for (uint32_t tx = 0; tx < tilesX; tx++) q[xq][(inY && tx >= rect[0] && tx < rect[1]) ? 0 : 1].push_back(ty << 16 | tx);
+		const bool strip = strips && live == 1;
+		const uint32_t n = strip ? nStrips : tilesX;
+		const uint32_t nIn = !inY ? 0u : (strip ? (sIn1 > sIn0 ? sIn1 - sIn0 : 0u) : (in1 > in0 ? in1 - in0 : 0u));
+		plan[16 + 4 * t] = (strip ? 2u : 1u) | (inY ? 0x100u : 0u);
+		plan[17 + 4 * t] = strip ? only : ty;
+		plan[18 + 4 * t] = cnt[xq][0]; plan[19 + 4 * t] = cnt[xq][1];      // (relative to the class: made absolute below)
+		cnt[xq][0] += nIn; cnt[xq][1] += n - nIn;
+		rowQueue[t] = (uint8_t)xq;
 	}
-	std::vector<uint32_t> list(16);
-	for (int x = 0; x < 8; x++) {
-		list[x] = (uint32_t)list.size();
-		list[8 + x] = (uint32_t)(q[x][0].size() + q[x][1].size());
-		list.insert(list.end(), q[x][0].begin(), q[x][0].end());
-		list.insert(list.end(), q[x][1].begin(), q[x][1].end());
+	uint32_t qBase[8], total = 16;
+	for (int x = 0; x < 8; x++) { qBase[x] = total; plan[x] = total; plan[8 + x] = cnt[x][0] + cnt[x][1]; total += cnt[x][0] + cnt[x][1]; }
+	for (uint32_t t = 0; t < tilesY; t++) {
+		if (!plan[16 + 4 * t]) continue;
+		const uint32_t x = rowQueue[t];
+		plan[18 + 4 * t] += qBase[x]; plan[19 + 4 * t] += qBase[x] + cnt[x][0];
 	}
-	HIPCHK(hipDeviceSynchronize());      // an earlier launch may still be reading the list that is recycled
-	if (list.size() > e->cap) {
-		if (e->list) HIPCHK(hipFree(e->list));
-		e->list = nullptr; e->cap = 0;
-		HIPCHK(hipMalloc((void**)&e->list, list.size() * sizeof(uint32_t)));
-		e->cap = list.size();
+	const size_t listWords = total;
+	if (listWords > s->listStride) {
+		HIPCHK(hipDeviceSynchronize());      // (growing: an earlier launch may still be reading the buffer that is freed)
+		if (s->listSlab) HIPCHK(hipFree(s->listSlab));
+		s->listSlab = nullptr; s->listStride = 0;
+		for (auto& q : s->tileQueues) { q.list = nullptr; q.key.clear(); q.costValid = false; }      // every cached list lived in the old slab
+		const size_t stride = (listWords + (listWords >> 3) + 4095) & ~(size_t)4095;
+		HIPCHK(hipMalloc((void**)&s->listSlab, 16 * stride * sizeof(uint32_t)));
+		s->listStride = stride;
 	}
+	e->list = s->listSlab + (size_t)(e - s->tileQueues.data()) * s->listStride;
+	e->cap = s->listStride;
 	// the ordered copy, where every tile may be listed in sixteen parts: ONE buffer per scene, shared by the cached lists (the
 	// launch that consumes it follows the ordering kernels on the same stream)
-	if (16 * list.size() > s->orderedCap) {
+	if (16 * listWords > s->orderedCap) {
+		HIPCHK(hipDeviceSynchronize());
 		if (s->orderedList) HIPCHK(hipFree(s->orderedList));
 		s->orderedList = nullptr; s->orderedCap = 0;
-		HIPCHK(hipMalloc((void**)&s->orderedList, 16 * list.size() * sizeof(uint32_t)));
-		s->orderedCap = 16 * list.size();
+		HIPCHK(hipMalloc((void**)&s->orderedList, 16 * listWords * sizeof(uint32_t)));
+		s->orderedCap = 16 * listWords;
 	}
-	HIPCHK(hipMemcpy(e->list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	e->listed = (uint32_t)(list.size() - 16);
+	// The plan goes through a ring of pinned host buffers the kernel reads directly; a slot is taken again eight lists later (its event says whether the
+	// kernel that read it has run: it has, unless eight views were set without the device getting a turn).  The list that is recycled may still be read
+	// by an earlier launch: the kernel runs on the stream of the caller (or the null stream: prepareView), behind it.
+	{
+		if (!s->planRing[0].host) {
+			// all eight slots in one pinned allocation, on first use (rtx_scene_create: not on the path of a new view), each good for 2 048 tile rows
+			const size_t each = 16 + 4 * 2048;
+			uint32_t* hostAll = nullptr; uint32_t* devAll = nullptr;
+			HIPCHK(hipHostMalloc((void**)&hostAll, 8 * each * sizeof(uint32_t), hipHostMallocMapped));
+			HIPCHK(hipHostGetDevicePointer((void**)&devAll, hostAll, 0));
+			for (int k = 0; k < 8; k++) {
+				s->planRingBase = hostAll;
+				s->planRing[k].host = hostAll + k * each; s->planRing[k].dev = devAll + k * each; s->planRing[k].capWords = each; s->planRing[k].shared = true;
+				HIPCHK(hipEventCreateWithFlags(&s->planRing[k].done, hipEventDisableTiming));
+			}
+		}
+		rtx_scene::PlanSlot& slot = s->planRing[s->planNext++ & 7u];
+		if (slot.used) HIPCHK(hipEventSynchronize(slot.done));
+		if (plan.size() > slot.capWords) {
+			if (slot.shared) { slot.host = nullptr; slot.shared = false; }      // (a slot of the common allocation is simply left behind: freed with slot 0)
+			if (slot.host) HIPCHK(hipHostFree(slot.host));
+			slot.host = nullptr; slot.capWords = 0;
+			const size_t want = std::max<size_t>(plan.size(), 16 + 4 * 1100);
+			HIPCHK(hipHostMalloc((void**)&slot.host, want * sizeof(uint32_t), hipHostMallocMapped));
+			HIPCHK(hipHostGetDevicePointer((void**)&slot.dev, slot.host, 0));
+			slot.capWords = want;
+		}
+		if (!slot.done) HIPCHK(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+		memcpy(slot.host, plan.data(), plan.size() * sizeof(uint32_t));
+		const uint32_t cols = std::max(std::max(tilesX, nStrips), 16u);
+		hipLaunchKernelGGL(rtxTileListKernel, dim3((cols + 255) / 256, std::max(tilesY, 1u)), dim3(256), 0, st, (const uint32_t*)slot.dev, tilesX, nStrips, in0, in1, sIn0, sIn1, e->list);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(slot.done, st));
+		slot.used = true;
+	}
+	if (s->verifyLists) {
+		// (tests: the straightforward construction on the host -- one entry after the other, the way rounds 1-4 built the list -- against what the device wrote)
+		std::vector<uint32_t> q[8][2];
+		for (uint32_t t = 0; t < tilesY; t++) {
+			const uint32_t kind = plan[16 + 4 * t];
+			if (!kind) continue;
+			const uint32_t xq = rowQueue[t], val = plan[17 + 4 * t];
+			const bool inY = (kind & 0x100u) != 0;
+			if ((kind & 0xffu) == 2u)
+				for (uint32_t sx = 0; sx * 64 < W1; sx++) {
+					const uint32_t tx0 = sx * 8, tx1 = std::min(tx0 + 8, tilesX);
+					q[xq][(inY && tx1 > rect[0] && tx0 < rect[1]) ? 0 : 1].push_back(0x10000000u | sx << 16 | val);
+				}
+			else for (uint32_t tx = 0; tx < tilesX; tx++) q[xq][(inY && tx >= rect[0] && tx < rect[1]) ? 0 : 1].push_back(val << 16 | tx);
+		}
+		std::vector<uint32_t> want(16), got(listWords);
+		for (int x = 0; x < 8; x++) {
+			want[x] = (uint32_t)want.size();
+			want[8 + x] = (uint32_t)(q[x][0].size() + q[x][1].size());
+			want.insert(want.end(), q[x][0].begin(), q[x][0].end());
+			want.insert(want.end(), q[x][1].begin(), q[x][1].end());
+		}
+		HIPCHK(hipStreamSynchronize(st));
+		HIPCHK(hipMemcpy(got.data(), e->list, listWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		if (want != got) return fail(RTX_ERR_DEVICE, "buildTileList: the list written on the device differs from the host's construction");
+	}
+	const std::vector<uint32_t>& list = plan;      // (only its size is used below)
+	(void)list;
+	e->listed = (uint32_t)(listWords - 16);
 	e->needValid = false;      // (computed on the device when the single launch first uses this list: renderFrameFused)
 	e->key = key;
 	e->lastUse = ++s->tileUse;
@@ -1068,6 +1190,7 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	int rc = ensureWork(s);
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream;
+	if (int ro = renderOn(s, st)) return ro;
 	Params p = s->params;
 	p.fb = fb_dev;
 	p.rowBegin = rowBegin; p.rowEnd = rowEnd;
@@ -1148,14 +1271,22 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	if ((rc = ensureFrameBuffers(s, tiles, &perQueue))) return rc;
 	if (!tq->needValid) {
 		// once per tile list, on the device: the listed tiles around every tile and the expected values of the completion counters
-		if (tiles > tq->needCap) {
+		// (the 16 cached lists share one allocation: per entry `needStride` bytes of neighbour counts, then 66 counters)
+		if (tiles > s->needStride) {
 			HIPCHK(hipDeviceSynchronize());
-			if (tq->need) HIPCHK(hipFree(tq->need));
-			tq->need = nullptr; tq->needCap = 0;
-			HIPCHK(hipMalloc((void**)&tq->need, tiles));
-			tq->needCap = tiles;
+			if (s->needSlab) HIPCHK(hipFree(s->needSlab));
+			s->needSlab = nullptr; s->needStride = 0;
+			for (auto& q : s->tileQueues) { q.need = nullptr; q.countExpect = nullptr; q.needValid = false; }
+			const size_t stride = (tiles + 4095) & ~(size_t)4095;
+			HIPCHK(hipMalloc((void**)&s->needSlab, 16 * (stride + 512)));
+			s->needStride = stride;
 		}
-		if (!tq->countExpect) HIPCHK(hipMalloc((void**)&tq->countExpect, 66 * sizeof(uint32_t)));
+		{
+			const size_t idx = (size_t)(tq - s->tileQueues.data());
+			tq->need = s->needSlab + idx * (s->needStride + 512);
+			tq->countExpect = (uint32_t*)(tq->need + s->needStride);
+			tq->needCap = s->needStride;
+		}
 		HIPCHK(hipMemsetAsync(s->tileClass, 0, tiles, st));      // (scratch here: the marks; the classes are written later)
 		HIPCHK(hipMemsetAsync(tq->countExpect, 0, 66 * sizeof(uint32_t), st));
 		hipLaunchKernelGGL(rtxTileMarkKernel, dim3(64, 8), dim3(256), 0, st, (const uint32_t*)tq->list, p.tilesXFull, s->tileClass);
@@ -1236,6 +1367,7 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	int rc = ensureWork(s);
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream;
+	if (int ro = renderOn(s, st)) return ro;
 	const uint32_t lastRow = (rowEnd < H - 1 ? rowEnd : H - 1);
 	rtx_scene::TileQueues* tq = nullptr;
 	if (lastRow > rowBegin) {
@@ -1327,6 +1459,7 @@ int rtx_set_knob(rtx_scene* s, const char* name, double value)
 	else if (n == "ssaa_local_below") k.localBelow = (long long)value;
 	else if (n == "ssaa_sparse_below") k.sparseBelow = (long long)value;
 	else if (n == "frame_queue_cap") k.frameQueueCap = (uint32_t)value;
+	else if (n == "verify_lists") s->verifyLists = value != 0;
 	else if (n == "frame_rule_tiles") k.frameRuleTiles = value >= 4294967295.0 ? 0xffffffffu : (uint32_t)value;
 	else if (n == "frame_rule_tiles_analytic") k.frameRuleTilesAnalytic = value >= 4294967295.0 ? 0xffffffffu : (uint32_t)value;
 	else if (n == "debug_items") k.debugItems = value != 0;
@@ -1408,6 +1541,7 @@ int rtx_sobel(rtx_scene* s, const float* fb_dev, uint32_t rowBegin, uint32_t row
 	int rc = ensureWork(s);
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream;
+	if (int ro = renderOn(s, st)) return ro;
 	if ((rc = stamp(s, 1, st))) return rc;
 	dim3 grid((W + 61) / 62, (rowEnd - rowBegin + 4 * kSobelRows - 1) / (4 * kSobelRows));      // (a wave: 62 columns x kSobelRows rows)
 	hipLaunchKernelGGL(rtxSobelKernel, grid, dim3(256), 0, st, fb_dev, mask_dev, W, H, rowBegin, rowEnd,
@@ -1427,6 +1561,7 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	int rc = ensureWork(s);
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream;
+	if (int ro = renderOn(s, st)) return ro;
 	// (work[1], the queue head, and work[10], the slot budget used, are zeroed by rtxSsaaScatterKernel; [8], [9]: the layout
 	// decision and its count, see below)
 	if ((uint32_t)s->tileCap < s->params.tilesXFull * ((H + 7) / 8) || W > 0xffffu || H > 0xffffu) return fail(RTX_ERR_ARG, "frame too large for the SSAA pixel list");
@@ -1486,6 +1621,7 @@ int rtx_quantize_bgr8(rtx_scene* s, const float* fb_dev, uint8_t* bgr_dev, void*
 	HIPCHK(hipSetDevice(s->device));
 	if (((uintptr_t)fb_dev & 15u) || ((uintptr_t)bgr_dev & 3u)) return fail(RTX_ERR_ARG, "rtx_quantize_bgr8: fb must be 16-byte aligned, the image 4-byte aligned");
 	const size_t n = (size_t)(W / 4) * H;
+	if (int ro = renderOn(s, (hipStream_t)stream)) return ro;
 	hipLaunchKernelGGL(rtxQuantizeKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fb_dev, bgr_dev, W, H,
 	                   s->params.bandH, s->params.nParts, s->params.part);
 	HIPCHK(hipGetLastError());

@@ -1825,6 +1825,32 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 // rtx_render_frame, once per tile list: which tiles are listed (mark), then for every listed tile the number of listed
 // tiles in its 3x3 neighbourhood, itself included (need; 0 = not listed), the number of listed tiles by index % 64
 // (expect[k]) and how many of those are not zero (expect[64]; the last block to finish counts them).
+// The eight pass-1 queues of a view, written on the device from a per-tile-row PLAN (rtx_api.hip, buildTileList: what a tile row is listed as, its
+// queue and where its entries start -- O(rows) on the host, read here straight from pinned host memory): words [0, 16) of the plan are the list's
+// header, then four words per tile row -- kind (0 not listed, 1 tiles, 2 the 64 x 1 strips of one pixel row; bit 8: the row crosses the meshes' tile
+// rectangle), ty or y, first entry of the row's tiles inside the rectangle, first entry of those outside (the queues list the tiles that can see
+// a mesh first).  in0 / in1: the columns (tiles, or strips for kind 2: sIn0 / sIn1) inside the rectangle.  One thread per tile or strip.
+__global__ void __launch_bounds__(256) rtxTileListKernel(const uint32_t* __restrict__ plan, uint32_t tilesX, uint32_t nStrips, uint32_t in0, uint32_t in1,
+                                                         uint32_t sIn0, uint32_t sIn1, uint32_t* __restrict__ list)
+{
+	const uint32_t row = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (row == 0 && c < 16) list[c] = plan[c];
+	const uint32_t kind = plan[16 + 4 * row], val = plan[17 + 4 * row], base0 = plan[18 + 4 * row], base1 = plan[19 + 4 * row];
+	const bool inY = (kind & 0x100u) != 0;
+	if ((kind & 0xffu) == 1u) {
+		if (c >= tilesX) return;
+		const uint32_t nIn = inY && in1 > in0 ? in1 - in0 : 0u;
+		const bool in = nIn != 0 && c >= in0 && c < in1;
+		list[in ? base0 + (c - in0) : base1 + (nIn != 0 && c >= in1 ? c - nIn : c)] = val << 16 | c;
+	}
+	else if ((kind & 0xffu) == 2u) {
+		if (c >= nStrips) return;
+		const uint32_t nIn = inY && sIn1 > sIn0 ? sIn1 - sIn0 : 0u;
+		const bool in = nIn != 0 && c >= sIn0 && c < sIn1;
+		list[in ? base0 + (c - sIn0) : base1 + (nIn != 0 && c >= sIn1 ? c - nIn : c)] = 0x10000000u | c << 16 | val;
+	}
+}
+
 __global__ void __launch_bounds__(256) rtxTileMarkKernel(const uint32_t* __restrict__ list, uint32_t tilesXFull, uint8_t* __restrict__ mark)
 {
 	const uint32_t q = blockIdx.y, base = list[q], n = list[8 + q];

@@ -59,6 +59,19 @@ void rah_scene_resize(void* h, int w, int ht)
 	s->options.width = (size_t)w; s->options.height = (size_t)ht;
 	s->invalidateView();
 }
+// Moves the camera (position, Euler angles in degrees: Camera::pos / Camera::rot, scene.h:52-66); the next use re-applies the view (rtx_scene_set_view).
+void rah_camera_set(void* h, const float* pos3, const float* rot3)
+{
+	Scene* s = (Scene*)h;
+	s->camera.pos = Vec3f(pos3[0], pos3[1], pos3[2]); s->camera.rot = Vec3f(rot3[0], rot3[1], rot3[2]);
+	s->camera.cameraRotated = false;
+	s->invalidateView();
+}
+void rah_camera_get(void* h, float* pos3, float* rot3)
+{
+	Scene* s = (Scene*)h;
+	pos3[0] = s->camera.pos.x; pos3[1] = s->camera.pos.y; pos3[2] = s->camera.pos.z; rot3[0] = s->camera.rot.x; rot3[1] = s->camera.rot.y; rot3[2] = s->camera.rot.z;
+}
 void rah_scene_set_device(void* h, int device) { ((Scene*)h)->device = device; }
 void rah_set_flag(void* h, const char* name, int v)
 {
