@@ -107,6 +107,7 @@ struct Knobs {
 	bool sources = true;                 // RTX_NO_SRC: no source copies of the prune records (every walk uses copy 0)
 	int pruneBoxes = -1;                 // RTX_PRUNE_BOXES=0|1: the kernels without / with the box test whatever the triangle sizes (-1: by the meshes)
 	bool estimate = true;                // RTX_NO_COST_ESTIMATE: no first-frame cost estimate
+	bool estimateShadows = true;         // RTX_NO_SHADOW_ESTIMATE / knob estimate_shadows: the leaves' shadows on the planes are not part of it
 	float costPerRef = 2.0f, costPerLeaf = 95.0f, costBase = 6100.0f;   // estimate = base + perRef refs + perLeaf leaves (100 MHz ticks per tile; tools/cost_fit.py on the final round-4 kernels: profiles/r04_cost_fit.txt)
 	float fatFactor = 3.0f;              // RTX_FAT_FACTOR: bundle width, in mean triangle edges, above which a bundle is split; 0 = never
 	uint32_t stripLimit = 100000u;       // RTX_STRIP_LIMIT: a halo strip slower than this (100 MHz ticks) is listed as tiles again
@@ -182,6 +183,8 @@ struct rtx_scene {
 	struct SrcMesh { PruneBlock* base = nullptr; uint32_t nWide = 0, nRefs = 0; const RefA* refA = nullptr; const RefB* refB = nullptr; const RefC* refC = nullptr;
 	                 const uint32_t* slotRange = nullptr; float* refP = nullptr; float* blockP = nullptr; float vmax = 0; uint32_t meshIndex = 0; };
 	std::vector<SrcMesh> srcMeshes;
+	std::vector<std::array<float, 4>> estLights;        // first-frame estimate: point lights (x, y, z, 2) and distant lights (direction, 1)
+	std::vector<std::array<float, 6>> estPlanes;        // ... and the planes they cast the meshes' shadows on (position, normal)
 	std::vector<std::array<float, 3>> srcLightPos;      // [l]: position of light l (point lights only count below nSrcLights)
 	std::vector<uint8_t> srcLightIsPoint;
 	float srcNmax = 1.0f;                 // the longest shading normal a shadow ray's origin is offset along (planes keep theirs un-normalised)
@@ -230,6 +233,7 @@ void readKnobs(Knobs& k)
 	k.sources = !getenv("RTX_NO_SRC");
 	k.pruneBoxes = (int)num("RTX_PRUNE_BOXES", -1);
 	k.estimate = !getenv("RTX_NO_COST_ESTIMATE");
+	k.estimateShadows = !getenv("RTX_NO_SHADOW_ESTIMATE");
 	if (const char* e = getenv("RTX_COST_COEFFS")) sscanf(e, "%f,%f,%f", &k.costPerRef, &k.costPerLeaf, &k.costBase);
 	if (const char* e = getenv("RTX_FAT_FACTOR")) k.fatFactor = strtof(e, nullptr);
 	k.stripLimit = (uint32_t)num("RTX_STRIP_LIMIT", k.stripLimit);
@@ -422,6 +426,16 @@ int estimateCosts(rtx_scene* s)
 	HIPCHK(hipMemsetAsync(s->costGrid, 0, 2 * cells * sizeof(uint32_t), nullptr));
 	for (const auto& m : s->meshLeaves)
 		if (m.n) hipLaunchKernelGGL(rtxCostSplatKernel, dim3((m.n + 255) / 256), dim3(256), 0, nullptr, m.boxes, m.n, v, gridW, gridH, s->costGrid);
+	// the leaves' shadows on the planes, per point / distant light (rtxCostShadowSplatKernel); a handful of launches of a few microseconds
+	if (s->knobs.estimateShadows)
+		for (size_t l = 0; l < s->estLights.size() && l < 8; l++)
+			for (size_t q = 0; q < s->estPlanes.size() && q < 4; q++)
+				for (const auto& m : s->meshLeaves) {
+					if (!m.n) continue;
+					const auto& L = s->estLights[l]; const auto& P = s->estPlanes[q];
+					hipLaunchKernelGGL(rtxCostShadowSplatKernel, dim3((m.n + 255) / 256), dim3(256), 0, nullptr, m.boxes, m.n, v, gridW, gridH, s->costGrid,
+					                   (int)L[3], L[0], L[1], L[2], P[0], P[1], P[2], P[3], P[4], P[5]);
+				}
 	const uint32_t tiles = txFull * tyFull;
 	hipLaunchKernelGGL(rtxCostFillKernel, dim3((tiles + 255) / 256), dim3(256), 0, nullptr, (const uint32_t*)s->costGrid, gridW, txFull, tyFull, s->tileCost,
 	                   s->knobs.costPerRef, s->knobs.costPerLeaf, s->knobs.costBase);
@@ -801,6 +815,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		if (o.type == RTX_OBJ_MESH && (o.mesh < 0 || (uint32_t)o.mesh >= desc->n_meshes)) return bail(fail(RTX_ERR_ARG, "bad mesh index"));
 		if (o.type == RTX_OBJ_MESH) s->analytic = false;
 		if (o.type == RTX_OBJ_PLANE) {
+			s->estPlanes.push_back({ { o.pos[0], o.pos[1], o.pos[2], o.normal[0], o.normal[1], o.normal[2] } });
 			const double nl = std::sqrt((double)o.normal[0] * o.normal[0] + (double)o.normal[1] * o.normal[1] + (double)o.normal[2] * o.normal[2]);
 			if (!(nl <= 1e30)) s->srcNmax = INFINITY; else s->srcNmax = std::max(s->srcNmax, (float)(nl * 1.000001));
 		}
@@ -849,6 +864,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		d.nPoints = l.n_points;
 		s->srcLightPos.push_back({ { l.pos[0], l.pos[1], l.pos[2] } });
 		s->srcLightIsPoint.push_back(l.type == RTX_LIGHT_POINT ? 1 : 0);
+		if (l.type == RTX_LIGHT_POINT) s->estLights.push_back({ { l.pos[0], l.pos[1], l.pos[2], 2.0f } });
+		else if (l.type == RTX_LIGHT_DISTANT) s->estLights.push_back({ { l.dir[0], l.dir[1], l.dir[2], 1.0f } });
 		if (l.type == RTX_LIGHT_AREA) {
 			if (!l.points || l.n_points == 0) return bail(fail(RTX_ERR_ARG, "area light without sample points"));
 			int rc;

@@ -1938,6 +1938,47 @@ __global__ void __launch_bounds__(256) rtxCostSplatKernel(const float* __restric
 		}
 }
 
+// The lights' side of the estimate (round 5): a tile of a PLANE that lies in the shadow of a leaf -- as seen from a point or distant light -- sends its shadow
+// rays through that leaf (scene.cpp:787), and where they graze the mesh's silhouette such floor tiles cost as much as mesh tiles (up to 0.5 ms at the headline)
+// while the camera's splat gives them 0: they ran last, four per atomic, and were the first frame's tail.  Every leaf box is projected from the light onto the
+// plane and from there through the camera; its references are added to the cells the shadow's rectangle touches.  lightKind 1: distant (lp = the direction the
+// light travels in), 2: point (lp = position).
+__global__ void __launch_bounds__(256) rtxCostShadowSplatKernel(const float* __restrict__ boxes, uint32_t nLeaves, const View view, uint32_t gridW, uint32_t gridH,
+                                                                uint32_t* __restrict__ grid, int lightKind, float lx, float ly, float lz,
+                                                                float px, float py, float pz, float nx, float ny, float nz)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nLeaves) return;
+	const float* b = boxes + (size_t)i * 8;
+	const uint32_t n = (uint32_t)b[6];
+	const float* M = view.camM;
+	float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f;
+	for (int c = 0; c < 8; ++c) {
+		const float cx = b[(c & 1) ? 3 : 0], cy = b[(c & 2) ? 4 : 1], cz = b[(c & 4) ? 5 : 2];
+		// where the light's ray through this corner meets the plane (beyond the corner, or the leaf casts no bounded shadow on it)
+		const float dx = lightKind == 2 ? cx - lx : lx, dy = lightKind == 2 ? cy - ly : ly, dz = lightKind == 2 ? cz - lz : lz;
+		const float den = dx * nx + dy * ny + dz * nz;
+		if (!(fabsf(den) > 1e-6f)) return;
+		const float t = ((px - cx) * nx + (py - cy) * ny + (pz - cz) * nz) / den;
+		if (!(t > 0.0f) || !(t < 1e4f)) return;
+		const float qx = cx + t * dx - view.camPos[0], qy = cy + t * dy - view.camPos[1], qz = cz + t * dz - view.camPos[2];
+		const float sx = qx * M[0] + qy * M[1] + qz * M[2], sy = qx * M[4] + qy * M[5] + qz * M[6], sz = qx * M[8] + qy * M[9] + qz * M[10];
+		if (!(sz < -1e-4f)) return;
+		const float xp = sx / -sz, yp = sy / -sz;
+		const float fx = (xp / (view.scale * view.aspect) + 1.0f) * 0.5f * (float)view.width - 1.0f, fy = (-yp / view.scale + 1.0f) * 0.5f * (float)view.height - 1.0f;
+		x0 = fminf(x0, fx); x1 = fmaxf(x1, fx); y0 = fminf(y0, fy); y1 = fmaxf(y1, fy);
+	}
+	if (!(x1 >= 0.0f && y1 >= 0.0f && x0 < (float)view.width && y0 < (float)view.height)) return;
+	const int cx0 = max(0, (int)floorf(x0 / 16.0f)), cx1 = min((int)gridW - 1, (int)floorf(x1 / 16.0f));
+	const int cy0 = max(0, (int)floorf(y0 / 16.0f)), cy1 = min((int)gridH - 1, (int)floorf(y1 / 16.0f));
+	if ((long long)(cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 4096) return;
+	for (int cy = cy0; cy <= cy1; ++cy)
+		for (int cx = cx0; cx <= cx1; ++cx) {
+			atomicAdd(grid + 2 * ((size_t)cy * gridW + cx), n);
+			atomicAdd(grid + 2 * ((size_t)cy * gridW + cx) + 1, 1u);
+		}
+}
+
 __global__ void __launch_bounds__(256) rtxCostFillKernel(const uint32_t* __restrict__ grid, uint32_t gridW, uint32_t tilesXFull, uint32_t tilesYFull,
                                                          uint32_t* __restrict__ tileCost, float perRef, float perLeaf, float base)
 {

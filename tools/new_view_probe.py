@@ -11,7 +11,7 @@ fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"); mask = torch.ze
 for _ in range(4): g.render_frame(fb, mask)
 torch.cuda.synchronize()
 pos, rot = g.camera_pose()
-host, dev = [], []
+host, dev, stages, warm = [], [], [], []
 for k in range(8):
     for _ in range(2): g.render_frame(fb, mask)
     t0 = time.perf_counter()
@@ -21,7 +21,12 @@ for k in range(8):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.render_frame(fb, mask); e1.record(); torch.cuda.synchronize()
     dev.append(e0.elapsed_time(e1))
+    stages.append((g.last_kernel_ms(0), g.last_kernel_ms(1), g.last_kernel_ms(2)))
+    g.render_frame(fb, mask); torch.cuda.synchronize()
+    warm.append((g.last_kernel_ms(0), g.last_kernel_ms(1), g.last_kernel_ms(2)))
     assert g.frame_status() == 0
 print("new view, host ms per rtx_scene_set_view:", " ".join("%.3f" % x for x in host))
 print("first frame of each new view, ms (HIP events):", " ".join("%.3f" % x for x in dev))
+print("   its stages (pass 1, Sobel, SSAA; three-launch frames only):", " ".join("%.3f/%.3f/%.3f" % x for x in stages))
+print("   the second frame of the view:", " ".join("%.3f/%.3f/%.3f" % x for x in warm))
 t0 = time.perf_counter(); g.resize(W, H); g.gpu(); print("same view again: %.3f ms" % ((time.perf_counter() - t0) * 1e3))
