@@ -437,8 +437,14 @@ int estimateCosts(rtx_scene* s)
 					                   (int)L[3], L[0], L[1], L[2], P[0], P[1], P[2], P[3], P[4], P[5]);
 				}
 	const uint32_t tiles = txFull * tyFull;
+	FarPlanes far;
+	memset(&far, 0, sizeof(far));
+	if (s->knobs.estimateShadows) {      // (the horizon of a plane: rtxCostFillKernel)
+		for (size_t q = 0; q < s->estPlanes.size() && q < 4; q++) memcpy(far.p[far.n++], s->estPlanes[q].data(), 24);
+		far.farDist = 1500.0f; far.farTicks = 200000u;      // (8192^2 headline scene, by tile row below the horizon: ~3 000 units 0.43 ms mean / 1.5 ms max, 1 000 units and nearer 0.06 ms like any floor tile)
+	}
 	hipLaunchKernelGGL(rtxCostFillKernel, dim3((tiles + 255) / 256), dim3(256), 0, nullptr, (const uint32_t*)s->costGrid, gridW, txFull, tyFull, s->tileCost,
-	                   s->knobs.costPerRef, s->knobs.costPerLeaf, s->knobs.costBase);
+	                   s->knobs.costPerRef, s->knobs.costPerLeaf, s->knobs.costBase, v, far);
 	HIPCHK(hipGetLastError());
 	s->costsUsable = true;
 	return RTX_OK;

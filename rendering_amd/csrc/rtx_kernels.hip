@@ -1979,15 +1979,38 @@ __global__ void __launch_bounds__(256) rtxCostShadowSplatKernel(const float* __r
 		}
 }
 
+// farPlanes (up to four planes: position, normal) + farTicks: a tile through which the camera sees a plane FAR away (the horizon of a floor) shades points
+// thousands of units from the meshes; their shadow rays come back through the scene as one huge, badly conditioned bundle that no record can prune (the
+// reference's own rounding error grows with |orig - v0|: the rigorous margins are metres wide) -- 1.5 ms for such a tile at 8192^2, and with an estimate of 0
+// they ran last, four per atomic: the first frame of a view took 13.7 ms of pass 1 against 9.9.  They are given farTicks, i.e. they start first.
+struct FarPlanes { float p[4][6]; uint32_t n; float farDist; uint32_t farTicks; };
 __global__ void __launch_bounds__(256) rtxCostFillKernel(const uint32_t* __restrict__ grid, uint32_t gridW, uint32_t tilesXFull, uint32_t tilesYFull,
-                                                         uint32_t* __restrict__ tileCost, float perRef, float perLeaf, float base)
+                                                         uint32_t* __restrict__ tileCost, float perRef, float perLeaf, float base, const View view, const FarPlanes far)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= tilesXFull * tilesYFull) return;
 	const uint32_t ty = t / tilesXFull, tx = t - ty * tilesXFull;
 	const size_t cell = (size_t)(ty / 2) * gridW + tx / 2;
 	const float refs = (float)grid[2 * cell], leaves = (float)grid[2 * cell + 1];
-	tileCost[t] = leaves > 0 ? (uint32_t)fminf(base + perRef * refs + perLeaf * leaves, 4.0e9f) : 0u;
+	uint32_t c = leaves > 0 ? (uint32_t)fminf(base + perRef * refs + perLeaf * leaves, 4.0e9f) : 0u;
+	if (far.n) {
+		// the rays through the tile's top and bottom rows (primaryRay's formula; no need for its bits here)
+		const float* M = view.camM;
+		for (int k = 0; k < 2; ++k) {
+			const float x = (float)(tx * 8 + 4) + 0.5f, y = (float)(ty * 8 + (k ? 7 : 0)) + 0.5f;
+			const float xp = (2 * (x + 0.5f) / (float)view.width - 1) * view.scale * view.aspect, yp = -(2 * (y + 0.5f) / (float)view.height - 1) * view.scale;
+			const float il = rsqrtf(xp * xp + yp * yp + 1.0f);
+			const float sx = xp * il, sy = yp * il, sz = -il;
+			const float dx = sx * M[0] + sy * M[4] + sz * M[8], dy = sx * M[1] + sy * M[5] + sz * M[9], dz = sx * M[2] + sy * M[6] + sz * M[10];
+			for (uint32_t q = 0; q < far.n; ++q) {
+				const float den = dx * far.p[q][3] + dy * far.p[q][4] + dz * far.p[q][5];
+				if (!(fabsf(den) > 1e-12f)) continue;
+				const float tt = ((far.p[q][0] - view.camPos[0]) * far.p[q][3] + (far.p[q][1] - view.camPos[1]) * far.p[q][4] + (far.p[q][2] - view.camPos[2]) * far.p[q][5]) / den;
+				if (tt > far.farDist) c = max(c, far.farTicks);
+			}
+		}
+	}
+	tileCost[t] = c;
 }
 
 // klass != null (rtx_render_frame): the class of a tile is the highest one within two tiles of it (rtxTileClassKernel) --
