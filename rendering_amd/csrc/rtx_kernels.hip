@@ -42,6 +42,11 @@ namespace {
 #else
 #define RTX_DBG_ONLY(...)
 #endif
+#if RTX_DBG || RTX_WAVE_TRACE
+#define RTX_TRACE_ONLY(...) __VA_ARGS__
+#else
+#define RTX_TRACE_ONLY(...)
+#endif
 
 #define RTX_AS4 __attribute__((address_space(4)))
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -336,7 +341,7 @@ __device__ __forceinline__ float attenuation(float intensity, float l2)
 // Render::trace for a whole wave (scene.cpp:724-756)
 // ------------------------------------------------------------------------------------------------
 struct Hit { int obj; float t; uint32_t tri; float u, v; };
-RTX_DBG_ONLY(__device__ unsigned long long gDbgWave[3 * 16384];)   // per wave of the last pass 1: first pop, last tile end, busy ticks
+RTX_TRACE_ONLY(__device__ unsigned long long gDbgWave[3 * 16384];)   // per wave of the last pass 1: first pop, last tile end, busy ticks
 RTX_DBG_ONLY(
 __device__ unsigned long long gDbgTimeline[3 * 8192 * 160];   // frame kernel: per wave up to 160 work items (start, duration, kind << 32 | item); start 0 = unused
 __device__ unsigned long long gDbgHist[64];   // [0,8) certificate outcomes (one sampled lane per evaluation), [16,64) by log2(leaf size)
@@ -1686,7 +1691,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 	// any wave may render any tile).  The queues are explicit tile lists built by the host (rtx_api.hip,
 	// buildTileList): tiles that can see a mesh come first, so the tail of the launch consists of cheap tiles.
 	const uint32_t xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
-	RTX_DBG_ONLY(
+	RTX_TRACE_ONLY(
 	const unsigned long long dbgStart = wall_clock64();
 	unsigned long long dbgEnd = dbgStart, dbgBusy = 0;
 	)
@@ -1726,7 +1731,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 			const unsigned long long t0 = wall_clock64();
 			const V3 c = castRayWave<STATS, MESH, false, BOXES>(P, valid, o, d, gl, cnt);
 			const unsigned long long dt = wall_clock64() - t0;
-			RTX_DBG_ONLY(dbgEnd = t0 + dt; dbgBusy += dt;)
+			RTX_TRACE_ONLY(dbgEnd = t0 + dt; dbgBusy += dt;)
 			if (lane == 0) {
 				// remembered per tile: the SSAA pass starts with the tiles that were expensive here (longest job first)
 				if (!strip) P.tileCost[ty * P.tilesXFull + tx] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
@@ -1739,7 +1744,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 			}
 		}
 	}
-	RTX_DBG_ONLY(if (lane == 0 && (gl >> 6) < 16384) { gDbgWave[3 * (gl >> 6)] = dbgStart; gDbgWave[3 * (gl >> 6) + 1] = dbgEnd; gDbgWave[3 * (gl >> 6) + 2] = dbgBusy; })
+	RTX_TRACE_ONLY(if (lane == 0 && (gl >> 6) < 16384) { gDbgWave[3 * (gl >> 6)] = dbgStart; gDbgWave[3 * (gl >> 6) + 1] = dbgEnd; gDbgWave[3 * (gl >> 6) + 2] = dbgBusy; })
 	if (STATS || RTX_DBG) flushCounts(P, cnt);
 }
 

@@ -7,6 +7,9 @@
 #ifndef RTX_DBG
 #define RTX_DBG 0               // 1: wave-level stage counters + per-wave pass-1 timeline, 2: + sampled outcomes / histograms (slow), 3: state-machine timers
 #endif
+#ifndef RTX_WAVE_TRACE
+#define RTX_WAVE_TRACE 0        // 1: three timestamps per pass-1 wave (first pop, end of the last tile, busy ticks) in a PRODUCT build: tools/wave_tail.py
+#endif
 #ifndef RTX_WAVES
 #define RTX_WAVES 5             // waves per SIMD of the pass-1 kernel (512 / RTX_WAVES VGPRs): 6 = 80 VGPRs spills the round loop (+8 %), 4 loses 20 %
 #endif
