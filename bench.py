@@ -427,6 +427,31 @@ def main():
         if frame_status != 0:
             raise SystemExit("bench.py: rtx_frame_status = 0x%x -- a timed frame's single launch gave up; the timing is void" % frame_status)
 
+    # N > 1: what the timed region measured is THROUGHPUT when the exchange of frame k runs beside the rendering of frame k + 1 (the default); the LATENCY of one
+    # frame -- render this rank's rows, quantise, gather on the render stream, wait -- is measured here, frame by frame (max over the ranks)
+    frame_latency_ms = None
+    if world > 1:
+        def one_frame_serial():
+            parallel.shard_frame(scene, fb, mask, world, rank, ssaa=ssaa, clear=False)
+            scene.quantize(fb, img)
+            if comm is not None:
+                comm.gather(scene, img, bottom_up=True)
+            elif backend == "nccl":
+                parallel.gather_frame(img, world, rank, bottom_up=True)
+            else:
+                host = img.cpu()
+                parallel.gather_frame(host, world, rank, bottom_up=True)
+                img.copy_(host)
+        sync()
+        one_frame_serial(); sync()
+        tl = time.perf_counter()
+        for _ in range(5):
+            one_frame_serial()
+            sync()
+        lat = torch.tensor([(time.perf_counter() - tl) / 5], dtype=torch.float64, device=rdev)
+        dist.all_reduce(lat, op=dist.ReduceOp.MAX)
+        frame_latency_ms = float(lat[0]) * 1e3
+
     verified = None
     if args.verify and world > 1:
         gathered = img.clone()
@@ -549,6 +574,9 @@ def main():
                    "walked_rays_per_frame": walked, "walked_mrays_s": round(walked * args.steps / dt / 1e6, 3),
                    "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.band_height(H, world), world, ", BGR8 bands collected on rank 0" if world > 1 else ""),
                    "gather": gather_via,
+                   # N > 1: ms_per_step is pipelined throughput when the gather overlaps the next frame's render; frame_latency_ms is one frame end to end
+                   "ms_per_step_is": None if world == 1 else ("pipelined throughput (gather of frame k beside the render of frame k + 1)" if pipe is not None else "serial frames (render, gather, next frame)"),
+                   "frame_latency_ms": None if frame_latency_ms is None else round(frame_latency_ms, 3),
                    "frame": ("one launch (rtxFrameKernel)" if one_launch else "three launches (pass 1, Sobel, SSAA)") if ssaa else "pass 1 only",
                    "measured_three_launches_ms": None if split_ms < 0 else round(split_ms, 3), "measured_one_launch_ms": None if fused_ms < 0 else round(fused_ms, 3),
                    "pass1_ms": round(ms1 / n1, 3) if n1 else None, "ssaa_ms": round(ms2 / n2, 3) if n2 else None,
