@@ -63,6 +63,12 @@ int rtx_vec_probe(int device, int op, uint32_t n, const float* a, const float* b
  * check of the reference-side binding (oracle/ref_binding.cpp) against this repo's host: tests/test_ref_binding.py. */
 int rtx_desc_serialize(const rtx_scene_desc* desc, void* out, size_t cap, size_t* need);
 
+/* rtx_bvh_build builds in a handful of launches (two persistent ones walk the tree through a queue of nodes); the level-by-level build of rounds 1-4 remains
+ * as its fallback (a pool ran out, its watchdog fired).  mode 1 forces the fallback (tests compare the two); process-wide. */
+int rtx_bvh_build_mode(int mode);
+/* Kernel launches (fills included) of a finished build, and whether the persistent launches did it (1) or the level-by-level build (0). */
+int rtx_bvh_launches(const rtx_bvh* bvh, uint32_t* launches, int* queued);
+
 #ifdef __cplusplus
 }
 #endif

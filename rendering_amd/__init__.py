@@ -38,7 +38,7 @@ RTX_SYMBOLS = [
     "rtx_counters_enable", "rtx_counters_reset", "rtx_counters_read", "rtx_last_kernel_ms", "rtx_math_probe",
     "rtx_cast_rays", "rtx_kernel_time_reset", "rtx_kernel_time_stats", "rtx_tile_cost_read", "rtx_set_row_ownership",
     "rtx_bvh_build", "rtx_bvh_info", "rtx_bvh_read", "rtx_bvh_destroy",
-    "rtx_vec_probe", "rtx_desc_serialize", "rtx_comm_unique_id", "rtx_comm_create", "rtx_comm_info", "rtx_comm_destroy", "rtx_comm_agree", "rtx_gather", "rtx_gather_plan",
+    "rtx_vec_probe", "rtx_desc_serialize", "rtx_bvh_build_mode", "rtx_bvh_launches", "rtx_comm_unique_id", "rtx_comm_create", "rtx_comm_info", "rtx_comm_destroy", "rtx_comm_agree", "rtx_gather", "rtx_gather_plan",
 ]
 
 
@@ -86,6 +86,7 @@ def load():
     rtx.rtx_set_row_ownership.argtypes = [vp, u32, u32, u32, i32]
     rtx.rtx_bvh_build.argtypes = [vp, u32, vp, vp, C.c_int32, i32, C.POINTER(vp)]
     rtx.rtx_bvh_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_float)]
+    rtx.rtx_bvh_launches.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_int)]
     rtx.rtx_bvh_read.argtypes = [vp, vp, vp, vp, vp, vp]
     rtx.rtx_bvh_destroy.argtypes = [vp]
     rtx.rtx_bvh_destroy.restype = None
@@ -177,9 +178,18 @@ def bvh_build(tri_pos, root_lo, root_hi, ac_penalty=1, device=0):
         _check(rtx.rtx_bvh_read(b, _np_ptr(d["bounds"]), _np_ptr(d["skip"]), _np_ptr(d["leaf_begin"]), _np_ptr(d["leaf_count"]),
                                 _np_ptr(d["refs"])), "rtx_bvh_read")
         d.update(n_nodes=nn.value, n_refs=nr.value, max_depth=md.value, build_ms=ms.value)
+        ln, q = C.c_uint32(), C.c_int()
+        _check(rtx.rtx_bvh_launches(b, C.byref(ln), C.byref(q)), "rtx_bvh_launches")
+        d.update(launches=ln.value, queued=bool(q.value))
         return d
     finally:
         rtx.rtx_bvh_destroy(b)
+
+
+def bvh_build_mode(mode):
+    """0: rtx_bvh_build in its persistent launches (default); 1: level by level (the fallback of the former; tests compare the two)."""
+    rtx, _ = load()
+    _check(rtx.rtx_bvh_build_mode(int(mode)), "rtx_bvh_build_mode")
 
 
 def bvh_build_host(tri_pos, root_lo, root_hi, ac_penalty=1):

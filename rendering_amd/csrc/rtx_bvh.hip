@@ -303,10 +303,379 @@ __global__ void emitRefsKernel(const BNode* __restrict__ nodes, const uint32_t* 
 
 } // namespace bvhb
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the same builder as ONE persistent launch (the level-synchronous form above needs ~27 levels x ~27 launches and three
+// host round trips per level -- 740 launches, 6.8 ms for 250 000 triangles, all of it launch latency).
+//
+// Work item = a node, processed by one block of 256 threads from the reference's leaf test to its two children (objects.cpp:470-526): the bisection
+// (676-689) as a loop inside the block -- each step one counting pass over the node's ids, reduced in the block --, the 1.5x duplication stop (498),
+// a STABLE partition of the ids into the two children (737-760: order inside a node = the reference's vector order; where a node or its ids sit in
+// the pools is irrelevant to the result) and the children's boxes (510-521).  Nodes are created by bumping one 64-bit counter (node slots + id
+// slots); block b handles the nodes b, b + G, b + 2G ... and waits for each to be published by the block that created it (its own flag: no address
+// is polled by more than one block).  Subtree sizes travel bottom-up as the leaves finish (the second child to report continues at the parent);
+// when the root's are known every slot a block could still be waiting for is marked "no node".  Pre-order indices, first references and the emission
+// in the DFS-left-first layout are then one plain launch (thread per node: the path to the root gives the index; wave per leaf for the references).
+//
+// The eight L2s are not coherent with each other: what one block writes for another (node records, id lists) is stored write-through (agent-scope
+// atomic stores) into 128-byte-aligned allocations (no line is shared between two writers or read before it is complete), acknowledged
+// (s_waitcnt vmcnt(0)) before the flag that publishes it; flags and sizes are read with agent-scope atomic loads.  A 2-s watchdog turns a bug into
+// an error (the level-synchronous build then runs instead), not a hung GPU.
+namespace bvhq {
+
+struct alignas(128) QNode {
+	float lo[3], hi[3];
+	uint32_t begin, count;       // ids of this node: idPool[begin, begin + count)
+	uint32_t depth, parent;      // root: depth 1, parent ~0
+	uint32_t state;              // bvhb::kLeaf, or kFinished = split
+	uint32_t child;              // left child (right = child + 1)
+	uint32_t subNodes, subRefs;  // written when the subtree is complete
+	uint32_t arrived;            // children that have reported
+	uint32_t ready;              // 1: the record is complete, 3: no such node (the build is over)
+	uint32_t refStart;           // finishKernel
+	uint32_t processed;          // the node has been looked at (leaf or split): the second launch skips it
+	uint32_t pad[14];
+};
+static_assert(sizeof(QNode) == 128, "one node record per 128-byte line");
+
+struct Ctl {                     // every word that several blocks touch on a line of its own
+	unsigned long long alloc; uint32_t padA[14];     // [63:40] node slots handed out, [39:0] id slots handed out
+	uint32_t error; uint32_t padB[15];               // 1 pool exhausted, 2 watchdog
+	uint32_t finished; uint32_t nodes; uint32_t refs; uint32_t maxDepth; uint32_t padC[12];
+	uint32_t big; uint32_t padD[15];                 // nodes of more than kSmall ids that are published and not yet processed
+};
+static_assert(sizeof(Ctl) == 256, "control block");
+
+#define BVHQ_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#ifdef RTX_BVHQ_DBG
+__device__ unsigned long long gBvhqDbg[64][4];      // per node < 64: start, after the bisection, after the partition, count
+#endif
+__device__ __forceinline__ void qstore(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, BVHQ_AGENT); }
+__device__ __forceinline__ void qstoref(float* p, float v) { __hip_atomic_store(p, v, BVHQ_AGENT); }
+__device__ __forceinline__ uint32_t qload(const uint32_t* p) { return __hip_atomic_load(p, BVHQ_AGENT); }
+__device__ __forceinline__ float qloadf(const float* p) { return __hip_atomic_load(p, BVHQ_AGENT); }
+__device__ __forceinline__ void acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// A block is 1 024 threads: the nodes at the top of the tree hold hundreds of thousands of ids and ONE block walks them (six bisection steps + the partition);
+// with 256 threads the root alone took a millisecond and a half (the passes are chains of dependent loads: id, then its extent).
+constexpr uint32_t kQB = 1024, kQW = kQB / 64;
+// sum of four per-thread counters over the block (every thread gets the result)
+__device__ __forceinline__ void blockSum4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, uint32_t (*part)[4])
+{
+	for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); d += __shfl_xor(d, o, 64); }
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) { uint32_t* q = part[threadIdx.x >> 6]; q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
+	__syncthreads();
+	a = b = c = d = 0;
+	for (uint32_t w = 0; w < kQW; w++) { a += part[w][0]; b += part[w][1]; c += part[w][2]; d += part[w][3]; }
+}
+
+// loPool / hiPool: beside every id of a node its extent along THE NODE'S OWN split axis (written by the parent's partition, which knows the child's box and
+// therefore its axis): the six counting passes of a bisection stream two float arrays instead of chasing id -> extent (two dependent loads per id and pass).
+__device__ __forceinline__ int splitAxis(const float* lo, const float* hi)      // objects.cpp:486-490: the strictly longest dimension, else y over z
+{
+	const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+	if (dx > dy && dx > dz) return 0;
+	return dy > dz ? 1 : 2;
+}
+// WAVE = false: a node is processed by the whole block (1 024 threads) -- the launch for the BIG nodes (more than kSmall ids: the top of the tree, where one
+// node's passes are long) -- and small nodes are left alone; WAVE = true: a node is processed by ONE wave (no barrier anywhere), four nodes at a time per block
+// of 256 -- the second launch, which finds the small nodes the first one left (published, not processed) and everything below them.  Worker k of W handles the
+// nodes k, k + W, k + 2 W ...  Markers in QNode::ready: 1 the record is complete, 2 "the launch for the big nodes is over" (to the second launch: not made yet),
+// 3 "the build is over".
+constexpr uint32_t kSmall = 1024;
+template <bool WAVE>
+__global__ void __launch_bounds__(WAVE ? 256 : kQB) buildKernel(QNode* nodes, uint32_t nodeCap, uint32_t* idPool, float* loPool, float* hiPool, unsigned long long idCap, Ctl* ctl,
+                                                                const float* __restrict__ ext, uint32_t nTris, int32_t penalty, uint32_t slack)
+{
+	__shared__ uint32_t part[kQW][4];
+	__shared__ uint32_t shNode[12];
+	__shared__ uint32_t shAlloc[2];
+	__shared__ uint32_t waveCnt[kQW][2];
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t tid = WAVE ? lane : threadIdx.x;                    // index in the group that shares a node
+	const uint32_t GS = WAVE ? 64u : kQB, nSeg = WAVE ? 1u : kQW;      // its size; wave segments of the final count / partition
+	const uint32_t W = WAVE ? gridDim.x * 4u : gridDim.x, me = WAVE ? blockIdx.x * 4u + wave : blockIdx.x;
+	const unsigned long long started = wall_clock64();
+	auto gsync = [&]() { if (!WAVE) __syncthreads(); };
+	for (uint32_t idx = me;; idx += W) {
+		if (idx >= nodeCap) { if (tid == 0) atomicMax(&ctl->error, 1u); return; }
+		// ---- wait for the node to be published (or for the end of this launch)
+		uint32_t verdict = 0;
+		if (tid == 0) {
+			uint32_t spins = 0;
+			for (;;) {
+				const uint32_t r = qload(&nodes[idx].ready);
+				if (r == 1 || r == 3 || (!WAVE && r == 2)) { verdict = r; break; }
+				if ((++spins & 63u) == 0) {
+					if (qload(&ctl->error) != 0) { verdict = 3; break; }
+					if (wall_clock64() - started > 200000000ull) { atomicMax(&ctl->error, 2u); verdict = 3; break; }
+				}
+				__builtin_amdgcn_s_sleep(20);
+			}
+		}
+		float lo[3], hi[3];
+		uint32_t begin, count, depth, parent;
+		if (WAVE) {
+			verdict = (uint32_t)__builtin_amdgcn_readfirstlane((int)verdict);
+			if (verdict != 1) return;
+			const QNode* n = nodes + idx;
+			if (qload(&n->processed) != 0) continue;                   // (done by the launch for the big nodes)
+			for (int c = 0; c < 3; c++) { lo[c] = qloadf(&n->lo[c]); hi[c] = qloadf(&n->hi[c]); }
+			begin = qload(&n->begin); count = qload(&n->count); depth = qload(&n->depth); parent = qload(&n->parent);
+		}
+		else {
+			if (tid == 0) {
+				shNode[11] = verdict;
+				if (verdict == 1) {
+					const QNode* n = nodes + idx;
+					for (int c = 0; c < 3; c++) { shNode[c] = __float_as_uint(qloadf(&n->lo[c])); shNode[3 + c] = __float_as_uint(qloadf(&n->hi[c])); }
+					shNode[6] = qload(&n->begin); shNode[7] = qload(&n->count); shNode[8] = qload(&n->depth); shNode[9] = qload(&n->parent);
+				}
+			}
+			__syncthreads();
+			if (shNode[11] != 1) return;
+			for (int c = 0; c < 3; c++) { lo[c] = __uint_as_float(shNode[c]); hi[c] = __uint_as_float(shNode[3 + c]); }
+			begin = shNode[6]; count = shNode[7]; depth = shNode[8]; parent = shNode[9];
+			__syncthreads();
+			if (count <= kSmall) continue;                             // (the second launch's)
+		}
+#ifdef RTX_BVHQ_DBG
+		if (tid == 0 && idx < 64) gBvhqDbg[idx][0] = wall_clock64();
+#endif
+		const uint32_t* ids = idPool + begin;
+		const float* L = loPool + begin;
+		const float* Hh = hiPool + begin;
+		const uint32_t seg = WAVE ? count : ((count + kQW - 1) / kQW + 63u) & ~63u;      // entries per wave in the final count and the partition
+		// ---- objects.cpp:477: leaf by size; 486-490: the axis
+		bool leaf = (unsigned long long)count <= (unsigned long long)depth * (unsigned long long)(long long)penalty;
+		uint32_t nl = 0, nr = 0;
+		float s = 0;
+		int ax = 2;
+		if (!leaf) {
+			ax = splitAxis(lo, hi);
+			const float mn = lo[ax], mx = hi[ax];
+			float left = mn, right = mx;
+			// objects.cpp:676-689: halve [left, right] until it is narrower than 0.1, comparing the cost 0.05 either side of the middle
+			for (int step = 0; step < 4096; step++) {
+				const float mid = right - (right - left) / 2;
+				if (right - left < 0.1f) { s = mid; break; }
+				const float s1 = mid - 0.05f, s2 = mid + 0.05f;
+				uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+				for (uint32_t e = tid; e < count; e += 4 * GS) {      // (four entries in flight per thread)
+					float l[4], h[4];
+					for (int k = 0; k < 4; k++) { const bool in = e + k * GS < count; l[k] = in ? L[e + k * GS] : __builtin_inff(); h[k] = in ? Hh[e + k * GS] : -__builtin_inff(); }
+					for (int k = 0; k < 4; k++) { c0 += l[k] <= s1; c1 += h[k] >= s1; c2 += l[k] <= s2; c3 += h[k] >= s2; }
+				}
+				if (WAVE) { for (int o = 32; o >= 1; o >>= 1) { c0 += __shfl_xor(c0, o, 64); c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64); c3 += __shfl_xor(c3, o, 64); } }
+				else blockSum4(c0, c1, c2, c3, part);
+				// nLeft * (s - min) + nRight * (max - s), counts promoted to float (objects.cpp:672)
+				const float k1 = (float)(int)c0 * (s1 - mn) + (float)(int)c1 * (mx - s1);
+				const float k2 = (float)(int)c2 * (s2 - mn) + (float)(int)c3 * (mx - s2);
+				if (k1 < k2) right = mid; else left = mid;
+				if (step == 4095) { s = right - (right - left) / 2; if (tid == 0) atomicMax(&ctl->error, 3u); }      // (non-finite coordinates: the interval never narrows)
+			}
+			// The final count (objects.cpp:741-757 decide the sides with the same compares) by WAVE SEGMENTS: wave w owns the entries [w seg, (w + 1) seg) -- its totals
+			// are where its part of either child's list begins, so the partition below needs no barrier per chunk.
+			{
+				const uint32_t e0 = (WAVE ? 0u : wave) * seg, e1 = min(e0 + seg, count);
+				uint32_t a = 0, b = 0;
+				for (uint32_t e = e0 + lane; e < e1; e += 256) {
+					float l[4], h[4];
+					for (int k = 0; k < 4; k++) { const bool in = e + 64 * k < e1; l[k] = in ? L[e + 64 * k] : __builtin_inff(); h[k] = in ? Hh[e + 64 * k] : -__builtin_inff(); }
+					for (int k = 0; k < 4; k++) { a += l[k] <= s; b += h[k] >= s; }
+				}
+				for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+				if (WAVE) { nl = a; nr = b; }
+				else {
+					__syncthreads();
+					if (lane == 0) { waveCnt[wave][0] = a; waveCnt[wave][1] = b; }
+					__syncthreads();
+					for (uint32_t w = 0; w < kQW; w++) { nl += waveCnt[w][0]; nr += waveCnt[w][1]; }
+				}
+			}
+			// objects.cpp:498: a leaf if one side is empty or the split duplicates too much (>= 1.5x, compared in double)
+			leaf = nl == 0 || nr == 0 || (double)((unsigned long long)nl + nr) >= (double)count * 1.5;
+		}
+#ifdef RTX_BVHQ_DBG
+		if (tid == 0 && idx < 64) { gBvhqDbg[idx][1] = wall_clock64(); gBvhqDbg[idx][3] = count; }
+#endif
+		int bigDelta = -1;                                             // (WAVE = false: big nodes in flight: this one is done ...)
+		bool rootDone = false;
+		if (!leaf) {
+			// ---- two node slots and nl + nr id slots (rounded up to whole 128-byte lines) with one atomic
+			const unsigned long long idsWanted = (((unsigned long long)nl + 31u) & ~31ull) + (((unsigned long long)nr + 31u) & ~31ull);
+			uint32_t child = 0, idBase32 = 0;
+			if (tid == 0) {
+				const unsigned long long old = atomicAdd(&ctl->alloc, (2ull << 40) | idsWanted);
+				const unsigned long long idBase = old & ((1ull << 40) - 1), nodeBase = old >> 40;
+				const bool ok = nodeBase + 2 + slack <= nodeCap && idBase + idsWanted <= idCap && idBase + idsWanted < (1ull << 32);
+				if (!ok) atomicMax(&ctl->error, 1u);
+				child = ok ? (uint32_t)nodeBase : 0xffffffffu; idBase32 = (uint32_t)idBase;
+				if (!WAVE) { shAlloc[0] = child; shAlloc[1] = idBase32; }
+			}
+			if (WAVE) { child = (uint32_t)__builtin_amdgcn_readfirstlane((int)child); idBase32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)idBase32); }
+			else { __syncthreads(); child = shAlloc[0]; idBase32 = shAlloc[1]; }
+			if (child == 0xffffffffu) return;
+			const uint32_t lBegin = idBase32, rBegin = lBegin + ((nl + 31u) & ~31u);
+			// ---- stable partition (objects.cpp:737-760): [ids with a vertex <= s] and [ids with a vertex >= s], each in the node's order, with their extents
+			// along the CHILD's split axis (its box is the parent's cut at s: objects.cpp:510-521).  Every wave writes its own segment's part of either list
+			// (offsets from the final count): no barrier inside.
+			float cl[3], ch[3];
+			for (int a = 0; a < 3; a++) { cl[a] = lo[a]; ch[a] = hi[a]; }
+			ch[ax] = s;
+			const int axL = splitAxis(cl, ch);
+			ch[ax] = hi[ax]; cl[ax] = s;
+			const int axR = splitAxis(cl, ch);
+			const float* elL = ext + (size_t)(2 * axL) * nTris; const float* ehL = ext + (size_t)(2 * axL + 1) * nTris;
+			const float* elR = ext + (size_t)(2 * axR) * nTris; const float* ehR = ext + (size_t)(2 * axR + 1) * nTris;
+			const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+			uint32_t offL = lBegin, offR = rBegin;
+			if (!WAVE) for (uint32_t w = 0; w < wave; w++) { offL += waveCnt[w][0]; offR += waveCnt[w][1]; }
+			const uint32_t e0 = (WAVE ? 0u : wave) * seg, e1 = min(e0 + seg, count);
+			for (uint32_t base = e0; base < e1; base += 256) {      // (four chunks of 64 in flight per wave)
+				uint32_t id[4]; float l[4], h[4];
+				for (int k = 0; k < 4; k++) {
+					const uint32_t e = base + 64 * k + lane;
+					const bool in = e < e1;
+					id[k] = in ? ids[e] : 0xffffffffu; l[k] = in ? L[e] : __builtin_inff(); h[k] = in ? Hh[e] : -__builtin_inff();
+				}
+				for (int k = 0; k < 4; k++) {
+					const bool fl = l[k] <= s, fr = h[k] >= s;
+					const unsigned long long bl = __ballot(fl), br = __ballot(fr);
+					if (fl) {
+						const uint32_t at = offL + (uint32_t)__popcll(bl & below);
+						qstore(idPool + at, id[k]); qstoref(loPool + at, axL == ax ? l[k] : elL[id[k]]); qstoref(hiPool + at, axL == ax ? h[k] : ehL[id[k]]);
+					}
+					if (fr) {
+						const uint32_t at = offR + (uint32_t)__popcll(br & below);
+						qstore(idPool + at, id[k]); qstoref(loPool + at, axR == ax ? l[k] : elR[id[k]]); qstoref(hiPool + at, axR == ax ? h[k] : ehR[id[k]]);
+					}
+					offL += (uint32_t)__popcll(bl); offR += (uint32_t)__popcll(br);
+				}
+			}
+			acknowledged();
+			gsync();
+#ifdef RTX_BVHQ_DBG
+			if (tid == 0 && idx < 64) gBvhqDbg[idx][2] = wall_clock64();
+#endif
+			if (tid == 0) {
+				qstore(&nodes[idx].child, child);
+				qstore(&nodes[idx].state, bvhb::kFinished);
+				qstore(&nodes[idx].processed, 1u);
+				// the children: the parent's box cut at s on the split axis (objects.cpp:510-521)
+				for (int k = 0; k < 2; k++) {
+					QNode* c = nodes + child + k;
+					for (int a = 0; a < 3; a++) { qstoref(&c->lo[a], (k == 1 && a == ax) ? s : lo[a]); qstoref(&c->hi[a], (k == 0 && a == ax) ? s : hi[a]); }
+					qstore(&c->begin, k ? rBegin : lBegin); qstore(&c->count, k ? nr : nl);
+					qstore(&c->depth, depth + 1); qstore(&c->parent, idx);
+				}
+				acknowledged();
+				qstore(&nodes[child].ready, 1u); qstore(&nodes[child + 1].ready, 1u);
+			}
+			bigDelta += (nl > kSmall) + (nr > kSmall);                 // (... its big children are on their way)
+		}
+		else if (tid == 0) {
+			// ---- a leaf: its subtree is complete; the second child to report completes the parent, and so on up to the root
+			qstore(&nodes[idx].state, bvhb::kLeaf);
+			qstore(&nodes[idx].processed, 1u);
+			qstore(&nodes[idx].subNodes, 1u); qstore(&nodes[idx].subRefs, count);
+			uint32_t n = idx, par = parent;
+			for (;;) {
+				acknowledged();
+				if (par == 0xffffffffu) {
+					// the root: the build is over.  Every slot some worker may still be waiting for is marked "no node" (by this whole wave, below).
+					const unsigned long long a = __hip_atomic_load(&ctl->alloc, BVHQ_AGENT);
+					qstore(&ctl->nodes, (uint32_t)(a >> 40)); qstore(&ctl->refs, qload(&nodes[n].subRefs));
+					qstore(&ctl->finished, 1u);
+					rootDone = true;
+					break;
+				}
+				if (atomicAdd(&nodes[par].arrived, 1u) == 0) break;      // the first child: the other one will carry on
+				const uint32_t c = qload(&nodes[par].child);
+				qstore(&nodes[par].subNodes, 1u + qload(&nodes[c].subNodes) + qload(&nodes[c + 1].subNodes));
+				qstore(&nodes[par].subRefs, qload(&nodes[c].subRefs) + qload(&nodes[c + 1].subRefs));
+				n = par; par = qload(&nodes[n].parent);
+			}
+		}
+		// ---- the end of this launch: the build is over (3), or -- the launch for the big nodes -- no big node is left (2).  The markers go to every slot a worker
+		// may still be waiting for: the `slack` slots behind the last node made.
+		uint32_t mark = 0;
+		if (tid == 0) {
+			acknowledged();
+			if (rootDone) mark = 3;
+			else if (!WAVE && atomicAdd(&ctl->big, (uint32_t)bigDelta) + (uint32_t)bigDelta == 0u) mark = 2;
+		}
+		if (WAVE) mark = (uint32_t)__builtin_amdgcn_readfirstlane((int)mark);
+		else { __syncthreads(); if (tid == 0) shAlloc[0] = mark; __syncthreads(); mark = shAlloc[0]; __syncthreads(); }
+		if (mark != 0) {
+			const uint32_t nNodes = (uint32_t)(__hip_atomic_load(&ctl->alloc, BVHQ_AGENT) >> 40);
+			for (uint32_t k = tid; k < slack && nNodes + k < nodeCap; k += GS) qstore(&nodes[nNodes + k].ready, mark);
+		}
+	}
+}
+
+// Pre-order index and first reference of every node from its path to the root (objects.cpp:601-629: a node, its left subtree, its right subtree), the
+// node records in that order, and -- a wave per 64 nodes -- the references of the leaves among them.
+__global__ void __launch_bounds__(256) finishKernel(const QNode* __restrict__ nodes, uint32_t n, const uint32_t* __restrict__ idPool, Ctl* ctl,
+                                                    float* bounds, int32_t* skip, int32_t* leafBegin, int32_t* leafCount, uint32_t* refs)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t pre = 0, refStart = 0, count = 0, begin = 0, depth = 0;
+	bool leaf = false;
+	if (i < n) {
+		const QNode& nd = nodes[i];
+		uint32_t c = i, p = nd.parent;
+		while (p != 0xffffffffu) {
+			const QNode& pn = nodes[p];
+			pre += 1;
+			if (c == pn.child + 1) { pre += nodes[pn.child].subNodes; refStart += nodes[pn.child].subRefs; }
+			c = p; p = pn.parent;
+		}
+		leaf = nd.state == bvhb::kLeaf; count = nd.count; begin = nd.begin; depth = nd.depth;
+		for (int a = 0; a < 3; a++) { bounds[(size_t)pre * 6 + a] = nd.lo[a]; bounds[(size_t)pre * 6 + 3 + a] = nd.hi[a]; }
+		skip[pre] = (int32_t)(pre + nd.subNodes);
+		leafBegin[pre] = leaf ? (int32_t)refStart : -1;
+		leafCount[pre] = leaf ? (int32_t)count : -1;
+	}
+	uint32_t d = depth;
+	for (int o = 32; o >= 1; o >>= 1) d = max(d, (uint32_t)__shfl_xor((int)d, o, 64));
+	if ((threadIdx.x & 63) == 0 && d) atomicMax(&ctl->maxDepth, d);
+	unsigned long long todo = __ballot(leaf && count != 0);
+	const uint32_t lane = threadIdx.x & 63;
+	while (todo) {
+		const int k = __builtin_ctzll(todo);
+		todo &= todo - 1;
+		const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)begin, k), cnt = (uint32_t)__builtin_amdgcn_readlane((int)count, k), r0 = (uint32_t)__builtin_amdgcn_readlane((int)refStart, k);
+		for (uint32_t e = lane; e < cnt; e += 64) refs[r0 + e] = idPool[b + e];
+	}
+}
+
+__global__ void initKernel(QNode* nodes, uint32_t* idPool, float* loPool, float* hiPool, Ctl* ctl, const float* __restrict__ ext, uint32_t nTris,
+                           float lx, float ly, float lz, float hx, float hy, float hz)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const float rl[3] = { lx, ly, lz }, rh[3] = { hx, hy, hz };
+	const int ax = splitAxis(rl, rh);
+	if (i < nTris) { idPool[i] = i; loPool[i] = ext[(size_t)(2 * ax) * nTris + i]; hiPool[i] = ext[(size_t)(2 * ax + 1) * nTris + i]; }
+	if (i == 0) {
+		QNode& r = nodes[0];
+		r.lo[0] = lx; r.lo[1] = ly; r.lo[2] = lz; r.hi[0] = hx; r.hi[1] = hy; r.hi[2] = hz;
+		r.begin = 0; r.count = nTris; r.depth = 1; r.parent = 0xffffffffu; r.ready = 1;
+		ctl->alloc = (1ull << 40) | (((unsigned long long)nTris + 31u) & ~31ull);
+		ctl->big = nTris > kSmall ? 1u : 0u;
+	}
+}
+
+} // namespace bvhq
+
+static int gBvhBuildMode = 0;      // rtx_bvh_build_mode (include/rtx_debug.h): 0 = the persistent launches, level by level only as their fallback; 1 = level by level
+
 struct rtx_bvh {
 	int device = 0;
 	uint32_t nNodes = 0, nRefs = 0, maxDepth = 0, launches = 0;
 	float buildMs = 0;
+	bool queued = false;         // built by the single persistent launch (bvhq) -- else level by level (bvhb)
+	void* slab = nullptr;        // bvhq: the five arrays below are one allocation
 	float* bounds = nullptr; int32_t* skip = nullptr; int32_t* leafBegin = nullptr; int32_t* leafCount = nullptr; uint32_t* refs = nullptr;
 };
 
@@ -332,6 +701,79 @@ int scanExclusive(uint32_t* data, uint32_t n, uint32_t* tmp, hipStream_t st, uin
 	return RTX_OK;
 }
 
+// The build as one persistent launch (bvhq).  RTX_OK with *out = nullptr: not done here (a pool ran out, the watchdog fired, RTX_BVH_BUILD=levels) -- the
+// caller builds level by level.
+int buildQueued(const float* tri_pos, uint32_t n_tris, const float* root_lo, const float* root_hi, int32_t ac_penalty, int device, rtx_bvh** out)
+{
+	using namespace bvhq;
+	*out = nullptr;
+	if (gBvhBuildMode == 1) return RTX_OK;
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, device));
+	int occ = 0, occW = 0;
+	HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, buildKernel<false>, (int)kQB, 0));
+	HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occW, buildKernel<true>, 256, 0));
+	if (occ < 1 || occW < 1) return RTX_OK;
+	// every worker resident: a worker waits for nodes other workers make
+	const uint32_t G = (uint32_t)std::min(occ, 2) * (uint32_t)prop.multiProcessorCount, GW = (uint32_t)std::min(occW, 8) * (uint32_t)prop.multiProcessorCount;
+	const uint32_t slack = std::max(G, GW * 4u);
+	const uint32_t nodeCap = std::max<uint32_t>(2 * n_tris, 1024) + slack + 64;
+	const unsigned long long idCap = std::min<unsigned long long>(32ull * n_tris + (1ull << 20), (1ull << 32) - 64);      // (ids of ALL levels: 27 levels x 2.6 n at the headline; three arrays)
+	std::vector<void*> scratch;
+	struct Cleanup { std::vector<void*>& v; ~Cleanup() { for (void* p : v) (void)hipFree(p); } } cleanup{ scratch };
+	auto dalloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256)); if (e == hipSuccess) scratch.push_back(*p); return e; };
+	float* dPos = nullptr; float* dExt = nullptr; QNode* dNodes = nullptr; uint32_t* dIds = nullptr; Ctl* dCtl = nullptr;
+	// (one allocation for everything transient: positions, extents, node pool, id pool, control block)
+	const size_t szPos = ((size_t)n_tris * 9 * 4 + 255) & ~(size_t)255, szExt = ((size_t)n_tris * 6 * 4 + 255) & ~(size_t)255;
+	const size_t szNodes = (size_t)nodeCap * sizeof(QNode), szIds = (size_t)idCap * 4, szCtl = 256;      // (szIds: each of the three pools)
+	char* base = nullptr;
+	if (dalloc((void**)&base, szPos + szExt + szNodes + 3 * szIds + szCtl) != hipSuccess) { (void)hipGetLastError(); return RTX_OK; }      // (not enough memory for the pools: level by level)
+	dNodes = (QNode*)base; dIds = (uint32_t*)(base + szNodes); float* dLo = (float*)(base + szNodes + szIds); float* dHi = (float*)(base + szNodes + 2 * szIds);
+	dCtl = (Ctl*)(base + szNodes + 3 * szIds); dPos = (float*)(base + szNodes + 3 * szIds + szCtl); dExt = (float*)((char*)dPos + szPos);
+	hipStream_t st = nullptr;
+	hipEvent_t ev0, ev1;
+	HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
+	struct EvCleanup { hipEvent_t a, b; ~EvCleanup() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evCleanup{ ev0, ev1 };
+	if (n_tris) HIPCHK(hipMemcpy(dPos, tri_pos, (size_t)n_tris * 9 * sizeof(float), hipMemcpyHostToDevice));
+	uint32_t launches = 0;
+	HIPCHK(hipEventRecord(ev0, st));
+	HIPCHK(hipMemsetAsync(dNodes, 0, szNodes, st));
+	HIPCHK(hipMemsetAsync(dCtl, 0, szCtl, st));
+	launches += 2;
+	if (n_tris) { hipLaunchKernelGGL(bvhb::triExtentKernel, dim3(gridFor(n_tris)), dim3(256), 0, st, dPos, n_tris, dExt); launches++; }
+	hipLaunchKernelGGL(initKernel, dim3(gridFor(std::max(n_tris, 1u))), dim3(256), 0, st, dNodes, dIds, dLo, dHi, dCtl, (const float*)dExt, n_tris, root_lo[0], root_lo[1], root_lo[2], root_hi[0], root_hi[1], root_hi[2]);
+	if (n_tris > kSmall) { hipLaunchKernelGGL(buildKernel<false>, dim3(G), dim3(kQB), 0, st, dNodes, nodeCap, dIds, dLo, dHi, idCap, dCtl, (const float*)dExt, n_tris, ac_penalty, slack); launches++; }
+	hipLaunchKernelGGL(buildKernel<true>, dim3(GW), dim3(256), 0, st, dNodes, nodeCap, dIds, dLo, dHi, idCap, dCtl, (const float*)dExt, n_tris, ac_penalty, slack);
+	launches += 2;
+	Ctl ctl;
+	HIPCHK(hipMemcpyAsync(&ctl, dCtl, sizeof(ctl), hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	if (ctl.error != 0 || !ctl.finished) return RTX_OK;
+	rtx_bvh* b = new rtx_bvh();
+	b->device = device; b->nNodes = ctl.nodes; b->nRefs = ctl.refs; b->queued = true;
+	const size_t nN = b->nNodes, nR = std::max<uint32_t>(b->nRefs, 1);
+	const size_t oSkip = (nN * 6 * 4 + 255) & ~(size_t)255, oLb = oSkip + ((nN * 4 + 255) & ~(size_t)255), oLc = oLb + ((nN * 4 + 255) & ~(size_t)255), oRefs = oLc + ((nN * 4 + 255) & ~(size_t)255);
+	if (hipMalloc(&b->slab, oRefs + nR * 4) != hipSuccess) { (void)hipGetLastError(); delete b; return fail(RTX_ERR_DEVICE, "out of device memory for the acceleration structure"); }
+	b->bounds = (float*)b->slab; b->skip = (int32_t*)((char*)b->slab + oSkip); b->leafBegin = (int32_t*)((char*)b->slab + oLb); b->leafCount = (int32_t*)((char*)b->slab + oLc);
+	b->refs = (uint32_t*)((char*)b->slab + oRefs);
+	hipLaunchKernelGGL(finishKernel, dim3(gridFor(b->nNodes)), dim3(256), 0, st, (const QNode*)dNodes, b->nNodes, (const uint32_t*)dIds, dCtl, b->bounds, b->skip, b->leafBegin, b->leafCount, b->refs);
+	launches++;
+	uint32_t maxDepth = 0;
+	if (hipMemcpyAsync(&maxDepth, &dCtl->maxDepth, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(ev1, st) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess ||
+	    hipGetLastError() != hipSuccess) { rtx_bvh_destroy(b); return fail(RTX_ERR_DEVICE, "acceleration-structure build failed on the device"); }
+	(void)hipEventElapsedTime(&b->buildMs, ev0, ev1);
+	b->maxDepth = maxDepth; b->launches = launches;
+#ifdef RTX_BVHQ_DBG
+	{
+		unsigned long long d[64][4];
+		(void)hipMemcpyFromSymbol(d, HIP_SYMBOL(gBvhqDbg), sizeof(d));
+		for (int i = 0; i < 16 && i < (int)b->nNodes; i++) fprintf(stderr, "[bvhq] node %d count %llu: starts at %.1f us, bisection %.1f us, partition %.1f us\n", i, d[i][3], (d[i][0] - d[0][0]) * 0.01, (d[i][1] - d[i][0]) * 0.01, d[i][2] > d[i][1] ? (d[i][2] - d[i][1]) * 0.01 : 0.0);
+	}
+#endif
+	*out = b;
+	return RTX_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -347,6 +789,14 @@ int rtx_bvh_build(const float* tri_pos, uint32_t n_tris, const float* root_lo, c
 	if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) return fail(RTX_ERR_NO_DEVICE, "no HIP device");
 	if (device < 0 || device >= nDev) return fail(RTX_ERR_ARG, "bad device index");
 	HIPCHK(hipSetDevice(device));
+	if (!std::isfinite(root_lo[0] + root_lo[1] + root_lo[2] + root_hi[0] + root_hi[1] + root_hi[2])) return fail(RTX_ERR_ARG, "root bounds are not finite");
+	{
+		// one persistent launch (bvhq); level by level (below) only when its pools ran out or its watchdog fired
+		rtx_bvh* q = nullptr;
+		const int rcq = buildQueued(tri_pos, n_tris, root_lo, root_hi, ac_penalty, device, &q);
+		if (rcq) return rcq;
+		if (q) { *out = q; return RTX_OK; }
+	}
 
 	// bump arena over a few large slabs (one hipMalloc per ~27 levels x 8 buffers would dominate the wall time);
 	// everything in it is freed on every exit path
@@ -501,6 +951,15 @@ int rtx_bvh_build(const float* tri_pos, uint32_t n_tris, const float* root_lo, c
 	return RTX_OK;
 }
 
+int rtx_bvh_build_mode(int mode) { if (mode < 0 || mode > 1) return fail(RTX_ERR_ARG, "rtx_bvh_build_mode: 0 or 1"); gBvhBuildMode = mode; return RTX_OK; }
+int rtx_bvh_launches(const rtx_bvh* b, uint32_t* launches, int* queued)
+{
+	if (!b) return fail(RTX_ERR_ARG, "bvh is NULL");
+	if (launches) *launches = b->launches;
+	if (queued) *queued = b->queued ? 1 : 0;
+	return RTX_OK;
+}
+
 int rtx_bvh_info(const rtx_bvh* b, uint32_t* n_nodes, uint32_t* n_refs, uint32_t* max_depth, float* build_ms)
 {
 	if (!b) return fail(RTX_ERR_ARG, "bvh is NULL");
@@ -527,6 +986,7 @@ void rtx_bvh_destroy(rtx_bvh* b)
 {
 	if (!b) return;
 	(void)hipSetDevice(b->device);
+	if (b->slab) { (void)hipFree(b->slab); delete b; return; }
 	if (b->bounds) (void)hipFree(b->bounds);
 	if (b->skip) (void)hipFree(b->skip);
 	if (b->leafBegin) (void)hipFree(b->leafBegin);

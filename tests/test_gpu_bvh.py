@@ -95,3 +95,22 @@ def test_error_paths(ra):
         ra.bvh_build(np.zeros((1, 9), np.float32), lo, np.array([np.inf, 1, 1], np.float32), 1)
     with pytest.raises(ra.RtxError):
         ra.bvh_build(np.zeros((1, 9), np.float32), lo, hi, 1, device=99)
+
+
+def test_persistent_build_equals_the_level_by_level_build(ra):
+    """rtx_bvh_build runs as two persistent launches over a queue of nodes (round 5: 740 launches -> 7); the level-by-level build of rounds 1-4 is its
+    fallback.  Both must give the reference's structure: compared with each other here, with the host builder / the reference's digests elsewhere."""
+    s = ra.Scene("scenes/cfg2_smooth_25k.scene", 64, 64)
+    h = s.bvh(1)
+    s.close()
+    q = ra.bvh_build(h["tris"][:, :9], h["bounds"][0, :3], h["bounds"][0, 3:], 1)
+    assert q["queued"] and q["launches"] <= 20, (q["queued"], q["launches"])
+    ra.bvh_build_mode(1)
+    try:
+        l = ra.bvh_build(h["tris"][:, :9], h["bounds"][0, :3], h["bounds"][0, 3:], 1)
+    finally:
+        ra.bvh_build_mode(0)
+    assert not l["queued"] and l["launches"] > 100
+    for k in ("bounds", "skip", "leaf_begin", "leaf_count", "refs"):
+        assert q[k].tobytes() == l[k].tobytes() == h[k].tobytes(), k
+    assert q["max_depth"] == l["max_depth"] == h["max_depth"]
