@@ -5,6 +5,7 @@ counters, gpurun_out/r04/r04_dbg_counts.txt), against the SQ_INSTS_VALU the hard
 of the body is taken), so the walk's share is an upper bound and "everything else" a lower bound.
 python tools/issue_account.py > profiles/r04_issue_account.txt   (also writes profiles/r04_issue_account.json: useful_valu_frac for bench.py)"""
 import json, os, re, sys
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"      # python tools/issue_account.py <round tag> > profiles/<tag>_issue_account.txt
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from srchash import source_hash
@@ -43,11 +44,11 @@ for ln in lines[start + 1:]:
 node = next(k for k in order if loops[k]["smem16"] >= 2 and loops[k]["vmem"] >= 2)
 after = order[order.index(node) + 1:]
 passes = [k for k in after if loops[k]["bperm"] >= 10][:4]
-dbg = open(os.path.join(ROOT, "gpurun_out", "r04", "r04_dbg_counts.txt")).read()
+dbg = open(os.path.join(ROOT, "gpurun_out", TAG, TAG + "_dbg_counts.txt")).read()
 sec = dbg.split("== nosrc")[0]
 m = re.search(r"node visits (\d+), reached leaves (\d+), filter passes \(64 references\) (\d+), of which rejected whole by stage 1 (\d+), by stage 2 (\d+); survivors tested exactly (\d+)", sec)
 visits, leaves, npass, rej1, rej2, exact = [int(x) for x in m.groups()]
-pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pass1_pmc.json")))
+pmc = json.load(open(os.path.join(ROOT, "profiles", TAG + "_pass1_pmc.json")))
 kern = [v for n, v in pmc["workloads"]["headline"]["kernels"].items() if "Pass1Kernel<false, true, true>" in n][0]
 total = kern["SQ_INSTS_VALU"]
 pv = sum(loops[k]["valu"] for k in passes) / len(passes)
@@ -78,6 +79,6 @@ useful = (21.0 * slot_tests if slot_tests else 0.0) + ev * exact
 print("useful arithmetic (per-ray slot box tests %s x 21 + exact tests %d x %d static): %.3e = %.1f %% of the issued VALU instructions" % (slot_tests, exact, ev, useful, 100.0 * useful / total))
 json.dump({"source_hash": pmc["source_hash"], "useful_valu_basis": "(per-ray slot box tests x 21 VALU + exact tests x the static body of the Moller-Trumbore loop) / SQ_INSTS_VALU; counts: RTX_DBG build of the same sources",
            "workloads": {"headline": {"useful_valu_frac": round(useful / total, 4), "node_visits": visits, "reached_leaves": leaves, "filter_passes": npass, "exact_tests": exact, "slot_tests": slot_tests}}},
-          open(os.path.join(ROOT, "profiles", "r04_issue_account.json"), "w"), indent=1)
+          open(os.path.join(ROOT, "profiles", TAG + "_issue_account.json"), "w"), indent=1)
 print("spill traffic inside the loops above: v_readlane / v_writelane %d in the node loop, %d per pass body, %d per exact test (VERDICT r2: 122 SGPR spill slots in the loops -- the spills that remain sit in the round loop around the walk)" % (
     loops[node]["readlane"], loops[passes[0]]["readlane"], loops[ex[0]]["readlane"] if ex else 0))
