@@ -112,6 +112,35 @@ def test_north_star_4096_ssaa_oracle_bands(ra, oracle, torch_cuda):
     assert n > 50000
 
 
+def test_north_star_4096_whole_frame_equals_the_oracle(ra, oracle, torch_cuda):
+    """The headline frame WHOLE -- every pixel of pass 1, every bit of the Sobel mask, every pixel after the 4-ray pass -- against the oracle (the
+    suite compared bands; the whole-frame equality lived in bench.py, against the reference itself, where it stays).  Rendered the way bench.py renders it:
+    rtx_render_frame, first frame of the view and a warm one.  The oracle's frame costs the box's host cores ~20 s."""
+    torch = torch_cuda
+    from rendering_amd import assets
+    assets.ensure(["bumpy_250k.obj"])
+    S = 4096
+    o = oracle.OracleScene("scenes/cfg2_smooth_250k.scene", S, S)
+    p1 = o.pass1()
+    ref = o.ssaa(p1.copy())
+    g = ra.Scene("scenes/cfg2_smooth_250k.scene", S, S)
+    fb = torch.zeros((S, S, 3), dtype=torch.float32, device="cuda")
+    mask = torch.zeros((S, S), dtype=torch.uint8, device="cuda")
+    g.render_pass1(fb)
+    torch.cuda.synchronize()
+    d1 = (bits(fb.cpu().numpy()) != bits(p1)).any(-1)
+    assert not d1.any(), "pass 1: %d of %d pixels differ from the oracle" % (int(d1.sum()), S * S)
+    for frame in range(2):
+        fb.zero_(); mask.zero_()
+        g.render_frame(fb, mask)
+        assert g.frame_status() == 0
+        d = (bits(fb.cpu().numpy()) != bits(ref)).any(-1)
+        assert not d.any(), "frame %d: %d of %d pixels differ from the oracle" % (frame, int(d.sum()), S * S)
+    changed = (bits(ref) != bits(p1)).any(-1)
+    assert int(mask.sum()) >= int(changed.sum()) > 50000      # (every re-rendered pixel that changed was flagged)
+    g.close()
+
+
 def test_cfg5_8192_ssaa_sharded_8_ways(ra, oracle, torch_cuda):
     """BASELINE cfg5: the 250k-triangle scene at 8192x8192 with the Sobel-adaptive 4-ray pass, rows dealt to 8 parts
     (rtx_set_row_ownership, 64-row bands, halo recomputed): the 8 parts assemble to exactly the unsharded frame, and the
