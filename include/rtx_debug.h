@@ -15,12 +15,12 @@ int rtx_set_frame_mode(rtx_scene* scene, int mode); /* -1 measure and choose (de
 /* Host only (no device is touched): what rtx_scene_create derives from a mesh before uploading it -- the tree with S = rtx_wide_node_slots()
  * descendants per node (log2 S binary levels per fetch; n_wide records of 32 S bytes: S slots of {lo.x hi.x lo.y hi.y lo.z hi.z, link,
  * first}; 0 when the boxes are not nested) and the prune blocks of its slots (n_wide records of 64 S bytes: S {c[3], P, h[3], Pgen} then S
- * {qc[3], wlo, qr[3], whi}; rtx_device.h), plus the record of the whole mesh.  For the CPU tests of their
+ * {qc[3], wlo, qr[3], whi}; rtx_device.h, DESIGN_HISTORY.md 3.1c), plus the record of the whole mesh.  For the CPU tests of their
  * invariants (tests/test_host_cpu.py); cap_wide = records the output arrays hold. */
 int rtx_mesh_flatten_probe(const rtx_mesh* mesh, uint32_t* n_wide, void* wide_out, void* prune_out, uint32_t cap_wide, float* root_rec8);
 int rtx_wide_node_slots(void);      /* slots of a wide node in this build: 4 or 8 */
 
-/* Host only: the P of the source copies of the prune records (rtx_device.h PruneRec, csrc/rtx_source.hip sourceP)
+/* Host only: the P of the source copies of the prune records (rtx_device.h PruneRec, csrc/rtx_source.hip sourceP; DESIGN_HISTORY.md 3.1d)
  * for n triangles given as (v0, e1, e2) = 9 floats each, the source point S3, its radius sigma and cam != 0 when the rays start
  * at S (the camera) rather than pass through it (a point light).  The function the device kernels run, for the CPU tests of the
  * bound (tests/test_prune_bound_cpu.py). */
@@ -64,7 +64,8 @@ int rtx_vec_probe(int device, int op, uint32_t n, const float* a, const float* b
 int rtx_desc_serialize(const rtx_scene_desc* desc, void* out, size_t cap, size_t* need);
 
 /* rtx_bvh_build builds in a handful of launches (two persistent ones walk the tree through a queue of nodes); the level-by-level build of rounds 1-4 remains
- * as its fallback (a pool ran out, its watchdog fired).  mode 1 forces the fallback (tests compare the two); process-wide. */
+ * as its fallback (a pool ran out, its watchdog fired).  mode 1 forces the fallback (tests compare the two), mode 2 gives the persistent launches pools that are far
+ * too small (tests: they must give up cleanly and the fallback must take over); process-wide. */
 int rtx_bvh_build_mode(int mode);
 /* Kernel launches (fills included) of a finished build, and whether the persistent launches did it (1) or the level-by-level build (0). */
 int rtx_bvh_launches(const rtx_bvh* bvh, uint32_t* launches, int* queued);

@@ -471,7 +471,7 @@ namespace {
 
 // The host side of a mesh's upload, free of any device call (so that it can be checked without a GPU: rtx_mesh_flatten_probe):
 // 32-byte node records, the tree with every other level skipped (when every box lies inside its parent's), and the prune
-// blocks of its slots.
+// blocks of its slots (DESIGN_HISTORY.md 3.1c).
 struct FlatMesh {
 	std::vector<Node> nodes;
 	std::vector<WideNode> wide;

@@ -717,7 +717,8 @@ int buildQueued(const float* tri_pos, uint32_t n_tris, const float* root_lo, con
 	// every worker resident: a worker waits for nodes other workers make
 	const uint32_t G = (uint32_t)std::min(occ, 2) * (uint32_t)prop.multiProcessorCount, GW = (uint32_t)std::min(occW, 8) * (uint32_t)prop.multiProcessorCount;
 	const uint32_t slack = std::max(G, GW * 4u);
-	const uint32_t nodeCap = std::max<uint32_t>(2 * n_tris, 1024) + slack + 64;
+	// (mode 2, tests: pools far too small -- the launches must notice, say so and leave the build to the level-by-level path)
+	const uint32_t nodeCap = (gBvhBuildMode == 2 ? 64u : std::max<uint32_t>(2 * n_tris, 1024)) + slack + 64;
 	const unsigned long long idCap = std::min<unsigned long long>(32ull * n_tris + (1ull << 20), (1ull << 32) - 64);      // (ids of ALL levels: 27 levels x 2.6 n at the headline; three arrays)
 	std::vector<void*> scratch;
 	struct Cleanup { std::vector<void*>& v; ~Cleanup() { for (void* p : v) (void)hipFree(p); } } cleanup{ scratch };
@@ -951,7 +952,7 @@ int rtx_bvh_build(const float* tri_pos, uint32_t n_tris, const float* root_lo, c
 	return RTX_OK;
 }
 
-int rtx_bvh_build_mode(int mode) { if (mode < 0 || mode > 1) return fail(RTX_ERR_ARG, "rtx_bvh_build_mode: 0 or 1"); gBvhBuildMode = mode; return RTX_OK; }
+int rtx_bvh_build_mode(int mode) { if (mode < 0 || mode > 2) return fail(RTX_ERR_ARG, "rtx_bvh_build_mode: 0, 1 or 2"); gBvhBuildMode = mode; return RTX_OK; }
 int rtx_bvh_launches(const rtx_bvh* b, uint32_t* launches, int* queued)
 {
 	if (!b) return fail(RTX_ERR_ARG, "bvh is NULL");

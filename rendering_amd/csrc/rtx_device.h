@@ -46,7 +46,7 @@ static_assert(sizeof(WideNode) == 32 * kWideSlots && (kWideSlots == 4 || kWideSl
 // ray-independent, so computing them once on upload is bit-identical.  The arrays are padded by 64 entries: a wave
 // always loads 64 consecutive references, the ones past the end of the leaf are masked out.
 //
-// How a leaf is processed: the 64 lanes of the wave first act as 64 TRIANGLES -- each lane classifies its
+// How a leaf is processed (DESIGN_HISTORY.md 3.3): the 64 lanes of the wave first act as 64 TRIANGLES -- each lane classifies its
 // reference against the wave's whole ray BUNDLE (box of origins x box of directions) with division-free tests on the
 // Moller-Trumbore numerators and rigorous rounding-error margins; a reference survives unless the reference renderer
 // is CERTAIN to reject it for every ray of the bundle.  Then the lanes act as 64 RAYS again and run the reference's
@@ -56,13 +56,13 @@ struct RefB { float e1x, e1y, e1z, e2x; };
 struct RefC { float e2y, e2z; };
 static_assert(sizeof(RefA) == 16 && sizeof(RefB) == 16 && sizeof(RefC) == 8, "reference records = dwordx4 + dwordx4 + dwordx2");
 
-// Prune record of one WideNode slot: the TRUE box of every triangle referenced in the slot's subtree, as
+// Prune record of one WideNode slot (DESIGN_HISTORY.md 3.1c): the TRUE box of every triangle referenced in the slot's subtree, as
 // centre / half-extent, and P = the largest |e1|_1 |e2|_1 among them.  The reference finds a triangle through the loose
 // cell of its leaf (objects.cpp:587-631) but what it ACCEPTS lies near the triangle: with det_c >= 1e-8 (objects.cpp:75-79)
 // the point orig + t_c dir is within 36 u dmax |orig - v0|_inf P / 1e-8 of it, whatever the conditioning.  A slot whose
 // inflated box no ray of the bundle can meet within [0, limit] cannot contribute and is not walked.  h < 0: no triangles.
 //
-// Source records (round 4): the bound above takes the worst conditioning the reference lets through (det_c = 1e-8).
+// Source records (round 4, DESIGN_HISTORY.md 3.1d): the bound above takes the worst conditioning the reference lets through (det_c = 1e-8).
 // When every ray of a walk passes within sigma of ONE point S -- the camera (primary rays: sigma = 0) or a point light (shadow
 // rays: sigma ~ bias) -- the conditioning of an accepted pair is bounded by geometry instead: det = H |dir| / |S' - X*| with H the
 // height of S' above the triangle's plane and X* the exact plane intersection, so the accepted point lies within

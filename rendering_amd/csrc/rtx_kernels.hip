@@ -2,7 +2,7 @@
 // Phong-Fresnel-texture-skybox shading / Sobel mask / SSAA (reference: src/scene.cpp:381-946,
 // src/objects.cpp:59-175,534-631,766-824, src/lights.cpp:18-63).  Citations are file:line into the reference.
 //
-// Execution model:
+// Execution model (DESIGN_HISTORY.md section 3):
 //   * persistent waves pull work items (8x8 pixel tiles, or 16 / 4 / 1 SSAA pixels x 4 samples) from atomic queues;
 //   * the 64 lanes of a wave are 64 rays = one BUNDLE; every Render::trace of the wave is ONE cooperative walk
 //     (meshWalk): the reference's tree two levels per fetch (rtxd::WideNode, scalar loads, a wave-level stack in LDS),
@@ -368,7 +368,7 @@ template <typename T> __device__ __forceinline__ T after(T x, uint32_t v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// The ray bundle of one Render::trace of the wave, and the bundle filter
+// The ray bundle of one Render::trace of the wave, and the bundle filter (DESIGN_HISTORY.md 3.3)
 // ------------------------------------------------------------------------------------------------
 // Wave-wide maximum over the lanes (all 64 lanes execute this; lanes that must not contribute pass -inf).  Four DPP
 // steps inside each row of 16, two row broadcasts, the result is read from lane 63.
@@ -645,7 +645,7 @@ __device__ __forceinline__ bool boxFailsRegular(float blox, float bhix, float bl
 //   An accepted hit has det_c >= 1e-8, 0 <= u_c <= 1, 0 <= v_c, u_c + v_c <= 1 (+ one rounding), 0 <= t_c < limit.  With the
 //   identity  det (orig - v0) = -Nt dir + Nu e1 + Nv e2  (Cramer; exact for the fp32 inputs) and the reference's rounding
 //   errors (|det_c - det| <= 5.1 u dmax s1 s2, |Nu_c - Nu| <= 12.2 u dmax ainf s2, |Nv_c - Nv| <= 12.2 u dmax ainf s1,
-//   |Nt_c - Nt| <= 6.1 u ainf s1 s2; s1 = |e1|_1, s2 = |e2|_1, ainf = |orig - v0|_inf, u = 2^-24):
+//   |Nt_c - Nt| <= 6.1 u ainf s1 s2; s1 = |e1|_1, s2 = |e2|_1, ainf = |orig - v0|_inf, u = 2^-24, DESIGN_HISTORY.md 3.3):
 //       orig + t' dir = v0 + u' e1 + v' e2 + R / det_c,   |R|_inf <= 35.6 u dmax ainf s1 s2,
 //   where t', u', v' are the computed numerators over det_c -- within 2 roundings of t_c, u_c, v_c, so the right-hand point
 //   is in the triangle up to 3 u (s1 + s2).  Hence orig + t' dir lies in T inflated by rho = 36 u dmax ainf P / 1e-8
@@ -1540,7 +1540,7 @@ constexpr int kParkFields = 25 - (kParkColor ? 0 : 3);
 constexpr int kPk = kParkColor ? 0 : -3;          // index shift of the fields behind objColor      // (26 with nSpec until the eight-slot walk's stack needed the kilobyte: five blocks per CU hold 31 744 B each)
 __shared__ float parkedState[kParkFields][256];
 // Five blocks per CU hold 31 744 B of LDS each (160 KB / 5, rounded down to the allocation granule): one array over the edge and the pass-1 kernel silently
-// runs four blocks per CU (-3 ... -20 %).  sobelStage belongs to the frame kernel only (four blocks per CU: 40 960 B each).
+// runs four blocks per CU (-3 ... -20 %, DESIGN_HISTORY.md 3.1e).  sobelStage belongs to the frame kernel only (four blocks per CU: 40 960 B each).
 static_assert(sizeof(powTab) + sizeof(leafBatch) + sizeof(wideStack) + sizeof(pruneUni) + sizeof(parkedState) <= (RTX_WAVES >= 5 ? 31744 : 40960),
               "the ray kernels' LDS no longer fits the blocks per CU that RTX_WAVES asks for");
 
@@ -1797,7 +1797,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 		if (!STATS) {
 			// what the item cost, as the time of a 16-pixel item (a 4-pixel item takes at least a quarter of it), kept per tile
 			// in the second half of tileCost: a profiling aid (rtx_tile_cost_read, tools/ssaa_items.py).  Ordering and sizing
-			// the next frame's items by it was measured and lost to the pass-1 costs that do it now
+			// the next frame's items by it was measured and lost to the pass-1 costs that do it now (DESIGN_HISTORY.md 6c)
 			const uint32_t npx = (uint32_t)__popcll(ballot(valid)) >> 2;
 			const unsigned long long dt16 = (wall_clock64() - t0) * (npx <= 4u ? 4u : (npx <= 8u ? 2u : 1u));
 			if (lane == 0 && pxy != 0xffffffffu) atomicMax(P.tileCost + P.nTiles + (y >> 3) * P.tilesXFull + (x >> 3), (uint32_t)(dt16 > 0xffffffffull ? 0xffffffffull : dt16));

@@ -1,10 +1,10 @@
-// Source records of the prune blocks (rtxd::PruneRec): for every wide-node slot the largest P_S of the triangles
+// Source records of the prune blocks (rtxd::PruneRec, DESIGN_HISTORY.md 3.1d): for every wide-node slot the largest P_S of the triangles
 // below it, for one source S -- the camera (rebuilt with the view) or a point light.  Included by rtx_api.hip.
 //
 // What P_S bounds.  The reference's ray / triangle test (objects.cpp:59-95: pvec = dir x e2, det = e1 . pvec, u = tvec . pvec / det,
 // qvec = tvec x e1, v = dir . qvec / det, t = e2 . qvec / det; fp32, no FMA) accepts a pair when det_c >= 1e-8, 0 <= u_c <= 1,
 // 0 <= v_c, u_c + v_c <= 1, 0 <= t_c (< the ray's limit: scene.cpp:740).  With the exact numerators det = dir . m (m = e2 x e1),
-// Nu, Nv, Nt of the SAME fp32 inputs and the rounding errors of the reference's evaluation (u = 2^-24, s1 = |e1|_1,
+// Nu, Nv, Nt of the SAME fp32 inputs and the rounding errors of the reference's evaluation (DESIGN_HISTORY.md 3.3; u = 2^-24, s1 = |e1|_1,
 // s2 = |e2|_1, l1 = |e1|_2, l2 = |e2|_2, ainf = |orig - v0|_inf, dmax = |dir|_inf)
 //     |det_c - det| <= ed = 5.1 u dmax s1 s2,  |Nu_c - Nu| <= eu = 12.2 u dmax ainf s2,  |Nv_c - Nv| <= ev = 12.2 u dmax ainf s1,
 //     |Nt_c - Nt| <= et = 6.1 u ainf s1 s2

@@ -1,7 +1,7 @@
 // Compile-time tunables of the ray kernels (rtx_kernels.hip), all in one place.  Each can be overridden on the hipcc command
 // line (-DRTX_WAVES=6: tools/build_variants.sh builds such variants for A/B runs); the defaults are what the product ships.
 // Everything that used to be an experiment SWITCH (alternative walks, filters, stores ...) has been retired: the losing
-// branches are kept as a patch (tools/research/r04_experiment_branches.patch).
+// branches are kept as a patch (tools/research/r04_experiment_branches.patch, DESIGN_HISTORY.md).
 #pragma once
 
 #ifndef RTX_DBG

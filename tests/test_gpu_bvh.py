@@ -114,3 +114,21 @@ def test_persistent_build_equals_the_level_by_level_build(ra):
     for k in ("bounds", "skip", "leaf_begin", "leaf_count", "refs"):
         assert q[k].tobytes() == l[k].tobytes() == h[k].tobytes(), k
     assert q["max_depth"] == l["max_depth"] == h["max_depth"]
+
+
+def test_persistent_build_gives_up_cleanly_when_its_pools_run_out(ra):
+    """Pools far too small (rtx_bvh_build_mode(2)): the persistent launches report it instead of writing out of bounds or waiting for ever, and rtx_bvh_build
+    delivers the structure through the level-by-level path."""
+    s = ra.Scene("scenes/cfg2_smooth_25k.scene", 64, 64)
+    h = s.bvh(1)
+    s.close()
+    ra.bvh_build_mode(2)
+    try:
+        d = ra.bvh_build(h["tris"][:, :9], h["bounds"][0, :3], h["bounds"][0, 3:], 1)
+    finally:
+        ra.bvh_build_mode(0)
+    assert not d["queued"]
+    for k in ("bounds", "skip", "leaf_begin", "leaf_count", "refs"):
+        assert d[k].tobytes() == h[k].tobytes(), k
+    again = ra.bvh_build(h["tris"][:, :9], h["bounds"][0, :3], h["bounds"][0, 3:], 1)
+    assert again["queued"] and again["refs"].tobytes() == h["refs"].tobytes()

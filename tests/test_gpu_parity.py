@@ -188,7 +188,7 @@ def test_tile_cost_map(ra):
 
 
 def test_surface_rays_250k_bit_exact(ra, oracle):
-    """Stress of the leaf certificates on the headline mesh: 60k rays that START ON the surface
+    """Stress of the leaf certificates (DESIGN_HISTORY.md 3.3) on the headline mesh: 60k rays that START ON the surface
     (like shadow / reflection rays: most of the mesh lies behind them) in pseudo-random directions, plus rays from
     inside the mesh, far outside, axis-aligned and grazing -- hit records and colours against the oracle."""
     from rendering_amd import assets

@@ -176,7 +176,7 @@ def test_scene_flags_are_per_scene(ra):
 
 @pytest.mark.parametrize("scene,obj", [("scenes/cfg2_smooth_4k.scene", 1), ("scenes/cfg4_textured_256.scene", 0), ("scenes/coincident.scene", 1)])
 def test_prune_records_enclose_what_they_stand_for(ra, scene, obj):
-    """The prune blocks of the wide walk (rtx_mesh_flatten_probe, host only): for every slot of every wide node
+    """The prune blocks of the wide walk (DESIGN_HISTORY.md 3.1c; rtx_mesh_flatten_probe, host only): for every slot of every wide node
     the box record encloses all vertices of all triangles referenced below it and P bounds their |e1|_1 |e2|_1, the plane
     record encloses their scaled normals and plane offsets; the records of a slot enclose those of the wide node below it;
     the wide nodes hold exactly the reference's boxes (log2 S levels apart, S = rtx_wide_node_slots()) and reach every leaf reference once."""

@@ -1,4 +1,4 @@
-"""CPU: the error bound the prune records rest on: a hit the reference accepts lies within
+"""CPU: the error bound the prune records rest on (DESIGN_HISTORY.md 3.1c): a hit the reference accepts lies within
 36 u dmax ainf s1 s2 / det_c of its triangle's box -- and NOT within a small fixed margin: for rays nearly in the plane of a
 triangle the reference's fp32 arithmetic (objects.cpp:59-95, restated in numpy, no FMA) accepts hits far off the triangle."""
 import numpy as np
@@ -17,7 +17,7 @@ def test_accepted_hits_lie_within_the_bound_and_not_within_an_ulp_margin():
 
 
 def test_source_records_bound_accepted_hits():
-    """with the source certificate (rays that start at the camera / end at a point light) an accepted hit lies within
+    """DESIGN_HISTORY.md 3.1d: with the source certificate (rays that start at the camera / end at a point light) an accepted hit lies within
     216 dmax ainf P_S + 2^-17 (ainf + |orig|) of its triangle's box, P_S from the function the device runs (rtx_source_p_probe); pairs
     without a certificate fall back to Pgen and stay within the unconditional bound."""
     from tools.research.src_bound_check import run
