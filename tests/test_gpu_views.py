@@ -82,3 +82,29 @@ def test_set_view_does_not_wait_for_the_device(ra):
     assert g.frame_status() == 0
     assert dt < 6 * one, "rtx_scene_set_view took %.3f ms behind twelve queued frames of %.3f ms each: it waited for the device" % (dt * 1e3, one * 1e3)
     g.close()
+
+
+def test_views_on_a_non_blocking_render_stream(ra):
+    """The same camera sequence rendered on a NON-BLOCKING stream (torch.cuda.Stream(): the null stream's implicit ordering does not cover it): the work
+    rtx_scene_set_view queues on the null stream must be ordered behind the frames still running on the render stream and before the next one (two events:
+    prepBegin / prepEnd / renderOn in rtx_api.hip).  No host synchronisation between a frame and the next view; pictures == the null-stream ones."""
+    w, h = 640, 400
+    g = ra.Scene("scenes/cfg2_smooth_25k.scene", w, h)
+    want = []
+    for pos, rot in POSES:
+        g.set_camera(pos, rot)
+        want.append(frame(g, w, h, 0))
+    side = torch.cuda.Stream()
+    fbs = [torch.zeros((h, w, 3), dtype=torch.float32, device="cuda") for _ in POSES]
+    masks = [torch.zeros((h, w), dtype=torch.uint8, device="cuda") for _ in POSES]
+    torch.cuda.synchronize()
+    g.set_frame_mode(0)
+    for rounds in range(3):
+        for k, (pos, rot) in enumerate(POSES):
+            g.set_camera(pos, rot)                       # queued behind the previous view's frame, which may still be running on `side`
+            g.render_frame(fbs[k], masks[k], stream=side)
+        side.synchronize()
+        assert g.frame_status() == 0
+        for k in range(len(POSES)):
+            assert np.array_equal(bits(fbs[k].cpu().numpy()), bits(want[k][0])) and np.array_equal(masks[k].cpu().numpy(), want[k][1]), "view %d, round %d" % (k, rounds)
+    g.close()
