@@ -475,7 +475,7 @@ def main():
     # The GPU has been idle while the host loaded that scene, and its clocks need a few milliseconds to come back: a second
     # fresh scene is timed (HIP events) directly behind three frames of the warm one -- what the first frame costs in software
     # (no measured tile costs: the estimate of rtx_scene_create orders and splits it; tools/cold_probe.py).
-    cold_ms = cold_busy_ms = set_view_ms = new_view_host_ms = new_view_frame_ms = None
+    cold_ms = cold_busy_ms = set_view_ms = new_view_host_ms = new_view_frame_ms = new_view_device_ms = None
     if world == 1:
         scene2 = RA.Scene(args.scene, W, H, device=local)
         scene2.gpu()
@@ -510,15 +510,20 @@ def main():
         pos, rot = scene3.camera_pose()
         for _ in range(3):
             step()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        ea.record()
         tv = time.perf_counter()
         scene3.set_camera(pos + np.float32([0.02, 0.01, 0.0]), rot + np.float32([0.0, 0.7, 0.0]))
         scene3.gpu()
         new_view_host_ms = (time.perf_counter() - tv) * 1e3
+        eb.record()      # (what the view's preparation costs the DEVICE: source records of the camera, cost estimate, tile lists -- queued, ahead of the first frame)
         e0.record()
         parallel.shard_frame(scene3, fb3, mask3, 1, 0, ssaa=ssaa, clear=False)
         e1.record()
         torch.cuda.synchronize()
         new_view_frame_ms = e0.elapsed_time(e1)
+        new_view_device_ms = ea.elapsed_time(eb)
         scene3.close()
         del fb3, mask3
     # The SURVEY 8d byte model (32 B per box test + 40 B per triangle test counted under REFERENCE traversal semantics
@@ -587,6 +592,7 @@ def main():
                    "cold_frame_gpu_busy_before_ms": None if cold_busy_ms is None else round(cold_busy_ms, 3),
                    "set_view_ms": None if set_view_ms is None else round(set_view_ms, 3),
                    "new_view_host_ms": None if new_view_host_ms is None else round(new_view_host_ms, 3),
+                   "new_view_device_ms": None if new_view_device_ms is None else round(new_view_device_ms, 3),
                    "new_view_first_frame_ms": None if new_view_frame_ms is None else round(new_view_frame_ms, 3),
                    # the reference renders ONE frame per process (main.cpp:15): the first frame of a scene as a rate, beside `value` (the steady state of a view)
                    "cold_frame_mrays_s": None if cold_busy_ms is None else round(rays_per_frame / cold_busy_ms / 1e3, 1),

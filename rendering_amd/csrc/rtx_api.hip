@@ -424,18 +424,18 @@ int estimateCosts(rtx_scene* s)
 		s->costGridCap = cells;
 	}
 	HIPCHK(hipMemsetAsync(s->costGrid, 0, 2 * cells * sizeof(uint32_t), nullptr));
-	for (const auto& m : s->meshLeaves)
-		if (m.n) hipLaunchKernelGGL(rtxCostSplatKernel, dim3((m.n + 255) / 256), dim3(256), 0, nullptr, m.boxes, m.n, v, gridW, gridH, s->costGrid);
-	// the leaves' shadows on the planes, per point / distant light (rtxCostShadowSplatKernel); a handful of launches of a few microseconds
+	// the camera's splat and the leaves' shadows on the planes, per point / distant light (rtxCostSplatKernel): one launch per set of leaves
+	SplatSources src;
+	memset(&src, 0, sizeof(src));
 	if (s->knobs.estimateShadows)
 		for (size_t l = 0; l < s->estLights.size() && l < 8; l++)
-			for (size_t q = 0; q < s->estPlanes.size() && q < 4; q++)
-				for (const auto& m : s->meshLeaves) {
-					if (!m.n) continue;
-					const auto& L = s->estLights[l]; const auto& P = s->estPlanes[q];
-					hipLaunchKernelGGL(rtxCostShadowSplatKernel, dim3((m.n + 255) / 256), dim3(256), 0, nullptr, m.boxes, m.n, v, gridW, gridH, s->costGrid,
-					                   (int)L[3], L[0], L[1], L[2], P[0], P[1], P[2], P[3], P[4], P[5]);
-				}
+			for (size_t q = 0; q < s->estPlanes.size() && q < 4 && src.n < 16; q++) {
+				const auto& L = s->estLights[l]; const auto& P = s->estPlanes[q];
+				src.kind[src.n] = (int32_t)L[3]; memcpy(src.l[src.n], L.data(), 12); memcpy(src.p[src.n], P.data(), 24);
+				src.n++;
+			}
+	for (const auto& m : s->meshLeaves)
+		if (m.n) hipLaunchKernelGGL(rtxCostSplatKernel, dim3((m.n + 255) / 256, 1 + src.n), dim3(256), 0, nullptr, m.boxes, m.n, v, gridW, gridH, s->costGrid, src);
 	const uint32_t tiles = txFull * tyFull;
 	FarPlanes far;
 	memset(&far, 0, sizeof(far));
@@ -1194,6 +1194,9 @@ int prepareView(rtx_scene* s)
 	if (lastRow == 0) return RTX_OK;
 	rtx_scene::TileQueues* tq = nullptr;
 	if ((rc = buildTileList(s, 0, lastRow, tilesX, 0, (lastRow + 7) / 8, &tq, true))) return rc;
+	// the list and the buffers of the single launch: only where rtx_render_frame may take it (frames of more tiles render in three launches by rule)
+	const uint32_t ruleTiles = s->analytic ? s->knobs.frameRuleTilesAnalytic : s->knobs.frameRuleTiles;
+	if (tq->listed > ruleTiles && s->knobs.frameMode != 1 && s->frameModeForced != 1) return RTX_OK;
 	if ((rc = buildTileList(s, 0, lastRow, tilesX, 0, (lastRow + 7) / 8, &tq, false))) return rc;
 	const size_t tiles = (size_t)((v.width + 7) / 8) * ((v.height + 7) / 8);
 	size_t perQueue = 0;

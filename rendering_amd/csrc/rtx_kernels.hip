@@ -1914,17 +1914,37 @@ __global__ void __launch_bounds__(256) rtxFrameClearKernel(uint32_t* __restrict_
 // (the TRUE box of the leaf's triangles: the cells of the reference's builder are several times larger).
 // rtxCostFillKernel turns cells into ticks per tile (coefficients fitted to measured tile costs: tools/cost_fit.py).
 // The estimate only orders and splits work; no pixel depends on it.  Measured costs replace it tile by tile.
+// blockIdx.y = 0: the camera's splat; y >= 1: the shadow of the leaves cast by light / plane pair y - 1 (below).  One launch for all of them (they only add to the
+// grid), and one 64-bit atomic per cell: (references, leaves) are neighbouring words.
+struct SplatSources { uint32_t n; int32_t kind[16]; float l[16][3]; float p[16][6]; };      // kind 1: distant light (l = the direction it travels in), 2: point light (l = position); p = plane (position, normal)
 __global__ void __launch_bounds__(256) rtxCostSplatKernel(const float* __restrict__ boxes, uint32_t nLeaves, const View view, uint32_t gridW, uint32_t gridH,
-                                                          uint32_t* __restrict__ grid)
+                                                          uint32_t* __restrict__ grid, const SplatSources src)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nLeaves) return;
 	const float* b = boxes + (size_t)i * 8;      // true box of the leaf's triangles (lo, hi), reference count
 	const uint32_t n = (uint32_t)b[6];
 	const float* M = view.camM;
+	const uint32_t sIdx = blockIdx.y;
 	float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f;
 	for (int c = 0; c < 8; ++c) {
-		const float px = b[(c & 1) ? 3 : 0] - view.camPos[0], py = b[(c & 2) ? 4 : 1] - view.camPos[1], pz = b[(c & 4) ? 5 : 2] - view.camPos[2];
+		float cx = b[(c & 1) ? 3 : 0], cy = b[(c & 2) ? 4 : 1], cz = b[(c & 4) ? 5 : 2];
+		if (sIdx != 0) {
+			// The lights' side of the estimate (round 5): a tile of a PLANE that lies in the shadow of a leaf -- as seen from a point or distant light -- sends its
+			// shadow rays through that leaf (scene.cpp:787), and where they graze the mesh's silhouette such floor tiles cost as much as mesh tiles (up to 0.5 ms at
+			// the headline) while the camera's splat gives them 0: they ran last, four per atomic, and were the first frame's tail.  The corner is projected from the
+			// light onto the plane (beyond the corner, or the leaf casts no bounded shadow on it) and from there through the camera.
+			const uint32_t k = sIdx - 1;
+			const bool point = src.kind[k] == 2;
+			const float dx = point ? cx - src.l[k][0] : src.l[k][0], dy = point ? cy - src.l[k][1] : src.l[k][1], dz = point ? cz - src.l[k][2] : src.l[k][2];
+			const float nx = src.p[k][3], ny = src.p[k][4], nz = src.p[k][5];
+			const float den = dx * nx + dy * ny + dz * nz;
+			if (!(fabsf(den) > 1e-6f)) return;
+			const float t = ((src.p[k][0] - cx) * nx + (src.p[k][1] - cy) * ny + (src.p[k][2] - cz) * nz) / den;
+			if (!(t > 0.0f) || !(t < 1e4f)) return;
+			cx += t * dx; cy += t * dy; cz += t * dz;
+		}
+		const float px = cx - view.camPos[0], py = cy - view.camPos[1], pz = cz - view.camPos[2];
 		// camera space: the inverse of primaryRay()'s rotation (orthonormal rMatrix, scene.cpp:22-49)
 		const float sx = px * M[0] + py * M[1] + pz * M[2], sy = px * M[4] + py * M[5] + pz * M[6], sz = px * M[8] + py * M[9] + pz * M[10];
 		if (!(sz < -1e-4f)) return;                        // reaches behind the camera: no estimate from this leaf
@@ -1937,51 +1957,8 @@ __global__ void __launch_bounds__(256) rtxCostSplatKernel(const float* __restric
 	const int cy0 = max(0, (int)floorf(y0 / 16.0f)), cy1 = min((int)gridH - 1, (int)floorf(y1 / 16.0f));
 	if ((long long)(cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 4096) return;      // (a leaf that fills the screen says nothing about where the work is)
 	for (int cy = cy0; cy <= cy1; ++cy)
-		for (int cx = cx0; cx <= cx1; ++cx) {
-			atomicAdd(grid + 2 * ((size_t)cy * gridW + cx), n);
-			atomicAdd(grid + 2 * ((size_t)cy * gridW + cx) + 1, 1u);
-		}
-}
-
-// The lights' side of the estimate (round 5): a tile of a PLANE that lies in the shadow of a leaf -- as seen from a point or distant light -- sends its shadow
-// rays through that leaf (scene.cpp:787), and where they graze the mesh's silhouette such floor tiles cost as much as mesh tiles (up to 0.5 ms at the headline)
-// while the camera's splat gives them 0: they ran last, four per atomic, and were the first frame's tail.  Every leaf box is projected from the light onto the
-// plane and from there through the camera; its references are added to the cells the shadow's rectangle touches.  lightKind 1: distant (lp = the direction the
-// light travels in), 2: point (lp = position).
-__global__ void __launch_bounds__(256) rtxCostShadowSplatKernel(const float* __restrict__ boxes, uint32_t nLeaves, const View view, uint32_t gridW, uint32_t gridH,
-                                                                uint32_t* __restrict__ grid, int lightKind, float lx, float ly, float lz,
-                                                                float px, float py, float pz, float nx, float ny, float nz)
-{
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= nLeaves) return;
-	const float* b = boxes + (size_t)i * 8;
-	const uint32_t n = (uint32_t)b[6];
-	const float* M = view.camM;
-	float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f;
-	for (int c = 0; c < 8; ++c) {
-		const float cx = b[(c & 1) ? 3 : 0], cy = b[(c & 2) ? 4 : 1], cz = b[(c & 4) ? 5 : 2];
-		// where the light's ray through this corner meets the plane (beyond the corner, or the leaf casts no bounded shadow on it)
-		const float dx = lightKind == 2 ? cx - lx : lx, dy = lightKind == 2 ? cy - ly : ly, dz = lightKind == 2 ? cz - lz : lz;
-		const float den = dx * nx + dy * ny + dz * nz;
-		if (!(fabsf(den) > 1e-6f)) return;
-		const float t = ((px - cx) * nx + (py - cy) * ny + (pz - cz) * nz) / den;
-		if (!(t > 0.0f) || !(t < 1e4f)) return;
-		const float qx = cx + t * dx - view.camPos[0], qy = cy + t * dy - view.camPos[1], qz = cz + t * dz - view.camPos[2];
-		const float sx = qx * M[0] + qy * M[1] + qz * M[2], sy = qx * M[4] + qy * M[5] + qz * M[6], sz = qx * M[8] + qy * M[9] + qz * M[10];
-		if (!(sz < -1e-4f)) return;
-		const float xp = sx / -sz, yp = sy / -sz;
-		const float fx = (xp / (view.scale * view.aspect) + 1.0f) * 0.5f * (float)view.width - 1.0f, fy = (-yp / view.scale + 1.0f) * 0.5f * (float)view.height - 1.0f;
-		x0 = fminf(x0, fx); x1 = fmaxf(x1, fx); y0 = fminf(y0, fy); y1 = fmaxf(y1, fy);
-	}
-	if (!(x1 >= 0.0f && y1 >= 0.0f && x0 < (float)view.width && y0 < (float)view.height)) return;
-	const int cx0 = max(0, (int)floorf(x0 / 16.0f)), cx1 = min((int)gridW - 1, (int)floorf(x1 / 16.0f));
-	const int cy0 = max(0, (int)floorf(y0 / 16.0f)), cy1 = min((int)gridH - 1, (int)floorf(y1 / 16.0f));
-	if ((long long)(cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 4096) return;
-	for (int cy = cy0; cy <= cy1; ++cy)
-		for (int cx = cx0; cx <= cx1; ++cx) {
-			atomicAdd(grid + 2 * ((size_t)cy * gridW + cx), n);
-			atomicAdd(grid + 2 * ((size_t)cy * gridW + cx) + 1, 1u);
-		}
+		for (int cx = cx0; cx <= cx1; ++cx)
+			atomicAdd((unsigned long long*)(grid + 2 * ((size_t)cy * gridW + cx)), (1ull << 32) | n);      // (+ n references, + 1 leaf)
 }
 
 // farPlanes (up to four planes: position, normal) + farTicks: a tile through which the camera sees a plane FAR away (the horizon of a floor) shades points
