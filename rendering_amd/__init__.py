@@ -102,6 +102,8 @@ def load():
     rtx.rtx_gather_plan.argtypes = [u32, u32, u32, C.c_size_t, i32, u32, vp, vp, vp, C.POINTER(u32)]
     host.rah_set_ac_build.argtypes = [i32, i32]
     host.rah_set_ac_build.restype = None
+    host.rah_set_ac_build_device.argtypes = [i32]
+    host.rah_set_ac_build_device.restype = None
     host.rah_bvh_build_info.argtypes = [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_float)]
     host.rah_last_error.restype = C.c_char_p
     host.rah_scene_load.restype = vp
@@ -331,6 +333,7 @@ class Scene:
 
     def __init__(self, scene_path, width=-1, height=-1, device=0, cwd=ROOT):
         self.rtx, self.host = load()
+        self.host.rah_set_ac_build_device(device)      # a rank builds its structures on the GPU it renders on
         self.h = C.c_void_p(self.host.rah_scene_load(cwd.encode(), scene_path.encode(), width, height))
         if not self.h:
             raise RtxError("could not load scene %s: %s" % (scene_path, self.host.rah_last_error().decode(errors="replace")))

@@ -89,6 +89,8 @@ void rah_flat_free(void* f) { freeFlatScene((FlatScene*)f); }
 
 // Where the next rah_scene_load builds acceleration structures: -1 auto, 0 host builder, 1 device (rtx_bvh_build).
 void rah_set_ac_build(int mode, int device) { options::acBuildOnDevice = mode; options::acBuildDevice = device; }
+// Only the device (one process per GPU: every rank builds on the GPU it renders on, as render_amd does per rank).
+void rah_set_ac_build_device(int device) { options::acBuildDevice = device; }
 
 // {built on the device (0/1), device build time in ms}
 int rah_bvh_build_info(void* h, int obj, int* onDevice, float* ms)
