@@ -55,6 +55,8 @@ for seed in range(first, first + n):
         if frames: print("   rtx_render_frame differs in %d of 6 frames" % frames)
         print("MISMATCH seed", seed, "pass-1 pixels", int((bits(ref1) != bits(got1)).any(-1).sum()), "ssaa pixels", int((bits(ref2) != bits(got2)).any(-1).sum()))
     o.close(); g.close()
+    if (seed - first) % 250 == 249:      # (a run cut short by its time limit still leaves a record)
+        print("progress: seeds %d..%d: %d mismatching scenes" % (first, seed, bad), flush=True)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from srchash import source_hash
 print("seeds %d..%d: %d mismatching scenes; sources %s" % (first, first + n - 1, bad, source_hash()))
