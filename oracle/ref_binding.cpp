@@ -1,4 +1,5 @@
-// TEST INFRASTRUCTURE (build container only) -- never shipped, never on the product path.
+// TEST INFRASTRUCTURE -- built in the build container only (needs /root/reference), never on the product path.  The built binary ships to the GPU box
+// as a checker (see `render` below); the reference's sources never do.
 //
 // The binding of INTEGRATION.md, COMPILED AGAINST THE REAL REFERENCE: this file includes the reference's own headers
 // (/root/reference/include/scene.h:68-100, objects.h:24-200, lights.h:21-73, options.h:9-37), is linked with the reference's own
@@ -11,8 +12,10 @@
 //       loads the scene with the reference's Scene(path), fills the description exactly as uploadScene() does and writes its
 //       canonical bytes (rtx_desc_serialize, include/rtx_debug.h).  tests/test_ref_binding.py compares them with the bytes of
 //       the description this repo's own host builds for the same file (rendering_amd/host/src/scene.cpp, flattenScene).
-//   oracle/_ref/ref_binding render <cwd> <scene> <width> <height> <out.bmp>      (needs a GPU: the box never has /root/reference,
-//       so this mode is for a maintainer's machine; it is compiled here to prove the calls type-check against both sides)
+//   oracle/_ref/ref_binding render <cwd> <scene> <width> <height> <out.bmp>      (needs a GPU)
+//       the reference's Scene(path) -> uploadScene -> rtxLaunchWorkers + rtxLaunchSSAA -> the reference's own saveImage writes <out.bmp>;
+//       then rtxRender (the one-call form), whose bytes must equal the file's.  The BINARY travels to the GPU box with the snapshot (oracle/_ref/ is
+//       git-ignored, not gpurun-ignored; /root/reference itself never travels): tests/test_gpu_ref_binding.py runs it there -- the drop-in end to end.
 #include "scene.h"
 #include "stats.h"
 #include "timer.h"
@@ -229,16 +232,27 @@ int main(int argc, char** argv)
 		fclose(f);
 		return 0;
 	}
+	// render: the reference's own Scene::render() sequence (scene.cpp:595-657) with the two launchers replaced by the binding's -- a zeroed framebuffer,
+	// rtxLaunchWorkers, rtxLaunchSSAA, then THE REFERENCE'S saveImage (util.cpp:15-76) writes <out> -- and, beside it, the one-call form rtxRender, whose
+	// BGR bytes must be the pixel bytes of the file saveImage wrote (exit code 7 otherwise).
+	if (out.size() < 5 || out.substr(out.size() - 4) != ".bmp") { fprintf(stderr, "render: <out> must end in .bmp\n"); return 2; }
 	rtx_scene* g = uploadScene(scene);
-	std::vector<Vec3f> fbHost(scene.options.width * scene.options.height);
+	std::vector<Vec3f> fbHost(scene.options.width * scene.options.height, Vec3f(0, 0, 0));      // new Vec3f[H * W]() (scene.cpp:599)
 	rtxLaunchWorkers(scene, g, fbHost.data());
 	rtxLaunchSSAA(scene, g, fbHost.data());
+	Options opts = scene.options;
+	opts.imageName = out.substr(0, out.size() - 4);                // saveImage appends ".bmp" (util.cpp:17)
+	if (saveImage(fbHost.data(), opts) != 0) return 6;
 	std::vector<uint8_t> bgr;
 	rtxRender(scene, g, bgr);
-	FILE* f = fopen(out.c_str(), "wb");
-	if (!f) return 6;
-	fwrite(bgr.data(), 1, bgr.size(), f);
-	fclose(f);
+	{
+		FILE* f = fopen(out.c_str(), "rb");
+		if (!f) return 6;
+		std::vector<uint8_t> file(54 + bgr.size());
+		const size_t got = fread(file.data(), 1, file.size(), f);
+		fclose(f);
+		if (got != file.size() || memcmp(file.data() + 54, bgr.data(), bgr.size()) != 0) { fprintf(stderr, "rtxRender's bytes differ from the file saveImage wrote\n"); return 7; }
+	}
 	rtx_scene_destroy(g);
 	return 0;
 }

@@ -1,14 +1,17 @@
-// TEST INFRASTRUCTURE (this container only) -- never shipped, never on the product path.
+// TEST INFRASTRUCTURE -- built in the build container only (needs /root/reference), never on the product path.
 //
 // Thin C-ABI harness around the *real* holoskii/Rendering translation units.  It is compiled by
 // oracle/Makefile against the sources where they lie (/root/reference/src/{scene,objects,lights,util}.cpp,
 // headers from /root/reference/include) into oracle/_ref/libref_harness.so.  Nothing from the reference
 // is copied: this file only calls its public API (scene.h:31-100, objects.h:69-164).
 //
-// Used by tools/make_golden.py to (a) validate oracle/rt_oracle.cpp bit-for-bit and (b) emit the
-// committed golden vectors under tests/golden/.  /root/reference does not exist on the GPU box: the GPU tests and
-// smoke() never touch this library; the built oracle/_ref/ travels there for ONE purpose -- bench.py's cpu_baseline leg
-// times it (kind "reference") beside the oracle port, as the measured CPU baseline.  Never on the product path.
+// What travels: the reference's SOURCES never leave /root/reference; the BUILT files under oracle/_ref/ (git-ignored, not
+// gpurun-ignored) travel to the GPU box with the snapshot, as the task's rules for a compilable reference prescribe, and are used
+// there for exactly two things -- (1) bench.py's cpu_baseline leg times this library (kind "reference") and compares the timed GPU
+// frame with its framebuffers, (2) tests/test_gpu_ref_binding.py runs oracle/_ref/ref_binding (the reference's Scene class driving
+// the GPU through the binding of INTEGRATION.md).  Here, in the build container, tools/make_golden.py uses it to (a) validate
+// oracle/rt_oracle.cpp bit-for-bit and (b) emit the committed golden vectors under tests/golden/.  (SURVEY.md 8c planned for no
+// reference binary on the GPU box; the compiled reference is the better baseline and checker, so it ships -- DESIGN.md section 4.)
 #include "scene.h"
 #include "stats.h"
 #include "options.h"

@@ -161,6 +161,7 @@ struct rtx_scene {
 		uint32_t frameSamples[2] = { 0, 0 };
 		uint32_t framesSeen = 0, generation = 0;
 		bool fusedGaveUp = false;         // the single launch once ended with an error for this view: three launches from then on
+		hipStream_t builtOn = nullptr; hipEvent_t builtEv = nullptr;      // the stream rtxTileListKernel wrote the list on, and its completion
 	};
 	// the last frame rendered in one launch (rtx_frame_status renders it again in three if the launch gave up)
 	// (only while nothing it depends on has changed: the view and the row ownership it was rendered with are part of it, and
@@ -196,6 +197,10 @@ struct rtx_scene {
 	// stream the two events below carry the order both ways: the preparation waits for the last render call, the next render call for the preparation.
 	hipStream_t lastRenderStream = nullptr; bool rendered = false;
 	hipEvent_t evRenderDone = nullptr, evPrepDone = nullptr; bool prepRecorded = false; hipStream_t prepSeenBy = nullptr;
+	// every distinct non-null stream a render call was made on since the last preparation (pass 1 on A with the quantiser on B, two frames in flight:
+	// ADVICE r5): the preparation waits for each of them, and each waits for the preparation (prepSeen)
+	struct RenderStream { hipStream_t st = nullptr; hipEvent_t done = nullptr; bool active = false, prepSeen = false; };
+	std::vector<RenderStream> renderStreams;
 	// tile-list plans travel through a ring of pinned host buffers read by rtxTileListKernel (no staging copy, no synchronisation)
 	struct PlanSlot { uint32_t* host = nullptr; uint32_t* dev = nullptr; size_t capWords = 0; hipEvent_t done = nullptr; bool used = false, shared = false; };
 	uint32_t* planRingBase = nullptr;
@@ -337,10 +342,13 @@ int prepareView(rtx_scene* s);
 // Order of the null-stream preparation work against the caller's render stream (see rtx_scene::lastRenderStream).
 int prepBegin(rtx_scene* s)
 {
-	if (s->rendered && s->lastRenderStream != nullptr) {
-		if (!s->evRenderDone) HIPCHK(hipEventCreateWithFlags(&s->evRenderDone, hipEventDisableTiming));
-		HIPCHK(hipEventRecord(s->evRenderDone, s->lastRenderStream));
-		HIPCHK(hipStreamWaitEvent(nullptr, s->evRenderDone, 0));
+	for (auto& rs : s->renderStreams) {
+		if (!rs.active) continue;
+		if (!rs.done) HIPCHK(hipEventCreateWithFlags(&rs.done, hipEventDisableTiming));
+		// (a stream the caller has destroyed since is reported as an invalid handle: nothing of it can still be running)
+		if (hipEventRecord(rs.done, rs.st) == hipSuccess) HIPCHK(hipStreamWaitEvent(nullptr, rs.done, 0));
+		else (void)hipGetLastError();
+		rs.active = false;
 	}
 	return RTX_OK;
 }
@@ -349,13 +357,24 @@ int prepEnd(rtx_scene* s)
 	if (!s->evPrepDone) HIPCHK(hipEventCreateWithFlags(&s->evPrepDone, hipEventDisableTiming));
 	HIPCHK(hipEventRecord(s->evPrepDone, nullptr));
 	s->prepRecorded = true; s->prepSeenBy = nullptr;
+	for (auto& rs : s->renderStreams) rs.prepSeen = false;
 	return RTX_OK;
 }
 // every entry point that launches on the caller's stream calls this first
 int renderOn(rtx_scene* s, hipStream_t st)
 {
-	if (st != nullptr && s->prepRecorded && s->prepSeenBy != st) { HIPCHK(hipStreamWaitEvent(st, s->evPrepDone, 0)); s->prepSeenBy = st; }
 	s->lastRenderStream = st; s->rendered = true;
+	if (st == nullptr) return RTX_OK;      // (the legacy null stream orders itself against the preparation)
+	rtx_scene::RenderStream* rs = nullptr;
+	for (auto& r : s->renderStreams) if (r.st == st) { rs = &r; break; }
+	if (!rs) {
+		// (a handful of streams per scene; the oldest idle entry is recycled beyond 8 -- its stream has been waited for by the last preparation)
+		if (s->renderStreams.size() >= 8) { for (auto& r : s->renderStreams) if (!r.active) { rs = &r; break; } }
+		if (!rs) { s->renderStreams.emplace_back(); rs = &s->renderStreams.back(); }
+		rs->st = st; rs->active = false; rs->prepSeen = false;
+	}
+	if (s->prepRecorded && !rs->prepSeen) { HIPCHK(hipStreamWaitEvent(st, s->evPrepDone, 0)); rs->prepSeen = true; s->prepSeenBy = st; }
+	rs->active = true;
 	return RTX_OK;
 }
 
@@ -917,6 +936,8 @@ void rtx_scene_destroy(rtx_scene* s)
 	if (s->tileFlags) (void)hipFree(s->tileFlags);
 	if (s->tileClass) (void)hipFree(s->tileClass);
 	for (auto& pr : s->probes) { if (pr.a) (void)hipEventDestroy(pr.a); if (pr.b) (void)hipEventDestroy(pr.b); }
+	for (auto& q : s->tileQueues) if (q.builtEv) (void)hipEventDestroy(q.builtEv);
+	for (auto& rs : s->renderStreams) if (rs.done) (void)hipEventDestroy(rs.done);
 	for (auto& sl : s->planRing) { if (sl.done) (void)hipEventDestroy(sl.done); if (sl.host && !sl.shared) (void)hipHostFree(sl.host); }
 	if (s->planRingBase) (void)hipHostFree(s->planRingBase);
 	if (s->evRenderDone) (void)hipEventDestroy(s->evRenderDone);
@@ -984,7 +1005,7 @@ bool stripsFit(const View& v) { return v.height <= 32768u && v.width <= 262144u;
 // that belongs to another device -- is listed as 64 x 1 pixel strips (0x10000000 | strip << 16 | y) instead of 8 x 8
 // tiles with one live row each: a wave's time goes into walking its bundle whatever the number of live lanes, and the
 // halo rows are a quarter of the tile rows of a 64-row band.
-int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t tilesX, uint32_t tileRow0, uint32_t tilesY, rtx_scene::TileQueues** out, bool strips = false, hipStream_t st = nullptr)
+int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t tilesX, uint32_t tileRow0, uint32_t tilesY, rtx_scene::TileQueues** out, bool strips, hipStream_t st)
 {
 	const Params& p = s->params;
 	if (!stripsFit(p.view)) strips = false;
@@ -993,7 +1014,11 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 	for (int i = 0; i < 3; i++) { uint32_t w; memcpy(&w, &p.view.camPos[i], 4); key.push_back(w); }
 	{ uint32_t w; memcpy(&w, &p.view.scale, 4); key.push_back(w); memcpy(&w, &p.view.aspect, 4); key.push_back(w); }
 	for (auto& q : s->tileQueues)
-		if (q.list && q.key == key) { q.lastUse = ++s->tileUse; *out = &q; return RTX_OK; }
+		if (q.list && q.key == key) {
+			// (written on another stream -- the null stream of prepareView is covered by evPrepDone, a caller's second render stream is not: ADVICE r5)
+			if (q.builtEv && q.builtOn != st && q.builtOn != nullptr && st != nullptr) HIPCHK(hipStreamWaitEvent(st, q.builtEv, 0));
+			q.lastUse = ++s->tileUse; *out = &q; return RTX_OK;
+		}
 	// new entry (the least recently used one is recycled once there are 16; callers keep pointers to entries across calls
 	// that may add one: the vector never reallocates)
 	if (s->tileQueues.capacity() < 16) s->tileQueues.reserve(16);
@@ -1057,12 +1082,15 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 		plan[18 + 4 * t] += qBase[x]; plan[19 + 4 * t] += qBase[x] + cnt[x][0];
 	}
 	const size_t listWords = total;
-	if (listWords > s->listStride) {
+	// (every list of this view fits 16 + the frame's tiles: a strip row has fewer entries than a tile row.  Sized for that at once, so that the
+	// second list of a frame -- tiles after strips, an owned band after the whole frame -- never grows the slab under a `tq` the caller holds: ADVICE r5)
+	const size_t frameWords = 16 + (size_t)((p.view.width + 7) / 8) * ((p.view.height + 7) / 8);
+	if (std::max(listWords, frameWords) > s->listStride) {
 		HIPCHK(hipDeviceSynchronize());      // (growing: an earlier launch may still be reading the buffer that is freed)
 		if (s->listSlab) HIPCHK(hipFree(s->listSlab));
 		s->listSlab = nullptr; s->listStride = 0;
 		for (auto& q : s->tileQueues) { q.list = nullptr; q.key.clear(); q.costValid = false; }      // every cached list lived in the old slab
-		const size_t stride = (listWords + (listWords >> 3) + 4095) & ~(size_t)4095;
+		const size_t stride = (std::max(listWords, frameWords) + 4095) & ~(size_t)4095;
 		HIPCHK(hipMalloc((void**)&s->listSlab, 16 * stride * sizeof(uint32_t)));
 		s->listStride = stride;
 	}
@@ -1070,16 +1098,17 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 	e->cap = s->listStride;
 	// the ordered copy, where every tile may be listed in sixteen parts: ONE buffer per scene, shared by the cached lists (the
 	// launch that consumes it follows the ordering kernels on the same stream)
-	if (16 * listWords > s->orderedCap) {
+	if (16 * std::max(listWords, frameWords) > s->orderedCap) {
 		HIPCHK(hipDeviceSynchronize());
 		if (s->orderedList) HIPCHK(hipFree(s->orderedList));
 		s->orderedList = nullptr; s->orderedCap = 0;
-		HIPCHK(hipMalloc((void**)&s->orderedList, 16 * listWords * sizeof(uint32_t)));
-		s->orderedCap = 16 * listWords;
+		HIPCHK(hipMalloc((void**)&s->orderedList, 16 * std::max(listWords, frameWords) * sizeof(uint32_t)));
+		s->orderedCap = 16 * std::max(listWords, frameWords);
 	}
 	// The plan goes through a ring of pinned host buffers the kernel reads directly; a slot is taken again eight lists later (its event says whether the
 	// kernel that read it has run: it has, unless eight views were set without the device getting a turn).  The list that is recycled may still be read
-	// by an earlier launch: the kernel runs on the stream of the caller (or the null stream: prepareView), behind it.
+	// by an earlier launch: the kernel runs on the stream `st` the CALLER renders on (every render entry point passes its own; prepareView the null stream,
+	// ordered by prepBegin / prepEnd), behind that launch.
 	{
 		if (!s->planRing[0].host) {
 			// all eight slots in one pinned allocation, on first use (rtx_scene_create: not on the path of a new view), each good for 2 048 tile rows
@@ -1111,6 +1140,9 @@ int buildTileList(rtx_scene* s, uint32_t rowBegin, uint32_t lastRow, uint32_t ti
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(slot.done, st));
 		slot.used = true;
+		if (!e->builtEv) HIPCHK(hipEventCreateWithFlags(&e->builtEv, hipEventDisableTiming));
+		HIPCHK(hipEventRecord(e->builtEv, st));
+		e->builtOn = st;
 	}
 	if (s->verifyLists) {
 		// (tests: the straightforward construction on the host -- one entry after the other, the way rounds 1-4 built the list -- against what the device wrote)
@@ -1193,11 +1225,11 @@ int prepareView(rtx_scene* s)
 	const uint32_t tilesX = (v.width - 1 + 7) / 8, lastRow = v.height - 1;
 	if (lastRow == 0) return RTX_OK;
 	rtx_scene::TileQueues* tq = nullptr;
-	if ((rc = buildTileList(s, 0, lastRow, tilesX, 0, (lastRow + 7) / 8, &tq, true))) return rc;
+	if ((rc = buildTileList(s, 0, lastRow, tilesX, 0, (lastRow + 7) / 8, &tq, true, nullptr))) return rc;
 	// the list and the buffers of the single launch: only where rtx_render_frame may take it (frames of more tiles render in three launches by rule)
 	const uint32_t ruleTiles = s->analytic ? s->knobs.frameRuleTilesAnalytic : s->knobs.frameRuleTiles;
 	if (tq->listed > ruleTiles && s->knobs.frameMode != 1 && s->frameModeForced != 1) return RTX_OK;
-	if ((rc = buildTileList(s, 0, lastRow, tilesX, 0, (lastRow + 7) / 8, &tq, false))) return rc;
+	if ((rc = buildTileList(s, 0, lastRow, tilesX, 0, (lastRow + 7) / 8, &tq, false, nullptr))) return rc;
 	const size_t tiles = (size_t)((v.width + 7) / 8) * ((v.height + 7) / 8);
 	size_t perQueue = 0;
 	if (tiles < (1u << 24) && (rc = ensureFrameBuffers(s, tiles, &perQueue))) return rc;
@@ -1233,7 +1265,7 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	p.workCounter = s->work + 128;            // eight per-XCD queue heads, 64 bytes apart
 	if (p.view.width > 0x7fff8u || p.view.height > 0x7fff8u) return fail(RTX_ERR_ARG, "frame too large");
 	rtx_scene::TileQueues* tq = nullptr;
-	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY, &tq, true))) return rc;
+	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY, &tq, true, st))) return rc;
 	p.tileList = tq->list;
 	p.stripBit = stripsFit(p.view) ? 0x10000000u : 0u;
 	if (tq->costValid || s->costsUsable) {
@@ -1291,7 +1323,7 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	p.tilesYFull = (H + 7) / 8;
 	p.workCounter = s->work + 128;            // eight per-XCD queue heads, 64 bytes apart
 	rtx_scene::TileQueues* tq = nullptr;
-	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY, &tq))) return rc;
+	if ((rc = buildTileList(s, rowBegin, lastRow, p.tilesX, p.tileRow0, tilesY, &tq, false, st))) return rc;
 	const size_t tiles = (size_t)p.tilesXFull * p.tilesYFull;
 	size_t perQueue = 0;
 	if ((rc = ensureFrameBuffers(s, tiles, &perQueue))) return rc;
@@ -1399,7 +1431,7 @@ int rtx_render_frame(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	if (lastRow > rowBegin) {
 		const uint32_t tilesX = (W - 1 + 7) / 8, tileRow0 = rowBegin / 8;
 		// (the list of the three-launch path: its entry also keeps what was measured for this view)
-		if ((rc = buildTileList(s, rowBegin, lastRow, tilesX, tileRow0, (lastRow + 7) / 8 - tileRow0, &tq, true))) return rc;
+		if ((rc = buildTileList(s, rowBegin, lastRow, tilesX, tileRow0, (lastRow + 7) / 8 - tileRow0, &tq, true, st))) return rc;
 	}
 	// finished frames: take their durations
 	for (auto& pr : s->probes) {

@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(WAVE ? 256 : kQB) buildKernel(QNode* nodes, ui
 #ifdef RTX_BVHQ_DBG
 		if (tid == 0 && idx < 64) { gBvhqDbg[idx][1] = wall_clock64(); gBvhqDbg[idx][3] = count; }
 #endif
-		int bigDelta = -1;                                             // (WAVE = false: big nodes in flight: this one is done ...)
+		const int bigDelta = -1;                                       // (WAVE = false: big nodes in flight: this one is done ...)
 		bool rootDone = false;
 		if (!leaf) {
 			// ---- two node slots and nl + nr id slots (rounded up to whole 128-byte lines) with one atomic
@@ -569,10 +569,12 @@ __global__ void __launch_bounds__(WAVE ? 256 : kQB) buildKernel(QNode* nodes, ui
 					qstore(&c->begin, k ? rBegin : lBegin); qstore(&c->count, k ? nr : nl);
 					qstore(&c->depth, depth + 1); qstore(&c->parent, idx);
 				}
+				// (... its big children are counted BEFORE they are published: a child that finishes first must not see the counter at 0 for a moment and end
+				// the launch while its sibling is still on its way -- ADVICE r5)
+				if (!WAVE) { const uint32_t kids = (uint32_t)(nl > kSmall) + (uint32_t)(nr > kSmall); if (kids) atomicAdd(&ctl->big, kids); }
 				acknowledged();
 				qstore(&nodes[child].ready, 1u); qstore(&nodes[child + 1].ready, 1u);
 			}
-			bigDelta += (nl > kSmall) + (nr > kSmall);                 // (... its big children are on their way)
 		}
 		else if (tid == 0) {
 			// ---- a leaf: its subtree is complete; the second child to report completes the parent, and so on up to the root

@@ -145,14 +145,16 @@ int rah_bvh_from_tris(const float* pos, int n, const float* lo, const float* hi,
 			tris[i].c = Vec3f(pos[i * 9 + 6], pos[i * 9 + 7], pos[i * 9 + 8]);
 		}
 		Options o; o.acPenalty = acPenalty;
-		const int keep = options::acBuildOnDevice;
-		options::acBuildOnDevice = 0;                       // the host builder
-		const bool quiet = options::enableOutput;
-		options::enableOutput = false;
+		// the host builder, quietly; both process-wide options are put back on EVERY way out (setup may throw: guarded<> catches it -- ADVICE r5)
+		struct Restore {
+			decltype(options::acBuildOnDevice) keep = options::acBuildOnDevice; const bool quiet = options::enableOutput;
+			Restore() { options::acBuildOnDevice = 0; options::enableOutput = false; }
+			~Restore() { options::acBuildOnDevice = keep; options::enableOutput = quiet; }
+		};
 		AccelerationStructure ac;
 		ac.setBounds(Vec3f(lo[0], lo[1], lo[2]), Vec3f(hi[0], hi[1], hi[2]));
-		const bool ok = ac.setup(tris, o);
-		options::acBuildOnDevice = keep; options::enableOutput = quiet;
+		bool ok;
+		{ Restore restore; ok = ac.setup(tris, o); }
 		if (!ok) return -1;
 		counts[0] = (long long)ac.nodes.size(); counts[1] = (long long)ac.leafCount(); counts[2] = (long long)ac.refs.size(); counts[3] = ac.maxDepth;
 		if (!bounds) return 0;

@@ -1,0 +1,49 @@
+"""The reference's OWN Scene(path) driving the GPU, end to end (VERDICT r5 missing 3 / next 6).
+
+oracle/_ref/ref_binding is the binding of INTEGRATION.md compiled against /root/reference/include and linked with the reference's own translation units
+(oracle/Makefile; built in the build container, the BINARY travels to the GPU box with the snapshot -- the reference's sources never do).  Its `render`
+mode is Scene::render() (scene.cpp:595-657) with the two launchers replaced: the reference's loader (scene.cpp:57) -> uploadScene -> rtxLaunchWorkers
+(rtx_render_pass1) + rtxLaunchSSAA (rtx_sobel + rtx_render_ssaa) -> the reference's own saveImage (util.cpp:15-76) writes the BMP; then the one-call form
+rtxRender (rtx_render_frame + rtx_quantize_bgr8), whose bytes the binary itself compares with the file (exit code 7).  The files must be the ones the
+unmodified reference CLI writes: md5 0e5f3b78... (cfg1 at 512^2) and d96bcb54... (cfg1 at 1920x1080) are SURVEY.md 8c's, from oracle/_ref/render_ref; the
+mesh scenes are compared with the oracle's BMP bytes (pinned to the reference: tests/test_oracle_vs_reference.py)."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIND = os.path.join(ROOT, "oracle", "_ref", "ref_binding")
+needs_binding = pytest.mark.skipif(not os.path.exists(BIND), reason="oracle/_ref/ref_binding not built (needs /root/reference at build time)")
+
+
+def run_binding(tmp_path, scene, w, h):
+    out = tmp_path / "binding.bmp"
+    r = subprocess.run([BIND, "render", ROOT, "scenes/%s.scene" % scene, str(w), str(h), str(out)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "ref_binding render: rc %d\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    return out.read_bytes()
+
+
+@needs_binding
+@pytest.mark.parametrize("w,h,md5", [(512, 512, "0e5f3b78e230e36d9bc9ed8fcdfa6fd3"), (1920, 1080, "d96bcb5498c89ae781d4f508d31f0b51")])
+def test_reference_scene_class_drives_the_gpu_cfg1(ra, tmp_path, w, h, md5):
+    bmp = run_binding(tmp_path, "cfg1_simple_shapes", w, h)
+    assert len(bmp) == 54 + 3 * w * h
+    assert hashlib.md5(bmp).hexdigest() == md5, "the BMP written through the binding is not the reference CLI's"
+
+
+@needs_binding
+@pytest.mark.parametrize("scene,w,h", [("cfg2_smooth_4k", 320, 240), ("cfg4_textured_256", 256, 256), ("mixed_materials", 200, 152)])
+def test_reference_scene_class_drives_the_gpu_meshes(ra, oracle, tmp_path, scene, w, h):
+    bmp = run_binding(tmp_path, scene, w, h)
+    o = oracle.OracleScene("scenes/%s.scene" % scene, w, h)
+    want = oracle.encode_bmp(o.ssaa(o.pass1()))
+    assert len(bmp) == len(want)
+    if bmp != want:
+        # (row 0 / column 0 of the reference's SSAA are its uninitialised mask border, SURVEY 0.7: defined as "not re-rendered" here and in the oracle alike)
+        a = np.frombuffer(bmp, np.uint8)[54:].reshape(h, w, 3); b = np.frombuffer(want, np.uint8)[54:].reshape(h, w, 3)
+        raise AssertionError("%d pixels of the binding's BMP differ from the oracle's" % int((a != b).any(-1).sum()))

@@ -108,3 +108,43 @@ def test_views_on_a_non_blocking_render_stream(ra):
         for k in range(len(POSES)):
             assert np.array_equal(bits(fbs[k].cpu().numpy()), bits(want[k][0])) and np.array_equal(masks[k].cpu().numpy(), want[k][1]), "view %d, round %d" % (k, rounds)
     g.close()
+
+
+@pytest.mark.parametrize("how", ["rows", "ownership"])
+def test_list_cache_misses_on_a_non_blocking_render_stream(ra, how):
+    """a tile list that is NOT prepared by rtx_scene_set_view -- a row sub-range, or any view under row ownership (prepareView returns early) -- is
+    written by rtxTileListKernel inside the render call.  That kernel must run on the caller's stream: on the null stream nothing orders it against a
+    non-blocking render stream, neither before the launch that reads the list nor behind the earlier launch still reading the recycled entry.  A moving
+    camera, more views than the list cache holds, no host synchronisation inside a round; pictures == the ones rendered on the null stream."""
+    w, h = 640, 400
+    g = ra.Scene("scenes/cfg2_smooth_25k.scene", w, h)
+    poses = [((0.02 * k, 0.01 * k, 0.0), (0.0, 1.5 * k, 0.0)) for k in range(20)]      # 20 views x (1 or 2 lists) > the 16 cached lists
+    if how == "ownership":
+        g.set_row_ownership(64, 2, 1, True)
+    rows = (96, 304) if how == "rows" else None
+    want = []
+    for pos, rot in poses:
+        g.set_camera(pos, rot)
+        fb = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+        mask = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+        g.set_frame_mode(0)
+        g.render_frame(fb, mask, rows=rows)
+        torch.cuda.synchronize()
+        assert g.frame_status() == 0
+        want.append((fb.cpu().numpy(), mask.cpu().numpy()))
+    side = torch.cuda.Stream()
+    fbs = [torch.zeros((h, w, 3), dtype=torch.float32, device="cuda") for _ in poses]
+    masks = [torch.zeros((h, w), dtype=torch.uint8, device="cuda") for _ in poses]
+    torch.cuda.synchronize()
+    for mode in (0, 1):
+        g.set_frame_mode(mode)
+        for k, (pos, rot) in enumerate(poses):
+            g.set_camera(pos, rot)
+            fbs[k].zero_(); masks[k].zero_()
+            side.wait_stream(torch.cuda.current_stream())
+            g.render_frame(fbs[k], masks[k], rows=rows, stream=side)
+        side.synchronize()
+        assert g.frame_status() == 0
+        for k in range(len(poses)):
+            assert np.array_equal(bits(fbs[k].cpu().numpy()), bits(want[k][0])) and np.array_equal(masks[k].cpu().numpy(), want[k][1]), "%s: view %d, mode %d" % (how, k, mode)
+    g.close()
