@@ -166,9 +166,10 @@ def cpu_baseline_port(scene_path, width, height, gpu_scene, target_s=15.0):
 # not observable with the counters at hand), falling back to 4 cycles per instruction when no stamped ISA summary exists.
 SIMDS, CLOCK_GHZ = 1024, 2.4
 VALU_PEAK_GINSTR = SIMDS * CLOCK_GHZ / 4
-PMC_JSON = os.path.join(ROOT, "profiles", "r05_pass1_pmc.json")
-ISA_JSON = os.path.join(ROOT, "profiles", "r05_pass1_isa.json")
-ACCOUNT_JSON = os.path.join(ROOT, "profiles", "r05_issue_account.json")
+PROFILE_TAG = "r06"      # the round whose profiles/ summaries this file quotes (regenerate: tools/pmc_pass1.sh r06, tools/isa_mix.py, tools/issue_account.py)
+PMC_JSON = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pass1_pmc.json")
+ISA_JSON = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pass1_isa.json")
+ACCOUNT_JSON = os.path.join(ROOT, "profiles", PROFILE_TAG + "_issue_account.json")
 
 
 def stamped(path):
@@ -185,7 +186,7 @@ def stamped(path):
 
 def pmc_roofline(avg_ms, scene_bytes, fb_bytes, kernel="rtxPass1Kernel<false, true, true>", workload="headline"):
     """Hardware-counter side of the roofline of the dominant kernel (rtxPass1Kernel where the frame is three launches,
-    rtxFrameKernel where it is one): VALU wave-instructions and HBM-side bytes per launch from profiles/r05_pass1_pmc.json
+    rtxFrameKernel where it is one): VALU wave-instructions and HBM-side bytes per launch from profiles/<round>_pass1_pmc.json
     (tools/pmc_pass1.sh: separate rocprofv3 --pmc passes of this command), over the launch duration measured live in THIS run."""
     d, why = stamped(PMC_JSON)
     if d is None:
@@ -196,7 +197,7 @@ def pmc_roofline(avg_ms, scene_bytes, fb_bytes, kernel="rtxPass1Kernel<false, tr
     if w is None:
         return {"counters": None, "note": "%s holds no counters of workload '%s'" % (os.path.basename(PMC_JSON), workload)}
     # the workload runs ONE variant of its dominant kernel (MESH / BOXES template arguments follow the scene): matched by family
-    fam = "FrameKernel<" if "FrameKernel" in kernel else "Pass1Kernel<false"
+    fam = "FrameKernel<" if "FrameKernel" in kernel else ("SsaaKernel<false" if "SsaaKernel" in kernel else ("Sobel" if "Sobel" in kernel else "Pass1Kernel<false"))
     k = [v for n, v in w["kernels"].items() if fam in n]
     kname = [n for n in w["kernels"] if fam in n]
     if not k:
@@ -430,6 +431,7 @@ def main():
     # N > 1: what the timed region measured is THROUGHPUT when the exchange of frame k runs beside the rendering of frame k + 1 (the default); the LATENCY of one
     # frame -- render this rank's rows, quantise, gather on the render stream, wait -- is measured here, frame by frame (max over the ranks)
     frame_latency_ms = None
+    gather_ms_rank = 0.0
     if world > 1:
         def one_frame_serial():
             parallel.shard_frame(scene, fb, mask, world, rank, ssaa=ssaa, clear=False)
@@ -444,13 +446,27 @@ def main():
                 img.copy_(host)
         sync()
         one_frame_serial(); sync()
+        # (the exchange alone: events on the render stream around quantise + gather of every serial frame)
+        g0 = [torch.cuda.Event(enable_timing=True) for _ in range(5)]; g1 = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         tl = time.perf_counter()
-        for _ in range(5):
-            one_frame_serial()
+        for k in range(5):
+            parallel.shard_frame(scene, fb, mask, world, rank, ssaa=ssaa, clear=False)
+            g0[k].record()
+            scene.quantize(fb, img)
+            if comm is not None:
+                comm.gather(scene, img, bottom_up=True)
+            elif backend == "nccl":
+                parallel.gather_frame(img, world, rank, bottom_up=True)
+            else:
+                host = img.cpu()
+                parallel.gather_frame(host, world, rank, bottom_up=True)
+                img.copy_(host)
+            g1[k].record()
             sync()
         lat = torch.tensor([(time.perf_counter() - tl) / 5], dtype=torch.float64, device=rdev)
         dist.all_reduce(lat, op=dist.ReduceOp.MAX)
         frame_latency_ms = float(lat[0]) * 1e3
+        gather_ms_rank = sum(a.elapsed_time(b) for a, b in zip(g0, g1)) / 5
 
     verified = None
     if args.verify and world > 1:
@@ -466,10 +482,26 @@ def main():
     n2, ms2 = scene.kernel_time_stats(2)
     n4, ms4 = scene.kernel_time_stats(4)
     frame_mode, split_ms, fused_ms = scene.frame_mode() if ssaa else (0, -1.0, -1.0)
-    # the dominant kernel: pass 1, or the single kernel of the frame where that is what ran
+    nS, msS = scene.kernel_time_stats(1)
+    # the dominant kernel = the launch with the largest SUMMED duration over the timed region (on cfg3 that is the SSAA launch,
+    # not pass 1): pass 1, Sobel, SSAA, or the single kernel of the frame where that is what ran
     one_launch = ssaa and n4 > n1
-    dom_kernel = "rtxFrameKernel<true, true>" if one_launch else "rtxPass1Kernel<false, true, true>"
-    avg_ms = ms4 / max(n4, 1) if one_launch else ms1 / max(n1, 1)
+    stages = {"rtxPass1Kernel<false, true, true>": (n1, ms1), "rtxSobelKernel": (nS, msS), "rtxSsaaKernel<false, true, true>": (n2, ms2), "rtxFrameKernel<true, true>": (n4, ms4)}
+    dom_kernel = max(stages, key=lambda k: stages[k][1])
+    n_dom, ms_dom = stages[dom_kernel]
+    avg_ms = ms_dom / max(n_dom, 1)
+    # N > 1: what the RCCL communicator itself says it is, and the slowest rank's stage times (the frame ends when the slowest rank does; the first real
+    # SCALE line should explain itself: VERDICT r5 next 9)
+    rccl_ranks = per_rank_max = None
+    if world > 1:
+        if comm is not None:
+            rccl_ranks = comm.info()[0]
+        mine = [ms1 / n1 if n1 else 0.0, msS / nS if nS else 0.0, ms2 / n2 if n2 else 0.0, ms4 / n4 if n4 else 0.0, gather_ms_rank]
+        mx = torch.tensor(mine, dtype=torch.float64, device=rdev); mn = mx.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        names = ("pass1_ms", "sobel_ms", "ssaa_ms", "frame_kernel_ms", "quantize_gather_ms")
+        per_rank_max = {k: round(float(v), 3) for k, v in zip(names, mx)}
+        per_rank_max.update({"min_" + k: round(float(v), 3) for k, v in zip(names, mn)})
     # cold frame: a freshly created scene in the warm process -- its first pass 1 has no tile costs of a previous launch to
     # order its queues by (the reference's use case is one frame per process)
     # The GPU has been idle while the host loaded that scene, and its clocks need a few milliseconds to come back: a second
@@ -532,7 +564,8 @@ def main():
     rendered_px = (W - 1) * (H - 1) / world
     alg_bytes = 32.0 * float(c1[1]) + 40.0 * float(c1[2]) + 12.0 * rendered_px
     walked = rays_per_frame - int(tot[3])
-    roof = {"bound": "valu_issue", "kernel": dom_kernel, "avg_launch_ms": round(avg_ms, 3), "launches_timed": n4 if one_launch else n1,
+    roof = {"bound": "valu_issue", "kernel": dom_kernel, "avg_launch_ms": round(avg_ms, 3), "launches_timed": n_dom,
+            "launch_ms_by_stage": {k: round(v[1] / v[0], 3) for k, v in stages.items() if v[0]},
             "unit": "G wave-instructions/s", "peak": SIMDS * CLOCK_GHZ / 2, "achieved": None, "frac": None, "traffic": None,
             "algorithmic_ref_semantics_bytes": int(alg_bytes), "box_tests": int(c1[1]), "tri_tests": int(c1[2])}
     if world == 1:
@@ -556,6 +589,9 @@ def main():
             # byte model of the REFERENCE's traversal (32 B per box test + 40 B per triangle test + 12 B per pixel) would need at this speed, as a
             # multiple of the peak: far above 1 means the kernel does not do the reference's per-ray work (it shares every fetch among 64 rays and
             # rejects whole groups of triangles), which is why the line's `frac` is the VALU-issue fraction.
+            # what measures headroom: the share of the issue peak that carries USEFUL arithmetic (box / triangle / shading arithmetic of the reference's own
+            # algorithm; the rest is bundle, prune, queue and bookkeeping overhead -- profiles/<round>_issue_account.txt)
+            roof["useful_frac"] = round(roof["frac"] * pm["useful_valu_frac"], 4) if pm.get("useful_valu_frac") else None
             roof["hbm_frac"] = pm["hbm"]["frac"]
             roof["ref_semantics_bytes_over_peak"] = round(alg_bytes / (avg_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 2)
             if mean_cycles:
@@ -566,8 +602,10 @@ def main():
         roof["counters"] = pm
     out = {
         "metric": "Mrays/s + ms/frame at 4096^2, 250k-tri BVH scene",
-        "value": round(rays_per_frame * args.steps / dt / 1e6, 3),
-        "value_walked": round(walked * args.steps / dt / 1e6, 3),      # without the moot shadow rays, which are counted (the reference casts them) but never walked
+        # `value` counts the rays the kernels WALK.  The reference also casts `moot_shadow_rays` (stats::raysCasted counts them): shadow rays whose answer cannot
+        # change the pixel, which the kernels provably need not trace -- `value_counted` includes them (the reference's own definition of a ray)
+        "value": round(walked * args.steps / dt / 1e6, 3),
+        "value_counted": round(rays_per_frame * args.steps / dt / 1e6, 3),
         "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -576,15 +614,16 @@ def main():
         "config": {"workload": "%s @%dx%d, pass 1%s" % (os.path.basename(args.scene), W, H, " + Sobel-adaptive SSAA" if ssaa else ""),
                    "name": args.config,
                    "rays_per_frame": rays_per_frame, "moot_shadow_rays": int(tot[3]),
-                   "walked_rays_per_frame": walked, "walked_mrays_s": round(walked * args.steps / dt / 1e6, 3),
+                   "walked_rays_per_frame": walked, "counted_mrays_s": round(rays_per_frame * args.steps / dt / 1e6, 3),
                    "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.band_height(H, world), world, ", BGR8 bands collected on rank 0" if world > 1 else ""),
-                   "gather": gather_via,
+                   "gather": gather_via, "rccl_ranks": rccl_ranks, "slowest_rank": per_rank_max,
                    # N > 1: ms_per_step is pipelined throughput when the gather overlaps the next frame's render; frame_latency_ms is one frame end to end
                    "ms_per_step_is": None if world == 1 else ("pipelined throughput (gather of frame k beside the render of frame k + 1)" if pipe is not None else "serial frames (render, gather, next frame)"),
                    "frame_latency_ms": None if frame_latency_ms is None else round(frame_latency_ms, 3),
                    "frame": ("one launch (rtxFrameKernel)" if one_launch else "three launches (pass 1, Sobel, SSAA)") if ssaa else "pass 1 only",
                    "measured_three_launches_ms": None if split_ms < 0 else round(split_ms, 3), "measured_one_launch_ms": None if fused_ms < 0 else round(fused_ms, 3),
                    "pass1_ms": round(ms1 / n1, 3) if n1 else None, "ssaa_ms": round(ms2 / n2, 3) if n2 else None,
+                   "sobel_ms": round(msS / nS, 3) if nS else None,
                    "pass1_grays_s": round(float(tot_p1) / (ms1 / n1) / 1e6, 2) if n1 else None, "ssaa_grays_s": round(float(tot_p2) / (ms2 / n2) / 1e6, 2) if n2 and ssaa else None,
                    "scene_create_ms": round(scene_create_ms, 1), "bvh_build": bvh_ms,
                    "frame_kernel_ms": round(ms4 / n4, 3) if n4 else None,
@@ -595,8 +634,8 @@ def main():
                    "new_view_device_ms": None if new_view_device_ms is None else round(new_view_device_ms, 3),
                    "new_view_first_frame_ms": None if new_view_frame_ms is None else round(new_view_frame_ms, 3),
                    # the reference renders ONE frame per process (main.cpp:15): the first frame of a scene as a rate, beside `value` (the steady state of a view)
-                   "cold_frame_mrays_s": None if cold_busy_ms is None else round(rays_per_frame / cold_busy_ms / 1e3, 1),
-                   "cold_frame_wall_mrays_s": None if cold_ms is None else round(rays_per_frame / cold_ms / 1e3, 1),
+                   "cold_frame_mrays_s": None if cold_busy_ms is None else round(walked / cold_busy_ms / 1e3, 1),
+                   "cold_frame_wall_mrays_s": None if cold_ms is None else round(walked / cold_ms / 1e3, 1),
                    "pass1_rays_rank0": int(c1[0]), "ssaa_rays_rank0": int(c2[0]), "ssaa_pixels_rank0": int(mask.sum()),
                    "ssaa_box_tests": int(c2[1]), "ssaa_tri_tests": int(c2[2])},
         "roofline": roof,

@@ -246,6 +246,12 @@ class Comm:
         _check(self.rtx.rtx_gather(scene.gpu(), self.h, C.c_void_p(img.data_ptr()), row_bytes, int(bottom_up), root,
                                    Scene._stream_ptr(stream)), "rtx_gather")
 
+    def info(self):
+        """rtx_comm_info: (n_ranks, rank) as the RCCL communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = C.c_int(0), C.c_int(0)
+        _check(self.rtx.rtx_comm_info(self.h, C.byref(n), C.byref(r)), "rtx_comm_info")
+        return n.value, r.value
+
     def agree(self, ok, stream=None):
         """rtx_comm_agree: True iff every rank passed ok=True (called before gather, so that a failed rank does not leave the others waiting)."""
         out = C.c_int(0)
