@@ -661,7 +661,9 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 					PlaneRec& pl = prune[wi].plane[k];
 					memset(&pr, 0, sizeof(pr)); memset(&pl, 0, sizeof(pl));
 					pr.h[0] = pr.h[1] = pr.h[2] = -1e30f;      // empty: nothing can meet it
-					pl.qr[0] = pl.qr[1] = pl.qr[2] = -1.0f;    // no plane bound
+					// no plane bound: a record that can never be "dead" whatever the bundle -- q = 0 +- 0 (max dir . q + 2 kd >= 0), offsets in [-inf, +inf]
+					// (planeAlive's three rejections are all false for it; pruneEval8 has no separate "usable" test)
+					pl.wlo = -INFINITY; pl.whi = INFINITY;
 					const uint32_t nd = slotNode[wi][k];
 					if (nd == kNoNode) continue;
 					const Agg& a = agg[nd];

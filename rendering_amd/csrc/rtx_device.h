@@ -34,7 +34,7 @@ constexpr int kWideSlots = 1 << kWideLevels;
 // entries of the walk's per-wave stack in LDS (meshWalk): at most kWideSlots - 1 per wide level + 1 -- rtx_scene_create checks a mesh's depth against it
 // (a deeper tree is walked in the binary form).  Five blocks per CU hold 31 744 B of LDS each (the allocation granule): 76 entries x 16 B x 4 waves fit
 // beside 25 parked fields.
-constexpr int kWideStackEntries = kWideSlots == 4 ? 56 : (kWideSlots == 8 ? 76 : 124);
+constexpr int kWideStackEntries = kWideSlots == 4 ? 56 : (kWideSlots == 8 ? 72 : 124);      // (72: ten wide levels = thirty binary ones need 71; 256 bytes of LDS went to pruneUni's axis records)
 struct WideNode { Node slot[kWideSlots]; };
 static_assert(sizeof(WideNode) == 32 * kWideSlots && (kWideSlots == 4 || kWideSlots == 8 || kWideSlots == 16), "wide node = two s_load_dwordx16 per four slots");
 
@@ -78,7 +78,7 @@ constexpr float kSrcAinfMax = 32.0f;         // the source certificate assumes |
 // Its companion: box (centre qc, half-extent qr) of the scaled plane normals q = (e2 x e1) / (|e1|_1 |e2|_1) of those triangles
 // (|q|_inf <= 1) and the range [wlo, whi] of their plane offsets v0 . q.  The first stage of the bundle filter -- every ray
 // certainly sees the back / starts beyond the plane / ends before it -- holds for ALL triangles of the slot when it holds for
-// the box (interval arithmetic): det / (s1 s2) = dir . q,  Nt / (s1 s2) = v0 . q - orig . q.   qr < 0: no usable bound.
+// the box (interval arithmetic): det / (s1 s2) = dir . q,  Nt / (s1 s2) = v0 . q - orig . q.   No usable bound: q = 0 +- 0, [wlo, whi] = [-inf, +inf] (never rejected).
 struct PlaneRec { float qc[3]; float wlo; float qr[3]; float whi; };
 static_assert(sizeof(PlaneRec) == 32, "plane record = two dwordx4");
 // per wide node: PruneRec[kWideSlots] then PlaneRec[kWideSlots] (slot order) = 64 bytes per slot; lane k of the first 2 kWideSlots lanes of a wave reads record k

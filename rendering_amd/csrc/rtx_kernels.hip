@@ -124,8 +124,33 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y 
 __device__ __forceinline__ float len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 // geometry.h:99-102: (float)sqrt((double)len2) == correctly rounded sqrtf (53 >= 2*24+2)
 __device__ __forceinline__ float length(V3 a) { return __builtin_sqrtf(len2(a)); }
-// geometry.h:104-112: factor = (float)(1 / sqrt((double)len2))
-__device__ __forceinline__ float invLenD(float l2) { return (float)(1.0 / __builtin_sqrt((double)l2)); }
+// geometry.h:104-112: factor = (float)(1 / sqrt((double)len2)).  As written that is ~40 fp64 instructions (an fp64 square root and an fp64 division: two quarter-rate
+// transcendentals and two dozen half-rate FMAs), several times per shaded point (the primary direction, the normal, every light's L).  The fast path below
+// reaches the SAME float in 16 fp32 instructions: v_rsq_f32, one Newton step whose residual 1 - l2 y^2 is formed exactly (FMA: l2 y = t + te), and the exact
+// residual e1 of the candidate y1, which says how far y1 is from the true 1 / sqrt(l2) in units of its own last place: |y1 e1| / 2 < ulp / 2 (1 - 2^-16) means y1 is the
+// correctly rounded float of the true value with room to spare, and the reference's value -- the true value rounded to double twice (relative 2^-52), then to
+// float -- can only differ from that within 2^-28 ulp of a rounding boundary.  Otherwise (15 inputs in a million), and outside [2^-60, 2^60], the lane takes the
+// fp64 path.  Proof by enumeration: tools/research/rsqrt_exhaustive.c tries every mantissa, both exponent parities and every starting value within 3 ulp
+// of the truth (352 M cases: accepted => bit-identical; v_rsq_f32 is good to 1 ulp); on the device tests/test_gpu_parity.py runs all 2^24 mantissas.
+__device__ __forceinline__ float invLenSlow(float l2) { return (float)(1.0 / __builtin_sqrt((double)l2)); }
+__device__ __forceinline__ float invLenD(float l2)
+{
+#if RTX_FAST_INVLEN
+	const float y0 = __builtin_amdgcn_rsqf(l2);
+	const float t = l2 * y0, te = __builtin_fmaf(l2, y0, -t);
+	float e = __builtin_fmaf(-t, y0, 1.0f); e = __builtin_fmaf(-te, y0, e);
+	const float y1 = __builtin_fmaf(y0 * 0.5f, e, y0);
+	const float t1 = l2 * y1, t1e = __builtin_fmaf(l2, y1, -t1);
+	float e1 = __builtin_fmaf(-t1, y1, 1.0f); e1 = __builtin_fmaf(-t1e, y1, e1);
+	const float ulp = __uint_as_float((__float_as_uint(y1) & 0x7f800000u) - (23u << 23));
+	const bool sure = fabsf(e1 * y1) < ulp * 0.99998474f && l2 >= 0x1p-60f && l2 <= 0x1p60f;      // (NaN compares false: the fp64 path)
+	float r = y1;
+	if (!sure) r = invLenSlow(l2);
+	return r;
+#else
+	return invLenSlow(l2);
+#endif
+}
 __device__ __forceinline__ V3 normalized(V3 a)
 {
 	float l2 = len2(a);
@@ -421,7 +446,9 @@ __device__ __forceinline__ void waveMaxMin(float& hi, float& lo)
 	lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo), 63));
 }
 
-__device__ __forceinline__ Bundle makeBundle(bool active, const V3& o, const V3& d)
+// sameOrigin: every active lane's origin is the SAME point bit for bit (rays handed in at the camera: traceWave) -- the origin box is that point,
+// radius 0 (three of the six wave reductions are not needed)
+__device__ __forceinline__ Bundle makeBundle(bool active, const V3& o, const V3& d, bool sameOrigin = false)
 {
 	const float ninf = -__builtin_inff();
 	Bundle B;
@@ -432,7 +459,15 @@ __device__ __forceinline__ Bundle makeBundle(bool active, const V3& o, const V3&
 #else
 #define RTX_RANGE(x, c, r) hi = waveMax(active ? (x) : ninf); lo = -waveMax(active ? -(x) : ninf); centreRadius(lo, hi, c, r)
 #endif
-	RTX_RANGE(o.x, B.ocx, B.rox); RTX_RANGE(o.y, B.ocy, B.roy); RTX_RANGE(o.z, B.ocz, B.roz);
+	if (RTX_SAME_ORIGIN && sameOrigin) {
+		const int first = __builtin_ctzll(ballot(active) | (1ull << 63));
+		B.ocx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.x), first)); B.ocy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.y), first));
+		B.ocz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.z), first));
+		B.rox = B.roy = B.roz = 0.0f;
+	}
+	else {
+		RTX_RANGE(o.x, B.ocx, B.rox); RTX_RANGE(o.y, B.ocy, B.roy); RTX_RANGE(o.z, B.ocz, B.roz);
+	}
 	RTX_RANGE(d.x, B.dcx, B.rdx); RTX_RANGE(d.y, B.dcy, B.rdy); RTX_RANGE(d.z, B.dcz, B.rdz);
 #undef RTX_RANGE
 	const float dmax = fmaxf(fmaxf(fabsf(B.dcx) + B.rdx, fabsf(B.dcy) + B.rdy), fabsf(B.dcz) + B.rdz) * (1.0f + 0x1p-20f);
@@ -620,7 +655,15 @@ __shared__ WideItem wideStack[4][kWideStackEntries];      // (kWideSlots - 1 ent
 // walk: [0..5] the range of 1 / dir over the rays per axis (lo, hi; mirrored so that it is positive), [6..11] the range of
 // the origins per axis in the same mirrored coordinates (lo, hi), [12] 216 dmax, [13] the largest |origin| coordinate,
 // [14] bits 0-2: axis mirrored, bits 3-5: axis usable (1 / dir of one sign over the wave).
+#if RTX_PRUNE_AXIS
+// RTX_PRUNE_AXIS: the same quantities laid out for pruneEval8 -- six records of eight floats per wave, one per (test, axis):
+// [0..2] box test, axis x / y / z: { 1 / dir lo, hi (mirrored: positive), origin lo, hi (mirrored), the sign bit that mirrors a record's centre, +inf (axis usable) / -inf,
+//                                    216 dmax, the largest |origin| coordinate };
+// [3..5] plane test, axis x / y / z: { dc, rd, oc, ro (the bundle's direction / origin boxes as centre, radius), 2 K dmax, K (|orig| + |vertex|), -, - }
+__shared__ float pruneUni[4][48];
+#else
 __shared__ float pruneUni[4][24];      // ([16..18] the sign bits that mirror a record's centre, [19..21] per axis +inf (usable) / -inf (not))
+#endif
 // the prune records of the root's slots are evaluated too: +-0 with four slots (two levels down: as good as never pruned), -1.6 % with eight
 constexpr bool kPruneRoot = kWideLevels >= 3;
 // 36 u / 1e-8 (u = 2^-24) = 214.6: see pruneSlots
@@ -715,6 +758,80 @@ __device__ __forceinline__ bool planeAlive(const f4v& r0, const f4v& r1, const B
 	return !(dead && r1.x >= 0.0f);
 }
 
+#if RTX_PRUNE_AXIS
+// pruneAlive and planeAlive of the eight slots of one wide node with the lanes acting as (record, AXIS) pairs instead of records: lane 4 r + a looks at axis a
+// of record r (r < 8: slot r's PruneRec, r >= 8: slot r - 8's PlaneRec; a = 3: the record's fourth words -- P / Pgen, wlo / whi -- which it hands to its quad), so
+// that the per-axis arithmetic of both tests is one instruction for all three axes and what joins the axes (the largest |orig - vertex|, entry / exit, the three
+// dot products) is two DPP steps inside the quad: rotations among lanes 0-2 (lane 3 is never read).  ~70 VALU instructions per node visit against ~110 with one
+// record per lane on 16 lanes ("the prune / plane record evaluation runs on 16 of 64 lanes").  Same inequalities, same margins as pruneAlive /
+// planeAlive above -- only the order in which a dot product's three terms are added differs per lane, which the margins (kd doubled, eB: see planeAlive) cover
+// whatever the order; lane 4 r's verdict is the record's.  Returns bit 4 k set when slot k may contribute.
+// pu = the wave's six axis records (pruneUni); blk = the node's PruneBlock (wave-uniform).
+template <bool BOXES>
+__device__ __forceinline__ uint32_t pruneEval8(const RTX_AS1 char* blk, const float* pu, float tmaxB)
+{
+	static_assert(kWideSlots == 8, "pruneEval8: lanes = 16 records x 4");
+	const uint32_t lane = laneNow();      // (recomputed here: the addresses derived from it are otherwise hoisted out of the node loop and live -- spilled -- across the walk)
+	const uint32_t axis = lane & 3u;
+	const RTX_AS1 float* pf = (const RTX_AS1 float*)blk;      // (uniform base + a 32-bit lane offset: one scalar-base load, no 64-bit address arithmetic per lane)
+	const uint32_t word = 2u * lane - axis;                   // record lane >> 2 (eight words each), word lane & 3
+	const float f0 = pf[word], f1 = pf[word + 4u];            // box: c_a, h_a (lane 3: P, Pgen); plane: qc_a, qr_a (lane 3: wlo, whi)
+	uint32_t ui = (lane >> 5) * 3u + axis;
+	ui = ui < 5u ? ui : 5u;                      // (the fourth lane of a plane quad reads a record that exists; what it computes is never used)
+	const f4v ua = *(const f4v*)(pu + ui * 8u), ub = *(const f4v*)(pu + ui * 8u + 4u);
+	// ---- per axis, both tests (each meaningful on its own half of the wave)
+	// box (pruneAlive): centre mirrored, the largest |orig - vertex| along this axis
+	const float c = __uint_as_float(__float_as_uint(f0) ^ __float_as_uint(ub.x));
+	const float ai = fmaxf(c - ua.z, ua.w - c) + f1;
+	// plane (planeAlive): this axis' terms of  max dir . q,  orig . q -+ its radius
+	const float ax = fabsf(f0) + f1;
+	const float dq = __builtin_fmaf(ua.y, ax, __builtin_fmaf(fabsf(ua.x), f1, ua.x * f0));
+	const float oq = ua.z * f0;
+	const float orr = __builtin_fmaf(ua.w, ax, fabsf(ua.z) * f1);
+	const float pm = oq - orr, pp = oq + orr;
+	float ainf, dqHi, oqLo, oqHi, w0, w1, t0, t1, t2, t3;
+	// (a DPP source must not have been written by the two preceding VALU instructions: s_nop 1; inside the block the DPP sources are the block's inputs)
+	asm volatile("s_nop 1\n\t"
+	             "v_max_f32_dpp %6, %10, %10 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_add_f32_dpp %7, %11, %11 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_add_f32_dpp %8, %12, %12 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_add_f32_dpp %9, %13, %13 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_mov_b32_dpp %4, %14 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_mov_b32_dpp %5, %15 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_max_f32_dpp %0, %10, %6 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_add_f32_dpp %1, %11, %7 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_add_f32_dpp %2, %12, %8 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_add_f32_dpp %3, %13, %9 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf"
+	             : "=&v"(ainf), "=&v"(dqHi), "=&v"(oqLo), "=&v"(oqHi), "=&v"(w0), "=&v"(w1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+	             : "v"(ai), "v"(dq), "v"(pm), "v"(pp), "v"(f0), "v"(f1));
+	// ---- plane: (a) every ray sees the back, (b) starts beyond, (c) ends before every plane of the slot (planeAlive)
+	const float detHi = dqHi + ub.x;                                    // + 2 K dmax
+	const float ntHi = (w1 - oqLo) + ub.y, ntLo = (w0 - oqHi) - ub.y;   // whi - min orig . q + eB,  wlo - max orig . q - eB
+	// (a ballot per compare, joined on the scalar side: straight-line code, and a ballot of anything but a compare goes through a VGPR)
+	const uint64_t deadPlane = ballot(detHi < 0.0f) | ballot(ntHi < 0.0f) | (ballot(detHi > 0.0f) & ballot(ntLo >= tmaxB * (detHi * (1.0f + 0x1p-18f))));
+	uint32_t deadBits = (uint32_t)(deadPlane >> 32);      // slot k: lane 32 + 4 k
+	if (BOXES) {
+		// ---- box: the slot's true box inflated by rho against the bundle's segment [0, tmaxB] (pruneAlive)
+		const float Pn = ainf <= kSrcAinfMax ? w0 : w1;
+		const float rho = __builtin_fmaf(ub.z * ainf, Pn, 0x1p-17f * (ainf + ub.w)) * (1.0f + 0x1p-20f) + 1e-30f;
+		const float hh = f1 + rho;
+		const float a = (c - hh) - ua.w, b = (c + hh) - ua.z;
+		const float e = fminf(fminf(a * ua.x, a * ua.y), ub.y), f = fmaxf(fmaxf(b * ua.x, b * ua.y), -ub.y);
+		float ent, ext;
+		asm volatile("s_nop 1\n\t"
+		             "v_max_f32_dpp %2, %4, %4 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n\t"
+		             "v_min_f32_dpp %3, %5, %5 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n\t"
+		             "s_nop 0\n\t"
+		             "v_max_f32_dpp %0, %4, %2 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n\t"
+		             "v_min_f32_dpp %1, %5, %3 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf"
+		             : "=&v"(ent), "=&v"(ext), "=&v"(t0), "=&v"(t1) : "v"(e), "v"(f));
+		const uint64_t deadBox = ballot(ent > ext) | ballot(ext < 0.0f) | ballot(ent > tmaxB * (1.0f + 0x1p-18f));
+		deadBits |= (uint32_t)deadBox;                             // slot k: lane 4 k
+	}
+	return ~deadBits & 0x11111111u;
+}
+#endif
+
 template <bool STATS, bool CULL, bool REGULAR, bool WIDE = false, bool FEWRAYS = false, bool BOXES = true>
 __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool consider, bool shadow, const V3& o, const V3& d,
                                          float ix, float iy, float iz, bool sx, bool sy, bool sz, float tLimit,
@@ -779,12 +896,23 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				e.y = fmaxf(fmaxf(fabsf(B.ocx) + B.rox, fabsf(B.ocy) + B.roy), fabsf(B.ocz) + B.roz);
 				e.z = __uint_as_float((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u) | (okx ? 8u : 0u) | (oky ? 16u : 0u) | (okz ? 32u : 0u));
 				e.w = kFilterK * (e.y + F(mp[13])) * (1.0f + 0x1p-20f) + 1e-30f;      // K (|orig| + |vertex|): see planeAlive
-				*(f4v*)(pu + 0) = a; *(f4v*)(pu + 4) = b; *(f4v*)(pu + 8) = c; *(f4v*)(pu + 12) = e;
 				f4v f, g;
 				f.x = __uint_as_float(nx ? 0x80000000u : 0u); f.y = __uint_as_float(ny ? 0x80000000u : 0u); f.z = __uint_as_float(nz ? 0x80000000u : 0u);
 				f.w = okx ? __builtin_inff() : -__builtin_inff();
 				g.x = oky ? __builtin_inff() : -__builtin_inff(); g.y = okz ? __builtin_inff() : -__builtin_inff(); g.z = 0; g.w = 0;
+#if RTX_PRUNE_AXIS
+				f4v r;
+				r.x = a.x; r.y = a.y; r.z = b.z; r.w = b.w; *(f4v*)(pu + 0) = r;  r.x = f.x; r.y = f.w; r.z = e.x; r.w = e.y; *(f4v*)(pu + 4) = r;
+				r.x = a.z; r.y = a.w; r.z = c.x; r.w = c.y; *(f4v*)(pu + 8) = r;  r.x = f.y; r.y = g.x; r.z = e.x; r.w = e.y; *(f4v*)(pu + 12) = r;
+				r.x = b.x; r.y = b.y; r.z = c.z; r.w = c.w; *(f4v*)(pu + 16) = r; r.x = f.z; r.y = g.y; r.z = e.x; r.w = e.y; *(f4v*)(pu + 20) = r;
+				const float kd2 = 2.0f * B.kd;
+				r.x = B.dcx; r.y = B.rdx; r.z = B.ocx; r.w = B.rox; *(f4v*)(pu + 24) = r; r.x = kd2; r.y = e.w; r.z = 0; r.w = 0; *(f4v*)(pu + 28) = r;
+				r.x = B.dcy; r.y = B.rdy; r.z = B.ocy; r.w = B.roy; *(f4v*)(pu + 32) = r; r.x = kd2; r.y = e.w; r.z = 0; r.w = 0; *(f4v*)(pu + 36) = r;
+				r.x = B.dcz; r.y = B.rdz; r.z = B.ocz; r.w = B.roz; *(f4v*)(pu + 40) = r; r.x = kd2; r.y = e.w; r.z = 0; r.w = 0; *(f4v*)(pu + 44) = r;
+#else
+				*(f4v*)(pu + 0) = a; *(f4v*)(pu + 4) = b; *(f4v*)(pu + 8) = c; *(f4v*)(pu + 12) = e;
 				*(f4v*)(pu + 16) = f; *(f4v*)(pu + 20) = g;
+#endif
 			}
 			if (!B.sane) pruneRecs = nullptr;      // NaN / inf / huge coordinates somewhere in the bundle: nothing is pruned
 		}
@@ -849,6 +977,18 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				uint32_t aliveM = (1u << kWideSlots) - 1u;
 				// (four slots: not at the root, where they are as good as never pruned -- 7 of 259 in tools/research/pruned_walk_sim.py; eight: everywhere)
 				const bool evalPrune = pruneRecs != nullptr && (kPruneRoot || link != 1);
+#if RTX_PRUNE_AXIS
+				// (aliveM in the form pruneEval8 returns: slot k = bit 4 k)
+				aliveM = 0x11111111u;
+				if (evalPrune) {
+					aliveM = pruneEval8<BOXES>(pruneRecs + ((size_t)(uint32_t)(link - 1) << 9), pu, tmaxB);
+					if (RTX_DBG) { cnt.wS4++; cnt.wLeafSkips += (uint32_t)kWideSlots - (uint32_t)__popc(aliveM); }
+				}
+#define RTX_ALIVE(k) ((aliveM >> (4 * (k))) & 1u)
+#define RTX_ALIVE4(q) ((aliveM >> (16 * (q))) & 0x1111u)
+#else
+#define RTX_ALIVE(k) ((aliveM >> (k)) & 1u)
+#define RTX_ALIVE4(q) ((aliveM >> (4 * (q))) & 0xfu)
 				if (evalPrune) {
 					// lanes [0, kWideSlots): the slots' boxes (PruneRec), [kWideSlots, 2 kWideSlots): their planes (PlaneRec); both tests run on every lane's record
 					const RTX_AS1 f4v* pr = (const RTX_AS1 f4v*)(pruneRecs + (((uint32_t)(link - 1) * (2u * kWideSlots) + (lane & (2u * kWideSlots - 1u))) << 5));
@@ -859,21 +999,22 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 					aliveM = bal & (bal >> kWideSlots) & ((1u << kWideSlots) - 1u);
 					if (RTX_DBG) { cnt.wS4++; cnt.wLeafSkips += (uint32_t)kWideSlots - (uint32_t)__popc(aliveM); }
 				}
+#endif
 				// The node's slots four at a time (two s_load_dwordx16: the SGPR file holds no more), the last four first, slots 3..0 of every four in
 				// that order, so that slot 0 ends up on top of the stack; four slots none of which is alive are not fetched.
 #define RTX_SLOT(rec, base, k)                                                                                                     \
-				if ((int32_t)rec[base + 6] != 0 && ((aliveM >> (k)) & 1u)) {                                                         \
+				if ((int32_t)rec[base + 6] != 0 && RTX_ALIVE(k)) {                                                         \
 					const bool fail = boxFailsRegular(F(rec[base]), F(rec[base + 1]), F(rec[base + 2]), F(rec[base + 3]), F(rec[base + 4]), F(rec[base + 5]), o, ix, iy, iz); \
 					const uint64_t mk_ = ballot(!fail) & inM;                                                                       \
 					if (RTX_DBG) cnt.wS3++;                                                                                         \
 					if (mk_ != 0) RTX_PUSH(rec[base + 6], rec[base + 7], mk_)                                                       \
 				}
-				if (kWideSlots > 4 && (aliveM >> 4) != 0) {
+				if (kWideSlots > 4 && RTX_ALIVE4(1) != 0) {
 					// the upper slots first, four at a time from the top (they are pushed first): the registers of slots 3..0 are given up for them and loaded
 					// again afterwards (a hit in the scalar cache; touching the lines of the upper slots when the node is popped made no difference: profiles/r04_wide8.txt)
 #pragma unroll
 					for (int q4 = kWideSlots / 4 - 1; q4 >= 1; --q4) {
-						if (((aliveM >> (4 * q4)) & 0xfu) == 0) continue;
+						if (RTX_ALIVE4(q4) == 0) continue;
 						const u32x16 wc = sload16((const char*)w + 128 * q4), wd = sload16((const char*)w + 128 * q4 + 64);
 						RTX_SLOT(wd, 8, 4 * q4 + 3) RTX_SLOT(wd, 0, 4 * q4 + 2) RTX_SLOT(wc, 8, 4 * q4 + 1) RTX_SLOT(wc, 0, 4 * q4)
 					}
@@ -881,10 +1022,10 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 					asm volatile("" : "+s"(w0));      // (a fresh load, not the value from before kept in 32 more SGPRs)
 					wa = sload16(w0); wb = sload16(w0 + 64);
 				}
-				if ((aliveM & 0xfu) != 0) {
+				if (RTX_ALIVE4(0) != 0) {
 					RTX_SLOT(wb, 8, 3) RTX_SLOT(wb, 0, 2) RTX_SLOT(wa, 8, 1)
 					// slot 0 would be popped next: a leaf there is noted right away (no trip through the stack) while the batch has room
-					if ((int32_t)wa[6] != 0 && (aliveM & 1u)) {
+					if ((int32_t)wa[6] != 0 && RTX_ALIVE(0)) {
 						const bool fail = boxFailsRegular(F(wa[0]), F(wa[1]), F(wa[2]), F(wa[3]), F(wa[4]), F(wa[5]), o, ix, iy, iz);
 						const uint64_t mk_ = ballot(!fail) & inM;
 						if (RTX_DBG) cnt.wS3++;
@@ -896,6 +1037,8 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				}
 #undef RTX_SLOT
 #undef RTX_PUSH
+#undef RTX_ALIVE
+#undef RTX_ALIVE4
 			}
 		}
 		else {
@@ -1136,8 +1279,10 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 			// filter to reject much (rays of a silhouette tile that hit different objects, a grazing strip of shadow-ray
 			// origins, coarse frames): then the lanes on one side of the middle of the widest axis go first, the others
 			// later, halving until the bundle is narrow.  Which lanes walk together changes the amount of work only.
+#if !RTX_REC2_RELOAD
 			const float fat = F(rec2[8]), mrad = F(rec2[12]);
 			const float mcx = F(rec2[9]), mcy = F(rec2[10]), mcz = F(rec2[11]);
+#endif
 			const uint32_t mflags = rec2[13];
 			// Rays that fail the root box (objects.cpp:590) take no further part: the bundles are formed by the others.
 			bool pending = consider;
@@ -1160,9 +1305,19 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 				if (STATS) cnt.box += __popcll(ballot(consider && fail));       // (their root-box test is still a test of the reference)
 				pending = consider && !fail;
 			}
+			// (src == 1: the ray starts at the camera, o == view.camPos bit for bit -- castRayWave)
+			const bool oneOrigin = RTX_SAME_ORIGIN && !STATS && ballot(pending && src != 1u) == 0;
 			while (ballot(pending) != 0) {
 				bool cl = pending;
-				Bundle B = makeBundle(cl, o, d);
+#if RTX_REC2_RELOAD
+				// what the split rule needs of the object's second line, fetched again per bundle (a hit in the scalar cache, requested ahead of the reductions below)
+				// instead of being kept in -- i.e. spilled from -- sixteen SGPRs across the walk of the previous bundle
+				const char* ob2 = (const char*)ob + 96;
+				asm volatile("" : "+s"(ob2));
+				const u32x8 geo = sload8(ob2);      // fatRadius, centre[3], radius, meshFlags, pad[2]
+				const float fat = F(geo[0]), mcx = F(geo[1]), mcy = F(geo[2]), mcz = F(geo[3]), mrad = F(geo[4]);
+#endif
+				Bundle B = makeBundle(cl, o, d, oneOrigin);
 				for (int split = 0; split < RTX_MAX_SPLITS; ++split) {
 					// width of the bundle where it can meet the mesh: origin box, and direction box times the distance to the far side
 					const float dist = fmaxf(fmaxf(fabsf(B.ocx - mcx), fabsf(B.ocy - mcy)), fabsf(B.ocz - mcz)) + mrad;
@@ -1173,7 +1328,7 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 					else lo = B.rdx >= B.rdy && B.rdx >= B.rdz ? d.x < B.dcx : (B.rdy >= B.rdz ? d.y < B.dcy : d.z < B.dcz);
 					if (ballot(cl && lo) == 0 || ballot(cl && !lo) == 0) break;
 					cl = cl && lo;
-					B = makeBundle(cl, o, d);
+					B = makeBundle(cl, o, d, oneOrigin);
 				}
 				float bt, bu, bv; uint32_t btri;
 				// The walk may use a source copy of the prune records when ALL its rays pass through that source and have a direction

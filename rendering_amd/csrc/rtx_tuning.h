@@ -46,3 +46,15 @@
 #ifndef RTX_BUNDLE_PAIRS
 #define RTX_BUNDLE_PAIRS 1      // makeBundle: 1 = waveMaxMin (two interleaved DPP chains per coordinate).  Rounds 2-4 shipped 0 without meaning to: the switch was
 #endif                          // tested (line 477) before it was defined (line 671) -- found when the switches were retired in round 5; A/B in profiles/r05_ab_*.txt
+#ifndef RTX_FAST_INVLEN
+#define RTX_FAST_INVLEN 1       // Vec3::normalize's (float)(1 / sqrt((double)len2)) through the exact fp32 fast path (rtx_kernels.hip, invLenD); 0 = always the fp64 expression
+#endif
+#ifndef RTX_SAME_ORIGIN
+#define RTX_SAME_ORIGIN 1       // makeBundle: bundles whose rays all start at the camera take their origin box as that point (no reductions over the origins)
+#endif
+#ifndef RTX_REC2_RELOAD
+#define RTX_REC2_RELOAD 1       // traceWave: the mesh's bundle-split constants are fetched again per bundle instead of living in SGPRs across the walk
+#endif
+#ifndef RTX_PRUNE_AXIS
+#define RTX_PRUNE_AXIS 1        // node visit: the prune / plane records of a wide node are evaluated with lanes = (record, axis) -- pruneEval8 -- instead of lanes = records (16 of 64 lanes)
+#endif

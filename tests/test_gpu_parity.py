@@ -92,6 +92,26 @@ def test_device_math_matches_host(ra, oracle):
         assert np.array_equal(bits(ra.math_probe(4, xs, ys)), bits(xs / ys))
 
 
+def test_normalize_factor_every_mantissa(ra):
+    """Vec3::normalize's factor (float)(1.0 / sqrt((double)len2)) (geometry.h:104-112) on the device -- the exact fp32 fast path of invLenD with its fp64
+    fallback -- against the expression itself for EVERY float mantissa, both exponent parities, at exponents inside, at the ends of and outside the fast
+    path's range, plus zeros, denormals, inf and NaN (tools/research/rsqrt_exhaustive.c is the same enumeration on the CPU for every starting value v_rsq_f32
+    could return)."""
+    m = np.arange(1 << 23, dtype=np.uint32)
+    for e in (127, 128, 126, 127 - 60, 127 - 61, 128 + 59, 127 + 61, 1, 254, 127 + 20, 127 - 33):
+        x = (np.uint32(e << 23) | m).view(np.float32)
+        want = (1.0 / np.sqrt(x.astype(np.float64))).astype(np.float32)
+        got = ra.math_probe(3, x)
+        bad = np.nonzero(bits(got) != bits(want))[0]
+        assert bad.size == 0, "exponent %d: %d of 2^23 differ, first x = %r: %r != %r" % (e, bad.size, x[bad[0]], got[bad[0]], want[bad[0]])
+    sp = np.array([0.0, 1e-45, 1e-39, 1.17549435e-38, 3.4028235e38, np.inf, np.nan, 1.0, 4.0, 0.25], np.float32)
+    with np.errstate(all="ignore"):
+        want = (1.0 / np.sqrt(sp.astype(np.float64))).astype(np.float32)
+    got = ra.math_probe(3, sp)
+    ok = (bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))
+    assert ok.all(), (sp[~ok], got[~ok], want[~ok])
+
+
 def test_counters_match_reference_semantics(ra, oracle):
     """64-bit rays / box tests / triangle tests under reference traversal semantics (stats.h)."""
     path = "scenes/cfg2_smooth_4k.scene"

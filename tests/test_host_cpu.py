@@ -225,7 +225,7 @@ def test_prune_records_enclose_what_they_stand_for(ra, scene, obj):
         assert (c - h <= span[0]).all() and (c + h >= span[1]).all(), "box record of slot %d of wide node %d" % (k, w)
         assert P >= span[2], "P of slot %d of wide node %d" % (k, w)
         qc, wlo, qr, whi = plane[w, k, 0:3].astype(np.float64), float(plane[w, k, 3]), plane[w, k, 4:7].astype(np.float64), float(plane[w, k, 7])
-        if qr[0] >= 0 and span[3] is not None:
+        if np.isfinite(wlo) and span[3] is not None:      # (a record without a plane bound is q = 0 +- 0, offsets [-inf, +inf]: never rejected)
             assert (qc - qr <= span[3]).all() and (qc + qr >= span[4]).all() and wlo <= span[5] and whi >= span[6], "plane record of slot %d of wide node %d" % (k, w)
             assert (np.abs(qc) + qr <= 1.0 + 1e-5).all()      # |q|_inf <= 1: what planeAlive's error terms assume
         return span
