@@ -35,6 +35,9 @@ sys.path.insert(0, %r)
 from tools import ref_harness as R
 import numpy as np
 s = R.RefScene(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), workers=int(sys.argv[4]))
+import json
+for k, v in json.loads(sys.argv[7]).items():      # options:: flags of the workload (process-global in the reference: set after the load)
+    R.lib().ref_set_flag(k.encode(), int(v))
 t0 = time.perf_counter(); fb = s.pass1(); dt = time.perf_counter() - t0
 print("REF_PASS1_SECONDS %%.6f" %% dt)
 # (untimed) the framebuffers themselves, for the whole-frame comparison with what the GPU renders in the timed region
@@ -46,7 +49,7 @@ if int(sys.argv[6]):
 """
 
 
-def reference_baseline(scene_path, width, height, gpu_scene, cores, ssaa=True):
+def reference_baseline(scene_path, width, height, gpu_scene, cores, ssaa=True, flags=None):
     """The REAL reference (oracle/_ref, built from /root/reference by oracle/Makefile where that tree exists; the .so
     travels with the repo): Scene::launchWorkers of the whole frame with nWorkers = host cores, in a child process
     (the reference prints progress to stdout and keeps process-global option flags).  None if it is not available."""
@@ -55,7 +58,7 @@ def reference_baseline(scene_path, width, height, gpu_scene, cores, ssaa=True):
         return None
     try:
         dump = os.path.join(tempfile.gettempdir(), "bench_ref_%d" % os.getpid())
-        out = subprocess.run([sys.executable, "-c", REF_CHILD % ROOT, scene_path, str(width), str(height), str(cores), dump, "1" if ssaa else "0"],
+        out = subprocess.run([sys.executable, "-c", REF_CHILD % ROOT, scene_path, str(width), str(height), str(cores), dump, "1" if ssaa else "0", json.dumps(flags or {})],
                              cwd=ROOT, capture_output=True, text=True, timeout=300)
         sec = [float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith("REF_PASS1_SECONDS")]
         if out.returncode != 0 or not sec:
@@ -105,23 +108,25 @@ def reference_baseline(scene_path, width, height, gpu_scene, cores, ssaa=True):
     return res
 
 
-def cpu_baseline(scene_path, width, height, gpu_scene, target_s=15.0):
+def cpu_baseline(scene_path, width, height, gpu_scene, target_s=15.0, flags=None):
     """Oracle (CPU restatement: same exhaustive BVH walk, thread per 128x128 tile, all host cores) on a bounded
     sample of the SAME frame: 32-row bands spread evenly over the image, as many as fit ~target_s seconds
     (the whole frame when the host is fast enough).  The rays of the sampled rows are counted by the
     instrumented GPU kernel (tests/test_gpu_parity.py proves those counts identical to the oracle's)."""
     cores = os.cpu_count() or 1
-    ref = reference_baseline(scene_path, width, height, gpu_scene, cores) if os.environ.get("BENCH_CPU_BASELINE", "reference") == "reference" else None
+    ref = reference_baseline(scene_path, width, height, gpu_scene, cores, flags=flags) if os.environ.get("BENCH_CPU_BASELINE", "reference") == "reference" else None
     if ref is not None:
         # the oracle port on a shorter sample beside it, so that the line can be compared where oracle/_ref is absent
-        ref["port"] = cpu_baseline_port(scene_path, width, height, gpu_scene, target_s=8.0)
+        ref["port"] = cpu_baseline_port(scene_path, width, height, gpu_scene, target_s=8.0, flags=flags)
         return ref
-    return cpu_baseline_port(scene_path, width, height, gpu_scene, target_s)
+    return cpu_baseline_port(scene_path, width, height, gpu_scene, target_s, flags=flags)
 
 
-def cpu_baseline_port(scene_path, width, height, gpu_scene, target_s=15.0):
+def cpu_baseline_port(scene_path, width, height, gpu_scene, target_s=15.0, flags=None):
     from oracle import oracle as O
     o = O.OracleScene(scene_path, width, height)
+    for k, v in (flags or {}).items():
+        O.lib().orc_set_flag(o.h, k.encode(), int(v))
     band = 32
     all_bands = [(y, min(y + band, height)) for y in range(0, height, band)]
     # probe: every 32nd band
@@ -243,7 +248,11 @@ CONFIGS = {
     "cfg4": ("scenes/cfg4_textured_1024.scene", 4096, 4096),
     "cfg5": ("scenes/cfg2_smooth_250k.scene", 8192, 8192),
     "area": ("scenes/area_light.scene", 1920, 1080),      # samples^2 shadow rays per hit (not a BASELINE configuration; VERDICT r4 "missing" item 5)
+    # options::useBackfaceCulling = 0 (options.h:27, objects.cpp:75-79): the on / off comparison is one of the four numbers the reference publishes (README.md:56-60)
+    "headline_nocull": ("scenes/cfg2_smooth_250k.scene", 4096, 4096),
+    "cfg2_nocull": ("scenes/cfg2_smooth_250k.scene", 1920, 1080),
 }
+CONFIG_FLAGS = {"headline_nocull": {"useBackfaceCulling": 0}, "cfg2_nocull": {"useBackfaceCulling": 0}}
 
 
 def main():
@@ -305,8 +314,15 @@ def main():
     # frame per process (main.cpp:15) and the load dwarfs a 4-ms frame
     torch.cuda.synchronize()
     t_load = time.perf_counter()
-    scene = RA.Scene(args.scene, W, H, device=local)
-    scene.gpu()
+    flags = CONFIG_FLAGS.get(args.config, {})
+
+    def load_scene():
+        sc = RA.Scene(args.scene, W, H, device=local)
+        for k, v in flags.items():
+            sc.set_flag(k, v)
+        sc.gpu()
+        return sc
+    scene = load_scene()
     torch.cuda.synchronize()
     scene_create_ms = (time.perf_counter() - t_load) * 1e3
     bvh_ms = []
@@ -509,16 +525,14 @@ def main():
     # (no measured tile costs: the estimate of rtx_scene_create orders and splits it; tools/cold_probe.py).
     cold_ms = cold_busy_ms = set_view_ms = new_view_host_ms = new_view_frame_ms = new_view_device_ms = None
     if world == 1:
-        scene2 = RA.Scene(args.scene, W, H, device=local)
-        scene2.gpu()
+        scene2 = load_scene()
         torch.cuda.synchronize()
         tc = time.perf_counter()
         parallel.shard_frame(scene2, fb, mask, 1, 0, ssaa=ssaa)
         torch.cuda.synchronize()
         cold_ms = (time.perf_counter() - tc) * 1e3
         scene2.close()
-        scene3 = RA.Scene(args.scene, W, H, device=local)
-        scene3.gpu()
+        scene3 = load_scene()
         torch.cuda.synchronize()
         fb3 = torch.zeros_like(fb); mask3 = torch.zeros_like(mask)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -612,7 +626,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s @%dx%d, pass 1%s" % (os.path.basename(args.scene), W, H, " + Sobel-adaptive SSAA" if ssaa else ""),
-                   "name": args.config,
+                   "name": args.config, "flags": flags or None,
                    "rays_per_frame": rays_per_frame, "moot_shadow_rays": int(tot[3]),
                    "walked_rays_per_frame": walked, "counted_mrays_s": round(rays_per_frame * args.steps / dt / 1e6, 3),
                    "parallelism": "rows in %d-row bands over %d GPU(s)%s" % (parallel.band_height(H, world), world, ", BGR8 bands collected on rank 0" if world > 1 else ""),
@@ -643,7 +657,7 @@ def main():
     if verified is not None:
         out["config"]["gathered_image_equals_single_gpu_image"] = verified
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.scene, W, H, scene)
+        out["cpu_baseline"] = cpu_baseline(args.scene, W, H, scene, flags=flags)
         par = (out["cpu_baseline"] or {}).get("parity")
         if par:      # the reference's own framebuffers of this very frame against the product path's (reference_baseline)
             for k in ("pass1_equals_reference_full_frame", "frame_equals_reference_full_frame"):

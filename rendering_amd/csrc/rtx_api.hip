@@ -1289,6 +1289,11 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	if ((rc = stamp(s, 0, st))) return rc;
 	if (s->stats) hipLaunchKernelGGL(rtxPass1Kernel<true>, dim3(blocks), dim3(256), 0, st, p);
 	else if (s->analytic) hipLaunchKernelGGL((rtxPass1Kernel<false, false>), dim3(blocks), dim3(256), 0, st, p);
+	// (mesh kernels exist per culling mode -- a constant of the view: neither form carries the other's walks)
+	else if (!(p.view.flags & RTX_FLAG_BACKFACE_CULL)) {
+		if (!s->boxPrune) hipLaunchKernelGGL((rtxPass1Kernel<false, true, false, 0>), dim3(blocks), dim3(256), 0, st, p);
+		else hipLaunchKernelGGL((rtxPass1Kernel<false, true, true, 0>), dim3(blocks), dim3(256), 0, st, p);
+	}
 	else if (!s->boxPrune) hipLaunchKernelGGL((rtxPass1Kernel<false, true, false>), dim3(blocks), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxPass1Kernel<false>, dim3(blocks), dim3(256), 0, st, p);
 	HIPCHK(hipGetLastError());
@@ -1389,6 +1394,10 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	if (blocks > wavesNeeded) blocks = wavesNeeded ? wavesNeeded : 1;
 	if ((rc = stamp(s, 4, st))) return rc;
 	if (s->analytic) hipLaunchKernelGGL(rtxFrameKernel<false>, dim3(blocks), dim3(256), 0, st, p);
+	else if (!(p.view.flags & RTX_FLAG_BACKFACE_CULL)) {
+		if (!s->boxPrune) hipLaunchKernelGGL((rtxFrameKernel<true, false, 0>), dim3(blocks), dim3(256), 0, st, p);
+		else hipLaunchKernelGGL((rtxFrameKernel<true, true, 0>), dim3(blocks), dim3(256), 0, st, p);
+	}
 	else if (!s->boxPrune) hipLaunchKernelGGL((rtxFrameKernel<true, false>), dim3(blocks), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxFrameKernel<true>, dim3(blocks), dim3(256), 0, st, p);
 	HIPCHK(hipGetLastError());
@@ -1666,6 +1675,10 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	HIPCHK(hipGetLastError());
 	if (s->stats) hipLaunchKernelGGL(rtxSsaaKernel<true>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	else if (s->analytic) hipLaunchKernelGGL((rtxSsaaKernel<false, false>), dim3(s->blocksSsaa), dim3(256), 0, st, p);
+	else if (!(p.view.flags & RTX_FLAG_BACKFACE_CULL)) {
+		if (!s->boxPrune) hipLaunchKernelGGL((rtxSsaaKernel<false, true, false, 0>), dim3(s->blocksSsaa), dim3(256), 0, st, p);
+		else hipLaunchKernelGGL((rtxSsaaKernel<false, true, true, 0>), dim3(s->blocksSsaa), dim3(256), 0, st, p);
+	}
 	else if (!s->boxPrune) hipLaunchKernelGGL((rtxSsaaKernel<false, true, false>), dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	else hipLaunchKernelGGL(rtxSsaaKernel<false>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	HIPCHK(hipGetLastError());

@@ -767,7 +767,15 @@ __device__ __forceinline__ bool planeAlive(const f4v& r0, const f4v& r1, const B
 // planeAlive above -- only the order in which a dot product's three terms are added differs per lane, which the margins (kd doubled, eB: see planeAlive) cover
 // whatever the order; lane 4 r's verdict is the record's.  Returns bit 4 k set when slot k may contribute.
 // pu = the wave's six axis records (pruneUni); blk = the node's PruneBlock (wave-uniform).
-template <bool BOXES>
+// CULL = false (options::useBackfaceCulling off, objects.cpp:75-79: a pair is rejected iff |det_c| < 1e-8): the plane test cannot drop back faces, and
+// which sign of Nt means "behind the origin" depends on the sign of det.  With min and max of dir . q over the bundle and the slot:
+//     min dir . q - 2 kd > 0  (every pair faces the rays)    -> (b), (c) as with culling;
+//     max dir . q + 2 kd < 0  (every pair shows its back: t = Nt / det = (-Nt) / |det|)  -> dead iff  wlo - max orig . q - eB > 0   (Nt > 0: t_c < 0)
+//                                                               or  -(whi - min orig . q + eB) >= tmaxB (-(min dir . q - 2 kd)) (1 + 2^-18)   (t_c >= every limit);
+//     sign uncertain -> alive.
+// The box test rests on |det_c| >= 1e-8 and magnitudes only (pruneAlive; the source certificates likewise: rtx_source.hip works with |a . m|, and its
+// error terms are symmetric in e1, e2 -- a back face is the front face (e2, e1) with u and v exchanged), so it is the same with and without culling.
+template <bool BOXES, bool CULL = true>
 __device__ __forceinline__ uint32_t pruneEval8(const RTX_AS1 char* blk, const float* pu, float tmaxB)
 {
 	static_assert(kWideSlots == 8, "pruneEval8: lanes = 16 records x 4");
@@ -808,7 +816,22 @@ __device__ __forceinline__ uint32_t pruneEval8(const RTX_AS1 char* blk, const fl
 	const float detHi = dqHi + ub.x;                                    // + 2 K dmax
 	const float ntHi = (w1 - oqLo) + ub.y, ntLo = (w0 - oqHi) - ub.y;   // whi - min orig . q + eB,  wlo - max orig . q - eB
 	// (a ballot per compare, joined on the scalar side: straight-line code, and a ballot of anything but a compare goes through a VGPR)
-	const uint64_t deadPlane = ballot(detHi < 0.0f) | ballot(ntHi < 0.0f) | (ballot(detHi > 0.0f) & ballot(ntLo >= tmaxB * (detHi * (1.0f + 0x1p-18f))));
+	uint64_t deadPlane;
+	if (CULL) deadPlane = ballot(detHi < 0.0f) | ballot(ntHi < 0.0f) | (ballot(detHi > 0.0f) & ballot(ntLo >= tmaxB * (detHi * (1.0f + 0x1p-18f))));
+	else {
+		// min dir . q: the same three terms with the radii subtracted
+		const float dql = __builtin_fmaf(-ua.y, ax, __builtin_fmaf(-fabsf(ua.x), f1, ua.x * f0));
+		float dqLo;
+		asm volatile("s_nop 1\n\t"
+		             "v_add_f32_dpp %1, %2, %2 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n\t"
+		             "s_nop 1\n\t"
+		             "v_add_f32_dpp %0, %2, %1 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf"
+		             : "=&v"(dqLo), "=&v"(t0) : "v"(dql));
+		const float detLo = dqLo - ub.x;
+		const uint64_t front = ballot(detLo > 0.0f), back = ballot(detHi < 0.0f);
+		deadPlane = (front & (ballot(ntHi < 0.0f) | ballot(ntLo >= tmaxB * (detHi * (1.0f + 0x1p-18f))))) |
+		            (back & (ballot(ntLo > 0.0f) | ballot(-ntHi >= tmaxB * (-detLo * (1.0f + 0x1p-18f)))));
+	}
 	uint32_t deadBits = (uint32_t)(deadPlane >> 32);      // slot k: lane 32 + 4 k
 	if (BOXES) {
 		// ---- box: the slot's true box inflated by rho against the bundle's segment [0, tmaxB] (pruneAlive)
@@ -981,7 +1004,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				// (aliveM in the form pruneEval8 returns: slot k = bit 4 k)
 				aliveM = 0x11111111u;
 				if (evalPrune) {
-					aliveM = pruneEval8<BOXES>(pruneRecs + ((size_t)(uint32_t)(link - 1) << 9), pu, tmaxB);
+					aliveM = pruneEval8<BOXES, CULL>(pruneRecs + ((size_t)(uint32_t)(link - 1) << 9), pu, tmaxB);
 					if (RTX_DBG) { cnt.wS4++; cnt.wLeafSkips += (uint32_t)kWideSlots - (uint32_t)__popc(aliveM); }
 				}
 #define RTX_ALIVE(k) ((aliveM >> (4 * (k))) & 1u)
@@ -994,7 +1017,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 					const RTX_AS1 f4v* pr = (const RTX_AS1 f4v*)(pruneRecs + (((uint32_t)(link - 1) * (2u * kWideSlots) + (lane & (2u * kWideSlots - 1u))) << 5));
 					const f4v r0 = pr[0], r1 = pr[1];
 					const bool aliveBox = !BOXES || pruneAlive(r0, r1, pu, tmaxB);      // (BOXES: see the kernels' template parameter)
-					const bool alivePlane = planeAlive(r0, r1, B, pu[15], tmaxB);
+					const bool alivePlane = !CULL || planeAlive(r0, r1, B, pu[15], tmaxB);      // (planeAlive's rejections assume culling; pruneEval8 has the other form)
 					const uint32_t bal = (uint32_t)ballot((lane & (uint32_t)kWideSlots) ? alivePlane : aliveBox);
 					aliveM = bal & (bal >> kWideSlots) & ((1u << kWideSlots) - 1u);
 					if (RTX_DBG) { cnt.wS4++; cnt.wLeafSkips += (uint32_t)kWideSlots - (uint32_t)__popc(aliveM); }
@@ -1249,7 +1272,9 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 
 // MESH = false: the variant for scenes without triangle meshes (spheres and planes only).  Without the walk the castRay
 // state machine fits the register file, and a small frame lasts as long as its slowest wave's chain of dependent rays.
-template <bool STATS, bool MESH = true, bool FEWRAYS = false, bool BOXES = true>
+// CULLK: options::useBackfaceCulling as the kernel knows it -- 1 on, 0 off (the product kernels: a per-view constant, so every kernel exists in both forms and
+// neither carries the other's walks), -1 read from the view at run time (the instrumented and the probe kernels)
+template <bool STATS, bool MESH = true, bool FEWRAYS = false, bool BOXES = true, int CULLK = -1>
 __device__ __forceinline__ void traceWave(const Params& P, bool active, bool shadow, V3 o, V3 d, float tmax,
                                           Hit& h, Counts& cnt, uint32_t src = 0)
 {
@@ -1257,7 +1282,7 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 	// 2 + l point light l (o = P + N bias, d = -normalize(P - pos_l): castRayWave)
 	h.obj = -1; h.t = tmax; h.tri = 0; h.u = 0; h.v = 0;
 	if (STATS) cnt.rays += __popcll(ballot(active));
-	const bool cull = (uni(P.view.flags) & 1u) != 0;
+	const bool cull = CULLK < 0 ? (uni(P.view.flags) & 1u) != 0 : CULLK != 0;
 	// AccelerationStructure::intersectBox's per-ray part (objects.cpp:543-544), hoisted out of the walk
 	const float ix = 1 / d.x, iy = 1 / d.y, iz = 1 / d.z;
 	const bool sx = ix < 0, sy = iy < 0, sz = iz < 0;
@@ -1288,9 +1313,11 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 			bool pending = consider;
 			// the min / max form of the box test (meshWalk<.., REGULAR>) is exact when no NaN can arise: regular boxes, finite
 			// origins and finite 1 / dir for every ray of the wave
-			const bool regular = (mflags & 2u) != 0 &&
-			                     ballot(consider && !(fabsf(ix) < __builtin_inff() && fabsf(iy) < __builtin_inff() && fabsf(iz) < __builtin_inff() &&
-			                                          fabsf(o.x) < 0x1p100f && fabsf(o.y) < 0x1p100f && fabsf(o.z) < 0x1p100f)) == 0;
+			// -- per RAY: a ray with a zero direction component (1 / 0 = inf: the central column / row of an unrotated camera) or a huge origin is walked
+			// apart from the others, in the binary form; the rest of the wave keeps the wide walk (one such lane used to demote all 64)
+			const bool laneRegular = fabsf(ix) < __builtin_inff() && fabsf(iy) < __builtin_inff() && fabsf(iz) < __builtin_inff() &&
+			                         fabsf(o.x) < 0x1p100f && fabsf(o.y) < 0x1p100f && fabsf(o.z) < 0x1p100f;
+			const bool meshRegular = (mflags & 2u) != 0;
 			const bool wideOk = (mflags & 4u) != 0;
 			if ((mflags & 1u) != 0) {
 				const float xlo = (F(rec2[2]) - o.x) * ix, xhi = (F(rec2[3]) - o.x) * ix, ylo = (F(rec2[4]) - o.y) * iy, yhi = (F(rec2[5]) - o.y) * iy;
@@ -1309,6 +1336,12 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 			const bool oneOrigin = RTX_SAME_ORIGIN && !STATS && ballot(pending && src != 1u) == 0;
 			while (ballot(pending) != 0) {
 				bool cl = pending;
+				// the regular rays first, as one bundle (or more: the split below); what is left afterwards are the irregular ones
+				bool regular = false;
+				if (meshRegular) {
+					const uint64_t regM = ballot(pending && laneRegular);
+					if (regM != 0) { cl = pending && laneRegular; regular = true; }
+				}
 #if RTX_REC2_RELOAD
 				// what the split rule needs of the object's second line, fetched again per bundle (a hit in the scalar cache, requested ahead of the reductions below)
 				// instead of being kept in -- i.e. spilled from -- sixteen SGPRs across the walk of the previous bundle
@@ -1342,6 +1375,11 @@ __device__ __forceinline__ void traceWave(const Params& P, bool active, bool sha
 					}
 				}
 				if (!STATS && cull && regular && wideOk) meshWalk<STATS, true, true, true, FEWRAYS, BOXES>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt, srcSel);
+#if RTX_WIDE_NOCULL
+				// culling off (options.h:27, objects.cpp:75-79): the same wide walk; its filter mirrors by the sign of det (bundleRejects1), its plane records
+				// keep what may show either face (pruneEval8<.., false>)
+				else if (!STATS && regular && wideOk) meshWalk<STATS, false, true, true, FEWRAYS, BOXES>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt, srcSel);
+#endif
 				else if (cull && regular) meshWalk<STATS, true, true, false, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				else if (cull) meshWalk<STATS, true, false, false, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
 				else meshWalk<STATS, false, false, false, FEWRAYS>(rec3, B, cl, shadow, o, d, ix, iy, iz, sx, sy, sz, h.t, bt, bu, bv, btri, cnt);
@@ -1712,7 +1750,7 @@ __device__ __forceinline__ const Params& freshParams(const Params& P)
 }
 
 // CAM: the rays handed in start at the camera (o == view.camPos bit for bit: pass 1, SSAA, the frame kernel -- not the probe rays)
-template <bool STATS, bool MESH = true, bool FEWRAYS = false, bool BOXES = true, bool CAM = true>
+template <bool STATS, bool MESH = true, bool FEWRAYS = false, bool BOXES = true, bool CAM = true, int CULLK = -1>
 __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3 d, uint32_t gl, Counts& cnt)
 {
 	const Params& P = freshParams(P0);
@@ -1752,7 +1790,7 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 			parkedState[24 + kPk][t] = s.specCoef;
 			asm volatile("" ::: "memory");
 		}
-		traceWave<STATS, MESH, FEWRAYS, BOXES>(freshParams(P0), qactive, qshadow, qo, qd, qtmax, h, cnt, qsrc);
+		traceWave<STATS, MESH, FEWRAYS, BOXES, CULLK>(freshParams(P0), qactive, qshadow, qo, qd, qtmax, h, cnt, qsrc);
 		if (MESH) {
 			asm volatile("" ::: "memory");
 			const uint32_t t = threadIdx.x;
@@ -1831,7 +1869,7 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 // ------------------------------------------------------------------------------------------------
 // BOXES = false: the variant for scenes whose meshes all have triangles too large for the box test of the prune records to prune
 // anything (rtxd::Object::pruneBoxes; cfg4): the same kernel without that test (the plane test stays).
-template <bool STATS, bool MESH = true, bool BOXES = true>
+template <bool STATS, bool MESH = true, bool BOXES = true, int CULLK = (STATS || !MESH) ? -1 : 1>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rtxPass1Kernel(const Params P)
 {
 	fillPowTab();
@@ -1884,7 +1922,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 			else
 			if (sload1(P.tileCost + ty * P.tilesXFull + tx) > RTX_PRIO_TICKS) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 			const unsigned long long t0 = wall_clock64();
-			const V3 c = castRayWave<STATS, MESH, false, BOXES>(P, valid, o, d, gl, cnt);
+			const V3 c = castRayWave<STATS, MESH, false, BOXES, true, CULLK>(P, valid, o, d, gl, cnt);
 			const unsigned long long dt = wall_clock64() - t0;
 			RTX_TRACE_ONLY(dbgEnd = t0 + dt; dbgBusy += dt;)
 			if (lane == 0) {
@@ -1920,7 +1958,7 @@ __device__ __forceinline__ uint32_t nthSetBit(uint64_t m, uint32_t n)   // posit
 	return pos;
 }
 
-template <bool STATS, bool MESH = true, bool BOXES = true>
+template <bool STATS, bool MESH = true, bool BOXES = true, int CULLK = (STATS || !MESH) ? -1 : 1>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTIC) rtxSsaaKernel(const Params P)
 {
 	fillPowTab();
@@ -1948,7 +1986,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 		V3 o, d;
 		primaryRay(P, fx, fy, o, d);
 		const unsigned long long t0 = wall_clock64();
-		const V3 c = castRayWave<STATS, MESH, true, BOXES>(P, valid, o, d, gl, cnt);      // (work items of 16, 4 or 1 pixels: see the exact tests of meshWalk)
+		const V3 c = castRayWave<STATS, MESH, true, BOXES, true, CULLK>(P, valid, o, d, gl, cnt);      // (work items of 16, 4 or 1 pixels: see the exact tests of meshWalk)
 		if (!STATS) {
 			// what the item cost, as the time of a 16-pixel item (a 4-pixel item takes at least a quarter of it), kept per tile
 			// in the second half of tileCost: a profiling aid (rtx_tile_cost_read, tools/ssaa_items.py).  Ordering and sizing
@@ -2542,7 +2580,7 @@ enum : uint32_t {
 };
 #define RTX_FRAME_QUEUES 64u
 
-template <bool MESH, bool BOXES = true>
+template <bool MESH, bool BOXES = true, int CULLK = MESH ? 1 : -1>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYTIC) rtxFrameKernel(const Params P)
 {
 	fillPowTab();
@@ -2704,7 +2742,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 		primaryRay(P, fx, fy, o, d);
 		if (slow) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 		const unsigned long long t0 = wall_clock64();
-		const V3 c = castRayWave<false, MESH, true, BOXES>(P, valid, o, d, gl, cnt);
+		const V3 c = castRayWave<false, MESH, true, BOXES, true, CULLK>(P, valid, o, d, gl, cnt);
 		const unsigned long long dt = wall_clock64() - t0;
 		RTX_DBG_ONLY(
 		if (lane == 0 && wave < 8192 && dbgItems < 160) {
@@ -2866,3 +2904,10 @@ template __global__ void rtxFrameKernel<false>(const Params);
 template __global__ void rtxPass1Kernel<false, true, false>(const Params);
 template __global__ void rtxSsaaKernel<false, true, false>(const Params);
 template __global__ void rtxFrameKernel<true, false>(const Params);
+// the same kernels for options::useBackfaceCulling = 0
+template __global__ void rtxPass1Kernel<false, true, true, 0>(const Params);
+template __global__ void rtxPass1Kernel<false, true, false, 0>(const Params);
+template __global__ void rtxSsaaKernel<false, true, true, 0>(const Params);
+template __global__ void rtxSsaaKernel<false, true, false, 0>(const Params);
+template __global__ void rtxFrameKernel<true, true, 0>(const Params);
+template __global__ void rtxFrameKernel<true, false, 0>(const Params);

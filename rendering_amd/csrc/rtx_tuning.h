@@ -58,3 +58,6 @@
 #ifndef RTX_PRUNE_AXIS
 #define RTX_PRUNE_AXIS 1        // node visit: the prune / plane records of a wide node are evaluated with lanes = (record, axis) -- pruneEval8 -- instead of lanes = records (16 of 64 lanes)
 #endif
+#ifndef RTX_WIDE_NOCULL
+#define RTX_WIDE_NOCULL 1       // options::useBackfaceCulling = 0 takes the wide walk with prune records too (0: the stackless binary walk, as until round 5)
+#endif

@@ -112,6 +112,45 @@ def test_north_star_4096_ssaa_oracle_bands(ra, oracle, torch_cuda):
     assert n > 50000
 
 
+@pytest.mark.parametrize("size", [1024, 4096])
+def test_culling_off_250k_oracle_bands(ra, oracle, torch_cuda, size):
+    """options::useBackfaceCulling = 0 (options.h:27; objects.cpp:75-79) on the 250k-triangle scene: since round 6 the wide walk with prune records
+    (meshWalk<.., CULL = false, .., WIDE>; pruneEval8<.., false> keeps slots that may show either face) instead of the stackless binary walk -- pass 1, the
+    Sobel mask and the re-rendered pixels against the oracle with the same flag, on bands through the poles, the silhouette, the middle and the shadow."""
+    from rendering_amd import assets
+    assets.ensure(["bumpy_250k.obj"])
+    g = ra.Scene("scenes/cfg2_smooth_250k.scene", size, size)
+    g.set_flag("useBackfaceCulling", 0)
+    assert (g.view_flags() & 1) == 0
+    o = oracle.OracleScene("scenes/cfg2_smooth_250k.scene", size, size)
+    oracle.lib().orc_set_flag(o.h, b"useBackfaceCulling", 0)
+    k = size / 4096.0
+    bands = [(int(y0 * k), int(y0 * k) + 4) for y0 in (0, 792, 1100, 2046, 3100, 3296, 3600)] + [(size - 4, size)]
+    n = check_bands_against_oracle(torch_cuda, g, o, bands)
+    assert n > 2000
+
+
+def test_centre_column_and_row_rays_do_not_change_the_picture(ra, oracle, torch_cuda):
+    """An unrotated camera's central pixel column / row have a direction component of exactly 0 (1 / dir = inf): those rays take the binary walk apart from
+    the others of their wave, which keep the wide walk (traceWave, laneRegular).  Frames whose width / height put such rays in the middle of the mesh --
+    even and odd sizes, so that the column exists or not -- against the oracle, whole."""
+    torch = torch_cuda
+    for w, h in ((322, 242), (323, 243), (642, 402)):
+        g = ra.Scene("scenes/cfg2_smooth_25k.scene", w, h)
+        o = oracle.OracleScene("scenes/cfg2_smooth_25k.scene", w, h)
+        ref = o.ssaa(o.pass1())
+        fb = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda"); mask = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+        for mode in (0, 1):
+            fb.zero_(); mask.zero_()
+            g.set_frame_mode(mode)
+            g.render_frame(fb, mask)
+            assert g.frame_status() == 0
+            d = (bits(fb.cpu().numpy()) != bits(ref)).any(-1)
+            d[0, :] = False; d[:, 0] = False
+            assert not d.any(), "%dx%d mode %d: %d pixels differ" % (w, h, mode, int(d.sum()))
+        g.close()
+
+
 def test_north_star_4096_whole_frame_equals_the_oracle(ra, oracle, torch_cuda):
     """The headline frame WHOLE -- every pixel of pass 1, every bit of the Sobel mask, every pixel after the 4-ray pass -- against the oracle (the
     suite compared bands; the whole-frame equality lived in bench.py, against the reference itself, where it stays).  Rendered the way bench.py renders it:

@@ -30,6 +30,15 @@ def test_source_records_bound_accepted_hits():
             assert ratio_cert < 0.25
             certified += ncert
     assert certified > 5000, "the sample no longer exercises the certificate"
+    # culling off (objects.cpp:75-79: |det_c| < 1e-8 rejects; back faces are accepted): the same bound, the source on either side of the plane --
+    # what lets the culling-off walk use the source copies of the prune records as well (pruneEval8<.., false>)
+    back = 0
+    for cam in (True, False):
+        for mode in ("graze", "sliver", "generic"):
+            ratio, ncert, off_cert, ratio_cert = run(40000, mode, cam, rng, quiet=True, cull=False)
+            assert ratio < 0.25 and ratio_cert < 0.25, "culling off, %s %s: an accepted hit at %.3f of the bound" % ("camera" if cam else "light", mode, max(ratio, ratio_cert))
+            back += ncert
+    assert back > 5000
 
 
 def test_source_p_never_exceeds_pgen_and_needs_height():

@@ -14,11 +14,11 @@ f32 = np.float32
 u = 2.0 ** -24
 
 
-def reference_mt(o, d, v0, e1, e2):
-    """Triangle::rayTriangleIntersect with culling (objects.cpp:59-95), one ray per triangle, fp32."""
+def reference_mt(o, d, v0, e1, e2, cull=True):
+    """Triangle::rayTriangleIntersect (objects.cpp:59-95), one ray per triangle, fp32; cull = options::useBackfaceCulling (objects.cpp:75-79)."""
     px = d[:, 1] * e2[:, 2] - d[:, 2] * e2[:, 1]; py = d[:, 2] * e2[:, 0] - d[:, 0] * e2[:, 2]; pz = d[:, 0] * e2[:, 1] - d[:, 1] * e2[:, 0]
     det = e1[:, 0] * px + e1[:, 1] * py + e1[:, 2] * pz
-    ok = ~(det.astype(np.float64) < 1e-8)
+    ok = ~(det.astype(np.float64) < 1e-8) if cull else ~(np.abs(det.astype(np.float64)) < 1e-8)
     with np.errstate(all="ignore"):
         inv = f32(1) / det
         tx = o[:, 0] - v0[:, 0]; ty = o[:, 1] - v0[:, 1]; tz = o[:, 2] - v0[:, 2]
@@ -32,7 +32,7 @@ def reference_mt(o, d, v0, e1, e2):
     return ok, tt, det
 
 
-def run(N, mode, cam, rng, quiet=False):
+def run(N, mode, cam, rng, quiet=False, cull=True):
     # triangles
     sc = 10.0 ** rng.uniform(-3, -1, (N, 1))
     v0 = rng.uniform(-1, 1, (N, 3)) * 10.0 ** rng.uniform(-1, 0.5, (N, 1))
@@ -52,6 +52,8 @@ def run(N, mode, cam, rng, quiet=False):
     cen = V0 + (E1 + E2) / 3
     inpl = np.sqrt(np.maximum(D * D - H * H, 0))
     side = -1.0 if cam else 1.0
+    if not cull:      # culling off: the source on either side of the plane (back faces are accepted too)
+        side = side * rng.choice([-1.0, 1.0], (N, 1))
     S = cen + tang * inpl + side * nn * H
     sigma = 0.0 if cam else float(10.0 ** rng.uniform(-5, -3.5))
     # target: in or around the triangle, out to a few edge lengths
@@ -80,7 +82,7 @@ def run(N, mode, cam, rng, quiet=False):
         perp = w - d6 * ((w * d6).sum(1) / (d6 * d6).sum(1))[:, None]
         keep = np.linalg.norm(perp, axis=1) <= sigma
         o, d, v0, e1, e2, S, V0, E1, E2, s1, s2, mm = [x[keep] for x in (o, d, v0, e1, e2, S, V0, E1, E2, s1, s2, mm)]
-    ok, tt, det = reference_mt(o, d, v0, e1, e2)
+    ok, tt, det = reference_mt(o, d, v0, e1, e2, cull)
     idx = np.nonzero(ok)[0]
     if len(idx) == 0:
         return 0.0, 0, 0.0, 0.0
