@@ -249,6 +249,11 @@ CONFIGS = {
     "cfg5": ("scenes/cfg2_smooth_250k.scene", 8192, 8192),
     "area": ("scenes/area_light.scene", 1920, 1080),      # samples^2 shadow rays per hit (not a BASELINE configuration; VERDICT r4 "missing" item 5)
     # options::useBackfaceCulling = 0 (options.h:27, objects.cpp:75-79): the on / off comparison is one of the four numbers the reference publishes (README.md:56-60)
+    # evidence beyond the two synthetic meshes the knobs were fitted on, all in the north-star scene at 4096^2 with the shipped knobs:
+    # a second 250k-triangle mesh without pole slivers, and the reference's own models (as the triangles its loader produced: rendering_amd/assets.py)
+    "knot": ("scenes/r6_knot_250k.scene", 4096, 4096),
+    "ref_bunny": ("scenes/r6_ref_bunny.scene", 4096, 4096), "ref_cow": ("scenes/r6_ref_cow.scene", 4096, 4096),
+    "ref_teapot": ("scenes/r6_ref_teapot.scene", 4096, 4096), "ref_sphere": ("scenes/r6_ref_sphere.scene", 4096, 4096),
     "headline_nocull": ("scenes/cfg2_smooth_250k.scene", 4096, 4096),
     "cfg2_nocull": ("scenes/cfg2_smooth_250k.scene", 1920, 1080),
 }
@@ -305,7 +310,10 @@ def main():
     from rendering_amd import assets, parallel
     import rendering_amd as RA
     if rank == 0:
-        assets.ensure(["bumpy_250k.obj"] if "250k" in args.scene else None)
+        # the generated assets the scene names (the two 250k-triangle meshes are made on demand only), plus the small default set
+        wanted = [os.path.basename(l.split("=", 1)[1].strip()) for l in open(args.scene) if l.startswith("name=scenes/assets/")]
+        assets.ensure()
+        assets.ensure([n for n in wanted if n in assets._GENERATORS])
     if world > 1:
         dist.barrier()
     W, H = args.width, args.height

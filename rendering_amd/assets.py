@@ -117,6 +117,55 @@ def torus_obj(nu=32, nv=24, R=1.0, r=0.35, uv=(1.0, 0.0, 1.0, 0.0)):
     return ("\n".join(lines) + "\n").encode()
 
 
+def knot_obj(nu=1000, nv=125, p=2, q=3, R=1.0, r=0.45, tube=0.17):
+    """Tube around a (p, q) torus knot, 2*nu*nv triangles with smooth normals (nu=1000, nv=125 -> 250 000): a second 250k-triangle mesh with NO pole
+    slivers (every quad has the same shape up to the curve's speed) and a silhouette full of self-occlusions -- evidence beyond the bumpy sphere the cost
+    model and the tuning knobs were fitted on (VERDICT r5 missing 4 / next 7)."""
+    t = 2.0 * np.pi * np.arange(nu) / nu
+
+    def centre(t):
+        c = R + r * np.cos(q * t)
+        return np.stack([c * np.cos(p * t), r * np.sin(q * t), c * np.sin(p * t)], -1)
+
+    h = 1e-4
+    C = centre(t)
+    T = centre(t + h) - centre(t - h); T /= np.linalg.norm(T, axis=-1, keepdims=True)
+    A = centre(t + h) - 2 * C + centre(t - h)                      # towards the centre of curvature
+    N1 = A - T * np.sum(A * T, -1, keepdims=True); N1 /= np.linalg.norm(N1, axis=-1, keepdims=True)
+    N2 = np.cross(T, N1)
+    a = 2.0 * np.pi * np.arange(nv) / nv
+    nrm = N1[:, None, :] * np.cos(a)[None, :, None] + N2[:, None, :] * np.sin(a)[None, :, None]      # [nu, nv, 3]
+    P = C[:, None, :] + tube * nrm
+    lines = ["# tube around a (%d,%d) torus knot nu=%d nv=%d (generated)" % (p, q, nu, nv)]
+    lines += ["v %.6f %.6f %.6f" % tuple(x) for x in P.reshape(-1, 3)]
+    lines += ["vn %.6f %.6f %.6f" % tuple(x) for x in nrm.reshape(-1, 3)]
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    va = i * nv + j + 1
+    vb = ((i + 1) % nu) * nv + j + 1
+    vc = ((i + 1) % nu) * nv + (j + 1) % nv + 1
+    vd = i * nv + (j + 1) % nv + 1
+    for a_, b_, c_, d_ in np.stack([va, vb, vc, vd], -1).reshape(-1, 4):
+        # (outward-facing for the reference's det > 0 front-face convention: checked by the culling-on render showing the knot, not its inside)
+        lines.append("f %d//%d %d//%d %d//%d" % (a_, a_, c_, c_, b_, b_))
+        lines.append("f %d//%d %d//%d %d//%d" % (a_, a_, d_, d_, c_, c_))
+    return ("\n".join(lines) + "\n").encode()
+
+
+def ref_model_obj(name):
+    """One of the reference's own models (input/objects/{bunny,cow,teapot,sphere,shotgun}.obj) as an OBJ of the triangles the REFERENCE'S LOADER produced from it
+    (tests/golden/ref_models.npz, tools/make_golden_ref_models.py: positions only -- the OBJ files themselves stay in /root/reference): `v` lines and `f a b c`,
+    no `vn` (face normals, objects.cpp:20, 127).  The loaders normalise it into the scene's size / pos again (objects.cpp:285-330)."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "ref_models.npz"))
+    tri = d["pos_" + name].reshape(-1, 3).astype(np.float64)
+    # (back around the origin: the golden triangles are where the reference's scene put them, z < 0 throughout -- and the reference's loader starts its running
+    # maximum at the smallest POSITIVE float, objects.cpp:231, so an all-negative axis gets a wrong extent)
+    tri = tri - 0.5 * (tri.min(0) + tri.max(0))
+    lines = ["# %s: the triangles the reference's loader produced (tests/golden/ref_models.npz)" % name]
+    lines += ["v %.7g %.7g %.7g" % tuple(x) for x in tri]
+    lines += ["f %d %d %d" % (3 * k + 1, 3 * k + 2, 3 * k + 3) for k in range(len(tri) // 3)]
+    return ("\n".join(lines) + "\n").encode()
+
+
 def quad_poly_obj():
     """Tiny OBJ exercising `f a b c d` (no slashes) fan triangulation and a flat axis (objects.cpp:317-319,339-346)."""
     return (b"# unit quad, y flat\nv -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nf 1 4 3 2\n")
@@ -183,6 +232,9 @@ _GENERATORS = {
     "torus_uvwild.obj": lambda: torus_obj(32, 24, uv=(2.5, -0.75, -1.5, 1.2)),
     "coincident_4k.obj": coincident_obj,
     "quad.obj": quad_poly_obj,
+    "knot_250k.obj": knot_obj,
+    "ref_bunny.obj": lambda: ref_model_obj("bunny"), "ref_cow.obj": lambda: ref_model_obj("cow"), "ref_teapot.obj": lambda: ref_model_obj("teapot"),
+    "ref_sphere.obj": lambda: ref_model_obj("sphere"), "ref_shotgun.obj": lambda: ref_model_obj("shotgun"),
     "diffuse_1024.bmp": lambda: bmp24(diffuse_map(1024)),
     "normal_1024.bmp": lambda: bmp24(normal_map(1024)),
     "specular_1024.bmp": lambda: bmp24(specular_map(1024)),
@@ -198,7 +250,7 @@ def ensure(names=None):
     """Create the named assets (default: all but the 18 MB 250k mesh) if missing.  Returns {name: path}."""
     os.makedirs(ASSETS, exist_ok=True)
     if names is None:
-        names = [n for n in _GENERATORS if n != "bumpy_250k.obj"]
+        names = [n for n in _GENERATORS if n not in ("bumpy_250k.obj", "knot_250k.obj")]
     out = {}
     for n in names:
         p = os.path.join(ASSETS, n)
