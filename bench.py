@@ -257,6 +257,16 @@ CONFIGS = {
     "headline_nocull": ("scenes/cfg2_smooth_250k.scene", 4096, 4096),
     "cfg2_nocull": ("scenes/cfg2_smooth_250k.scene", 1920, 1080),
 }
+
+
+def one_launch_hint(scene):
+    """True when rtx_render_frame settled on the single launch for this view (nothing to pipeline: the stages already overlap inside it)."""
+    try:
+        return scene.frame_mode()[0] == 1
+    except Exception:
+        return False
+
+
 CONFIG_FLAGS = {"headline_nocull": {"useBackfaceCulling": 0}, "cfg2_nocull": {"useBackfaceCulling": 0}}
 
 
@@ -444,6 +454,11 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0])
+    # HIP-event durations of every launch of the timed region (on the launch stream: rtx_kernel_time_stats), read before anything else renders
+    n1, ms1 = scene.kernel_time_stats(0)
+    nS, msS = scene.kernel_time_stats(1)
+    n2, ms2 = scene.kernel_time_stats(2)
+    n4, ms4 = scene.kernel_time_stats(4)
     frame_status = 0
     if ssaa:
         # 0, or error | 0x100 when the single launch of some timed frame gave up (the last one was rendered again in three launches, earlier
@@ -492,6 +507,38 @@ def main():
         frame_latency_ms = float(lat[0]) * 1e3
         gather_ms_rank = sum(a.elapsed_time(b) for a, b in zip(g0, g1)) / 5
 
+    # N = 1, frames in a SEQUENCE: the SSAA launch of frame k (a few thousand latency-bound items: 0.3 of the issue peak) beside pass 1 + Sobel of frame k + 1 on a second
+    # stream, two framebuffers -- what a caller rendering a camera path would do.  Reported beside `ms_per_step`, which stays the serial frame (one stream, one
+    # framebuffer: every frame complete before the next begins); both framebuffers are compared with the serial frame afterwards.
+    pipelined_ms = pipelined_same = None
+    if world == 1 and ssaa and not one_launch_hint(scene):
+        fbs = [fb, torch.zeros_like(fb)]; masks = [mask, torch.zeros_like(mask)]
+        ref_fb, ref_mask = fb.clone(), mask.clone()
+        sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+        free = [None, None]
+
+        def piped(k):
+            i = k & 1
+            if free[i] is not None:
+                sA.wait_event(free[i])          # frame k - 2 has left this framebuffer
+            scene.render_pass1(fbs[i], stream=sA)
+            scene.sobel(fbs[i], masks[i], stream=sA)
+            e = torch.cuda.Event(); e.record(sA)
+            sB.wait_event(e)
+            scene.render_ssaa(masks[i], fbs[i], stream=sB)
+            free[i] = torch.cuda.Event(); free[i].record(sB)
+        torch.cuda.synchronize()
+        for k in range(4):
+            piped(k)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for k in range(args.steps):
+            piped(k)
+        torch.cuda.synchronize()
+        pipelined_ms = (time.perf_counter() - tp) / args.steps * 1e3
+        pipelined_same = bool((fbs[0] == ref_fb).all()) and bool((fbs[1] == ref_fb).all()) and bool((masks[0] == ref_mask).all()) and bool((masks[1] == ref_mask).all())
+        del fbs, masks, ref_fb, ref_mask
+
     verified = None
     if args.verify and world > 1:
         gathered = img.clone()
@@ -502,11 +549,7 @@ def main():
             torch.cuda.synchronize()
             verified = bool((whole == gathered).all())
         sync()
-    n1, ms1 = scene.kernel_time_stats(0)
-    n2, ms2 = scene.kernel_time_stats(2)
-    n4, ms4 = scene.kernel_time_stats(4)
     frame_mode, split_ms, fused_ms = scene.frame_mode() if ssaa else (0, -1.0, -1.0)
-    nS, msS = scene.kernel_time_stats(1)
     # the dominant kernel = the launch with the largest SUMMED duration over the timed region (on cfg3 that is the SSAA launch,
     # not pass 1): pass 1, Sobel, SSAA, or the single kernel of the frame where that is what ran
     one_launch = ssaa and n4 > n1
@@ -642,6 +685,8 @@ def main():
                    # N > 1: ms_per_step is pipelined throughput when the gather overlaps the next frame's render; frame_latency_ms is one frame end to end
                    "ms_per_step_is": None if world == 1 else ("pipelined throughput (gather of frame k beside the render of frame k + 1)" if pipe is not None else "serial frames (render, gather, next frame)"),
                    "frame_latency_ms": None if frame_latency_ms is None else round(frame_latency_ms, 3),
+                   # (N = 1) a sequence of frames with the SSAA launch of frame k beside pass 1 of frame k + 1: two streams, two framebuffers; never `value`
+                   "pipelined_ms_per_frame": None if pipelined_ms is None else round(pipelined_ms, 3), "pipelined_frames_equal_serial_frame": pipelined_same,
                    "frame": ("one launch (rtxFrameKernel)" if one_launch else "three launches (pass 1, Sobel, SSAA)") if ssaa else "pass 1 only",
                    "measured_three_launches_ms": None if split_ms < 0 else round(split_ms, 3), "measured_one_launch_ms": None if fused_ms < 0 else round(fused_ms, 3),
                    "pass1_ms": round(ms1 / n1, 3) if n1 else None, "ssaa_ms": round(ms2 / n2, 3) if n2 else None,
