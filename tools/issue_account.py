@@ -5,13 +5,13 @@ counters, gpurun_out/r04/r04_dbg_counts.txt), against the SQ_INSTS_VALU the hard
 of the body is taken), so the walk's share is an upper bound and "everything else" a lower bound.
 python tools/issue_account.py > profiles/r04_issue_account.txt   (also writes profiles/r04_issue_account.json: useful_valu_frac for bench.py)"""
 import json, os, re, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"      # python tools/issue_account.py <round tag> > profiles/<tag>_issue_account.txt
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"      # python tools/issue_account.py <round tag> > profiles/<tag>_issue_account.txt
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from srchash import source_hash
 from isa_mix import klass, issue_cycles
 
-K = "_Z14rtxPass1KernelILb0ELb1ELb1EEvN4rtxd6ParamsE"
+K = "_Z14rtxPass1KernelILb0ELb1ELb1ELi1EEvN4rtxd6ParamsE"
 lines = open(os.path.join(ROOT, "build", "rtx_api-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith(K + ":"))
 loops, order, cur = {}, [], "top"
@@ -49,7 +49,7 @@ sec = dbg.split("== nosrc")[0]
 m = re.search(r"node visits (\d+), reached leaves (\d+), filter passes \(64 references\) (\d+), of which rejected whole by stage 1 (\d+), by stage 2 (\d+); survivors tested exactly (\d+)", sec)
 visits, leaves, npass, rej1, rej2, exact = [int(x) for x in m.groups()]
 pmc = json.load(open(os.path.join(ROOT, "profiles", TAG + "_pass1_pmc.json")))
-kern = [v for n, v in pmc["workloads"]["headline"]["kernels"].items() if "Pass1Kernel<false, true, true>" in n][0]
+kern = [v for n, v in pmc["workloads"]["headline"]["kernels"].items() if "Pass1Kernel<false, true, true" in n][0]
 total = kern["SQ_INSTS_VALU"]
 pv = sum(loops[k]["valu"] for k in passes) / len(passes)
 # the exact-test loop: the deepest loops nested right after each pass body
