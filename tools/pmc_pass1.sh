@@ -10,7 +10,7 @@ export RTX_ALLOW_ENV_KNOBS=1      # the product ignores RTX_* environment knobs 
 # FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots); the SQ counters fill two passes (the split of the wave-cycles --
 # SQ_WAIT_ANY = parked on s_waitcnt, SQ_WAIT_INST_ANY = ready but not issued, SQ_ACTIVE_INST_ANY = issuing -- and SQ_THREAD_CYCLES_VALU).
 # Usage: tools/pmc_pass1.sh <round tag, e.g. r05> [workloads, default: all]
-TAG=${1:-r05}
+TAG=${1:-r06}
 WLS=${2:-"headline cfg1 cfg2 cfg3 cfg4 cfg5 area"}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
