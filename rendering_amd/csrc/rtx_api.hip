@@ -450,7 +450,9 @@ int estimateCosts(rtx_scene* s)
 		for (size_t l = 0; l < s->estLights.size() && l < 8; l++)
 			for (size_t q = 0; q < s->estPlanes.size() && q < 4 && src.n < 16; q++) {
 				const auto& L = s->estLights[l]; const auto& P = s->estPlanes[q];
-				src.kind[src.n] = (int32_t)L[3]; memcpy(src.l[src.n], L.data(), 12); memcpy(src.p[src.n], P.data(), 24);
+				// (kind 1 distant, 2 point; an area light: 2 + 4 n_points -- the weight of its shadow in the estimate)
+				src.kind[src.n] = L[3] > 2.5f ? 2 : (int32_t)L[3]; src.weight[src.n] = L[3] > 2.5f ? (uint32_t)((L[3] - 2.0f) / 4.0f) : 1u;
+				memcpy(src.l[src.n], L.data(), 12); memcpy(src.p[src.n], P.data(), 24);
 				src.n++;
 			}
 	for (const auto& m : s->meshLeaves)
@@ -589,7 +591,7 @@ int flattenMesh(const rtx_mesh& m, bool pruneWanted, FlatMesh& out)
 		}
 		// The walk's stack: while a node of wide level L is visited, every level above it has at most kWideSlots - 1 of its slots waiting and the node
 		// pushes at most kWideSlots -- (kWideSlots - 1) (L - 1) + kWideSlots entries.  A tree deeper than the stack allows is walked in the binary form
-		// (eight slots, 76 entries: ten wide levels = thirty binary ones; the 250 000-triangle mesh has 27).
+		// (eight slots, 72 entries: ten wide levels = thirty binary ones need 71; the 250 000-triangle mesh has 27).
 		if (!nested || (kWideSlots - 1) * depthMax + 1 > kWideStackEntries) wide.clear();      // (wideStack holds kWideStackEntries per wave)
 		if (!wide.empty() && pruneWanted) {
 			// Prune records (rtxd::PruneRec): per binary node the true box of the triangles its subtree references and the
@@ -893,6 +895,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		s->srcLightIsPoint.push_back(l.type == RTX_LIGHT_POINT ? 1 : 0);
 		if (l.type == RTX_LIGHT_POINT) s->estLights.push_back({ { l.pos[0], l.pos[1], l.pos[2], 2.0f } });
 		else if (l.type == RTX_LIGHT_DISTANT) s->estLights.push_back({ { l.dir[0], l.dir[1], l.dir[2], 1.0f } });
+		// an area light casts n_points shadow rays per shaded point (scene.cpp:790-806) from about its centre: a point light whose shadow counts n_points times
+		else if (l.type == RTX_LIGHT_AREA) s->estLights.push_back({ { l.pos[0], l.pos[1], l.pos[2], 2.0f + 4.0f * (float)std::min<uint32_t>(l.n_points, 4096u) } });
 		if (l.type == RTX_LIGHT_AREA) {
 			if (!l.points || l.n_points == 0) return bail(fail(RTX_ERR_ARG, "area light without sample points"));
 			int rc;

@@ -32,8 +32,8 @@ static_assert(sizeof(Node) == 32, "node must be one s_load_dwordx8");
 constexpr int kWideLevels = RTX_WIDE_LEVELS;
 constexpr int kWideSlots = 1 << kWideLevels;
 // entries of the walk's per-wave stack in LDS (meshWalk): at most kWideSlots - 1 per wide level + 1 -- rtx_scene_create checks a mesh's depth against it
-// (a deeper tree is walked in the binary form).  Five blocks per CU hold 31 744 B of LDS each (the allocation granule): 76 entries x 16 B x 4 waves fit
-// beside 25 parked fields.
+// (a deeper tree is walked in the binary form).  Five blocks per CU hold 31 744 B of LDS each (the allocation granule): 72 entries x 16 B x 4 waves fit
+// beside 25 parked fields and the six axis records of pruneEval8 (rtx_kernels.hip, pruneUni).
 constexpr int kWideStackEntries = kWideSlots == 4 ? 56 : (kWideSlots == 8 ? 72 : 124);      // (72: ten wide levels = thirty binary ones need 71; 256 bytes of LDS went to pruneUni's axis records)
 struct WideNode { Node slot[kWideSlots]; };
 static_assert(sizeof(WideNode) == 32 * kWideSlots && (kWideSlots == 4 || kWideSlots == 8 || kWideSlots == 16), "wide node = two s_load_dwordx16 per four slots");
@@ -81,7 +81,8 @@ constexpr float kSrcAinfMax = 32.0f;         // the source certificate assumes |
 // the box (interval arithmetic): det / (s1 s2) = dir . q,  Nt / (s1 s2) = v0 . q - orig . q.   No usable bound: q = 0 +- 0, [wlo, whi] = [-inf, +inf] (never rejected).
 struct PlaneRec { float qc[3]; float wlo; float qr[3]; float whi; };
 static_assert(sizeof(PlaneRec) == 32, "plane record = two dwordx4");
-// per wide node: PruneRec[kWideSlots] then PlaneRec[kWideSlots] (slot order) = 64 bytes per slot; lane k of the first 2 kWideSlots lanes of a wave reads record k
+// per wide node: PruneRec[kWideSlots] then PlaneRec[kWideSlots] (slot order) = 64 bytes per slot.  Eight slots: lane 4 r + a of a wave reads words a and 4 + a of
+// record r (r < 8 boxes, r >= 8 planes; a = 3: the records' fourth words) -- rtx_kernels.hip, pruneEval8; other widths: lane k of the first 2 kWideSlots lanes reads record k
 struct PruneBlock { PruneRec box[kWideSlots]; PlaneRec plane[kWideSlots]; };
 static_assert(sizeof(PruneBlock) == 64 * kWideSlots, "prune block");
 

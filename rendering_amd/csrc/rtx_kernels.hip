@@ -5,16 +5,18 @@
 // Execution model (DESIGN_HISTORY.md section 3):
 //   * persistent waves pull work items (8x8 pixel tiles, or 16 / 4 / 1 SSAA pixels x 4 samples) from atomic queues;
 //   * the 64 lanes of a wave are 64 rays = one BUNDLE; every Render::trace of the wave is ONE cooperative walk
-//     (meshWalk): the reference's tree two levels per fetch (rtxd::WideNode, scalar loads, a wave-level stack in LDS),
-//     every lane testing the slot boxes on its own ray with the reference's arithmetic; slots whose triangles no ray of
-//     the bundle can hit are dropped beforehand (rtxd::PruneBlock: pruneAlive / planeAlive, lanes acting as slots);
+//     (meshWalk): the reference's tree three levels per fetch (rtxd::WideNode: eight slots, scalar loads, a wave-level stack
+//     in LDS), every lane testing the slot boxes on its own ray with the reference's arithmetic; slots whose triangles no ray
+//     of the bundle can hit are dropped beforehand (rtxd::PruneBlock; pruneEval8: the lanes acting as (record, axis) pairs --
+//     the inequalities are those of pruneAlive / planeAlive, which remain for the other node widths);
 //   * the references of the reached leaves are streamed 64 at a time with the lanes acting as TRIANGLES: the bundle
 //     filter (bundleRejects1/2) keeps what some ray might hit, the survivors are tested exactly (the reference's
 //     Moller-Trumbore, operation by operation) with the lanes acting as rays again, in the reference's order --
 //     "strict <, first hit wins" (objects.cpp:587-631);
-//   * trees that do not allow the wide walk (boxes not nested, culling off, a zero direction component, the
-//     instrumented variant) take the stackless binary walk: a lane that fails a box sleeps until the wave's cursor
-//     reaches the node's skip index;
+//   * what does not allow the wide walk (boxes not nested, a tree deeper than the stack, the instrumented variant; RAYS with
+//     a zero direction component or a huge origin, walked apart from the rest of their wave) takes the stackless binary walk:
+//     a lane that fails a box sleeps until the wave's cursor reaches the node's skip index.  Back-face culling off is a
+//     kernel of its own (CULLK): the same wide walk with the culling-free forms of the filter and of the plane records;
 //   * castRay's recursion is an explicit per-lane frame stack in HBM ([slot][field][lane], coalesced) so the
 //     nested colour expressions keep the reference's association order (scene.cpp:858-940).
 //
@@ -2109,16 +2111,17 @@ __global__ void __launch_bounds__(256) rtxFrameClearKernel(uint32_t* __restrict_
 // The estimate only orders and splits work; no pixel depends on it.  Measured costs replace it tile by tile.
 // blockIdx.y = 0: the camera's splat; y >= 1: the shadow of the leaves cast by light / plane pair y - 1 (below).  One launch for all of them (they only add to the
 // grid), and one 64-bit atomic per cell: (references, leaves) are neighbouring words.
-struct SplatSources { uint32_t n; int32_t kind[16]; float l[16][3]; float p[16][6]; };      // kind 1: distant light (l = the direction it travels in), 2: point light (l = position); p = plane (position, normal)
+struct SplatSources { uint32_t n; int32_t kind[16]; uint32_t weight[16]; float l[16][3]; float p[16][6]; };      // weight: shadow rays per shaded point towards this light (an area light's n_points)      // kind 1: distant light (l = the direction it travels in), 2: point light (l = position); p = plane (position, normal)
 __global__ void __launch_bounds__(256) rtxCostSplatKernel(const float* __restrict__ boxes, uint32_t nLeaves, const View view, uint32_t gridW, uint32_t gridH,
                                                           uint32_t* __restrict__ grid, const SplatSources src)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nLeaves) return;
 	const float* b = boxes + (size_t)i * 8;      // true box of the leaf's triangles (lo, hi), reference count
-	const uint32_t n = (uint32_t)b[6];
-	const float* M = view.camM;
 	const uint32_t sIdx = blockIdx.y;
+	const uint32_t wgt = sIdx != 0 ? src.weight[sIdx - 1] : 1u;
+	const uint32_t n = (uint32_t)b[6] * wgt;
+	const float* M = view.camM;
 	float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f;
 	for (int c = 0; c < 8; ++c) {
 		float cx = b[(c & 1) ? 3 : 0], cy = b[(c & 2) ? 4 : 1], cz = b[(c & 4) ? 5 : 2];
@@ -2151,7 +2154,7 @@ __global__ void __launch_bounds__(256) rtxCostSplatKernel(const float* __restric
 	if ((long long)(cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 4096) return;      // (a leaf that fills the screen says nothing about where the work is)
 	for (int cy = cy0; cy <= cy1; ++cy)
 		for (int cx = cx0; cx <= cx1; ++cx)
-			atomicAdd((unsigned long long*)(grid + 2 * ((size_t)cy * gridW + cx)), (1ull << 32) | n);      // (+ n references, + 1 leaf)
+			atomicAdd((unsigned long long*)(grid + 2 * ((size_t)cy * gridW + cx)), ((unsigned long long)wgt << 32) | n);      // (+ n references, + 1 leaf -- times the shadow rays per point)
 }
 
 // farPlanes (up to four planes: position, normal) + farTicks: a tile through which the camera sees a plane FAR away (the horizon of a floor) shades points
