@@ -59,7 +59,7 @@ def reference_baseline(scene_path, width, height, gpu_scene, cores, ssaa=True, f
     try:
         dump = os.path.join(tempfile.gettempdir(), "bench_ref_%d" % os.getpid())
         out = subprocess.run([sys.executable, "-c", REF_CHILD % ROOT, scene_path, str(width), str(height), str(cores), dump, "1" if ssaa else "0", json.dumps(flags or {})],
-                             cwd=ROOT, capture_output=True, text=True, timeout=300)
+                             cwd=ROOT, capture_output=True, text=True, timeout=900)
         sec = [float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith("REF_PASS1_SECONDS")]
         if out.returncode != 0 or not sec:
             return None

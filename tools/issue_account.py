@@ -41,7 +41,8 @@ for ln in lines[start + 1:]:
 # the wide walk: its node loop holds the two s_load_dwordx16 of a WideNode and the two prune-record loads; the pass bodies are the
 # loops with the ds_bpermute broadcasts of a survivor's record (first four in program order after the node loop = wide walk: two
 # passes per fetch, each compiled twice); the exact test is their innermost child
-node = next(k for k in order if loops[k]["smem16"] >= 2 and loops[k]["vmem"] >= 2)
+# (the INNERMOST such loop: since round 6 the object loop around the walk holds a mesh's three record loads and the split constants' reload as well)
+node = max((k for k in order if loops[k]["smem16"] >= 2 and loops[k]["vmem"] >= 2), key=lambda k: (loops[k]["smem16"], int(k.split()[-1])))
 after = order[order.index(node) + 1:]
 passes = [k for k in after if loops[k]["bperm"] >= 10][:4]
 dbg = open(os.path.join(ROOT, "gpurun_out", TAG, TAG + "_dbg_counts.txt")).read()
@@ -58,7 +59,7 @@ ex = [k for k in after if depth(k) == depth(passes[0]) + 1 and loops[k]["valu"] 
 ev = sum(loops[k]["valu"] for k in ex) / max(len(ex), 1)
 print("sources %s, counters of sources %s; headline frame, rtxPass1Kernel<false, true, true>, one launch" % (source_hash(), pmc["source_hash"]))
 print("SQ_INSTS_VALU (hardware)                                   %.3e wave-instructions" % total)
-rows = [("node visit (pop, WideNode + prune records, pruneAlive / planeAlive, 4 slot tests, pushes)", node, loops[node]["valu"], visits),
+rows = [("node visit (pop, WideNode + prune records, pruneEval8 on 48 lanes, 8 slot tests, pushes)", node, loops[node]["valu"], visits),
         ("filter pass of 64 references (assign, bundleRejects1/2, ballots; without the exact tests)", passes[0], pv, npass),
         ("exact test of one survivor (record through ds_bpermute, Moller-Trumbore)", ex[0] if ex else "-", ev, exact)]
 acc = 0
