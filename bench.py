@@ -285,6 +285,9 @@ def main():
     ap.add_argument("--verify", dest="verify", action="store_true", default=True,
                     help="N > 1 (default): after the timed region rank 0 also renders the whole frame alone and compares the gathered image with it")
     ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="N = 1: after the timed region also measure a SEQUENCE of frames with the SSAA launch of frame k beside pass 1 of frame k + 1 (two streams, two "
+                         "framebuffers) -> config.pipelined_ms_per_frame; never `value` (off by default: its overlapping launches would enter a profiler's per-kernel averages)")
     ap.add_argument("--serial-gather", action="store_true",
                     help="N > 1: rtx_gather on the render stream, frame by frame (default: on a second stream, overlapping the next frame)")
     args = ap.parse_args()
@@ -511,7 +514,7 @@ def main():
     # stream, two framebuffers -- what a caller rendering a camera path would do.  Reported beside `ms_per_step`, which stays the serial frame (one stream, one
     # framebuffer: every frame complete before the next begins); both framebuffers are compared with the serial frame afterwards.
     pipelined_ms = pipelined_same = None
-    if world == 1 and ssaa and not one_launch_hint(scene):
+    if args.pipelined and world == 1 and ssaa and not one_launch_hint(scene):
         fbs = [fb, torch.zeros_like(fb)]; masks = [mask, torch.zeros_like(mask)]
         ref_fb, ref_mask = fb.clone(), mask.clone()
         sA, sB = torch.cuda.Stream(), torch.cuda.Stream()

@@ -17,9 +17,19 @@ if [ "$1" = 1 ]; then
   (DBG_PRODUCT=1 RTX_DEBUG_ITEMS=1 python tools/dbg_counts.py; python tools/dbg_ssaa_product.py) 2>&1 | grep -v amdgpu.ids > $O/r06_dbg_counts.txt
   ./build.sh > /dev/null 2>&1
   tail -3 $O/pmc.log; head -3 $O/r06_dbg_counts.txt
+elif [ "$1" = 3 ]; then
+  # (only the runs under rocprofv3 and the default line again: after a change of bench.py alone)
+  python bench.py > $O/bench_default.log 2>&1; grep '^{' $O/bench_default.log > $O/r06_bench_default.json
+  bash tools/profile.sh r06 --steps 20 --warmup 5 > $O/profile_headline.log 2>&1
+  cp $(find gpurun_out/prof_r06 -name '*kernel_stats.csv' | head -1) $O/r06_kernel_stats.csv; cp gpurun_out/prof_r06/bench.json $O/r06_bench_under_rocprof.json
+  for c in cfg1 cfg2 cfg3 cfg4 cfg5 area knot ref_bunny headline_nocull; do
+    bash tools/profile.sh r06$c --config $c --steps 5 --warmup 1 > $O/profile_$c.log 2>&1
+    cp $(find gpurun_out/prof_r06$c -name '*kernel_stats.csv' | head -1) $O/r06_kernel_stats_$c.csv
+  done
+  head -4 $O/r06_kernel_stats.csv; cat $O/r06_bench_default.json | head -c 400
 else
-  for c in $WL; do python bench.py --config $c --steps 20 --warmup 5 2> $O/bench_$c.err | grep '^{' > $O/r06_bench_$c.json; done
-  cp $O/r06_bench_headline.json $O/r06_bench_default.json
+  for c in $WL; do python bench.py --config $c --steps 20 --warmup 5 --pipelined 2> $O/bench_$c.err | grep '^{' > $O/r06_bench_$c.json; done
+  python bench.py 2>/dev/null | grep '^{' > $O/r06_bench_default.json
   bash tools/profile.sh r06 --steps 5 --warmup 1 > $O/profile_headline.log 2>&1
   cp $(find gpurun_out/prof_r06 -name '*kernel_stats.csv' | head -1) $O/r06_kernel_stats.csv; cp gpurun_out/prof_r06/bench.json $O/r06_bench_under_rocprof.json
   for c in cfg1 cfg2 cfg3 cfg4 cfg5 area knot ref_bunny headline_nocull; do
