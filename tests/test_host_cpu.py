@@ -272,3 +272,35 @@ def test_a_tree_deeper_than_the_walks_stack_takes_the_binary_form(ra, depth, wid
     if wide_expected:
         link = wide[..., 6].view(np.int32)
         assert (link < 0).sum() == len(leaves)          # every leaf sits in exactly one slot
+
+
+@pytest.mark.parametrize("name", ["r6_ref_bunny", "r6_ref_cow", "r6_ref_teapot", "r6_ref_sphere"])
+def test_round6_workload_scenes_load_alike(ra, oracle, name):
+    """The round-6 bench workloads built from the reference's own models (rendering_amd/assets.py, ref_model_obj: the triangles the reference's loader produced,
+    tests/golden/ref_models.npz, written back as an OBJ): the host's loader + builder and the oracle's (pinned to the reference: tests/test_oracle_vs_reference.py)
+    produce the same triangles and the same acceleration structure, bit for bit."""
+    from rendering_amd import assets
+    assets.ensure()
+    s = ra.Scene("scenes/%s.scene" % name, 64, 64)
+    o = oracle.OracleScene("scenes/%s.scene" % name, 64, 64)
+    a, b = s.bvh(1), o.bvh(1)
+    assert a is not None and b is not None and a["n_tris"] == b["n_tris"] > 900
+    for k in ("n_nodes", "n_leaves", "n_refs", "max_depth"):
+        assert a[k] == b[k], k
+    for k in ("bounds", "skip", "leaf_begin", "leaf_count", "refs", "tris"):
+        assert np.array_equal(np.ascontiguousarray(a[k]).view(np.uint8), np.ascontiguousarray(b[k]).view(np.uint8)), k
+
+
+def test_knot_generator_is_a_closed_outward_tube():
+    """The second 250k-triangle mesh (assets.knot_obj) at a small size: 2 nu nv faces, every vertex used, and every face's geometric normal on the side of its
+    vertex normals (the reference culls by winding: det > 0 is the front, objects.cpp:75-77)."""
+    from rendering_amd import assets
+    txt = assets.knot_obj(nu=60, nv=12).decode().split("\n")
+    v = np.array([[float(t) for t in l.split()[1:]] for l in txt if l.startswith("v ")])
+    vn = np.array([[float(t) for t in l.split()[1:]] for l in txt if l.startswith("vn ")])
+    f = np.array([[int(t.split("//")[0]) - 1 for t in l.split()[1:]] for l in txt if l.startswith("f ")])
+    assert len(v) == 60 * 12 == len(vn) and len(f) == 2 * 60 * 12 and set(f.ravel()) == set(range(len(v)))
+    # the reference's front face: det = e1 . (dir x e2) > 0 for a ray coming from outside, i.e. (e2 x e1) points against the outward normal
+    m = np.cross(v[f[:, 2]] - v[f[:, 0]], v[f[:, 1]] - v[f[:, 0]])
+    outward = vn[f[:, 0]] + vn[f[:, 1]] + vn[f[:, 2]]
+    assert ((m * outward).sum(1) < 0).all()
