@@ -134,6 +134,7 @@ struct rtx_scene {
 	bool stats = false;
 	bool analytic = true;         // no object is a triangle mesh: the ray kernels without the walk are launched
 	bool boxPrune = false;        // some mesh has triangles small enough for the box test of the prune records: the kernels with it are launched
+	bool plain = true;            // every object is Diffuse and every light a point / distant light: the mesh kernels without recursion, powf and area-light sums are launched (PLAIN)
 	// lazily sized work buffers
 	float* frames = nullptr; size_t framesBytes = 0, framesArea = 0;
 	uint32_t* tileCost = nullptr; uint32_t* items = nullptr; size_t tileCap = 0;   // per-tile pass-1 cost, SSAA scan array (2 tiles + 1, then scan scratch)
@@ -843,6 +844,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		if (o.material < 0 || o.material > 3) return bail(fail(RTX_ERR_ARG, "bad material"));
 		if (o.type == RTX_OBJ_MESH && (o.mesh < 0 || (uint32_t)o.mesh >= desc->n_meshes)) return bail(fail(RTX_ERR_ARG, "bad mesh index"));
 		if (o.type == RTX_OBJ_MESH) s->analytic = false;
+		if (o.material != 0) s->plain = false;
 		if (o.type == RTX_OBJ_PLANE) {
 			s->estPlanes.push_back({ { o.pos[0], o.pos[1], o.pos[2], o.normal[0], o.normal[1], o.normal[2] } });
 			const double nl = std::sqrt((double)o.normal[0] * o.normal[0] + (double)o.normal[1] * o.normal[1] + (double)o.normal[2] * o.normal[2]);
@@ -897,6 +899,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out)
 		else if (l.type == RTX_LIGHT_DISTANT) s->estLights.push_back({ { l.dir[0], l.dir[1], l.dir[2], 1.0f } });
 		// an area light casts n_points shadow rays per shaded point (scene.cpp:790-806) from about its centre: a point light whose shadow counts n_points times
 		else if (l.type == RTX_LIGHT_AREA) s->estLights.push_back({ { l.pos[0], l.pos[1], l.pos[2], 2.0f + 4.0f * (float)std::min<uint32_t>(l.n_points, 4096u) } });
+		if (l.type == RTX_LIGHT_AREA) s->plain = false;
 		if (l.type == RTX_LIGHT_AREA) {
 			if (!l.points || l.n_points == 0) return bail(fail(RTX_ERR_ARG, "area light without sample points"));
 			int rc;
@@ -1244,6 +1247,22 @@ int prepareView(rtx_scene* s)
 
 } // namespace
 
+
+// The mesh kernels exist per (box test of the prune records, culling mode, PLAIN): constants of the scene / the view, so that no kernel carries another's code.
+#define RTX_LAUNCH_MESH_KERNEL(K, PRE, blocks_, st_, p_)                                                                        \
+	do {                                                                                                                       \
+		const bool cullOn_ = ((p_).view.flags & RTX_FLAG_BACKFACE_CULL) != 0, box_ = s->boxPrune, plain_ = s->plain;            \
+		if (plain_) {                                                                                                          \
+			if (cullOn_) { if (box_) hipLaunchKernelGGL((K<PRE true, 1, true>), dim3(blocks_), dim3(256), 0, st_, p_); else hipLaunchKernelGGL((K<PRE false, 1, true>), dim3(blocks_), dim3(256), 0, st_, p_); } \
+			else { if (box_) hipLaunchKernelGGL((K<PRE true, 0, true>), dim3(blocks_), dim3(256), 0, st_, p_); else hipLaunchKernelGGL((K<PRE false, 0, true>), dim3(blocks_), dim3(256), 0, st_, p_); }        \
+		}                                                                                                                      \
+		else {                                                                                                                 \
+			if (cullOn_) { if (box_) hipLaunchKernelGGL((K<PRE true, 1>), dim3(blocks_), dim3(256), 0, st_, p_); else hipLaunchKernelGGL((K<PRE false, 1>), dim3(blocks_), dim3(256), 0, st_, p_); } \
+			else { if (box_) hipLaunchKernelGGL((K<PRE true, 0>), dim3(blocks_), dim3(256), 0, st_, p_); else hipLaunchKernelGGL((K<PRE false, 0>), dim3(blocks_), dim3(256), 0, st_, p_); }        \
+		}                                                                                                                      \
+	} while (0)
+#define RTX_COMMA ,
+
 int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb_dev, void* stream)
 {
 	RoctxRange range("Render scene (rtx_render_pass1)");
@@ -1293,13 +1312,7 @@ int rtx_render_pass1(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, float* fb
 	if ((rc = stamp(s, 0, st))) return rc;
 	if (s->stats) hipLaunchKernelGGL(rtxPass1Kernel<true>, dim3(blocks), dim3(256), 0, st, p);
 	else if (s->analytic) hipLaunchKernelGGL((rtxPass1Kernel<false, false>), dim3(blocks), dim3(256), 0, st, p);
-	// (mesh kernels exist per culling mode -- a constant of the view: neither form carries the other's walks)
-	else if (!(p.view.flags & RTX_FLAG_BACKFACE_CULL)) {
-		if (!s->boxPrune) hipLaunchKernelGGL((rtxPass1Kernel<false, true, false, 0>), dim3(blocks), dim3(256), 0, st, p);
-		else hipLaunchKernelGGL((rtxPass1Kernel<false, true, true, 0>), dim3(blocks), dim3(256), 0, st, p);
-	}
-	else if (!s->boxPrune) hipLaunchKernelGGL((rtxPass1Kernel<false, true, false>), dim3(blocks), dim3(256), 0, st, p);
-	else hipLaunchKernelGGL(rtxPass1Kernel<false>, dim3(blocks), dim3(256), 0, st, p);
+	else RTX_LAUNCH_MESH_KERNEL(rtxPass1Kernel, false RTX_COMMA true RTX_COMMA, blocks, st, p);
 	HIPCHK(hipGetLastError());
 	if ((rc = stamp(s, 0, st))) return rc;
 	return RTX_OK;
@@ -1398,12 +1411,7 @@ static int renderFrameFused(rtx_scene* s, uint32_t rowBegin, uint32_t rowEnd, fl
 	if (blocks > wavesNeeded) blocks = wavesNeeded ? wavesNeeded : 1;
 	if ((rc = stamp(s, 4, st))) return rc;
 	if (s->analytic) hipLaunchKernelGGL(rtxFrameKernel<false>, dim3(blocks), dim3(256), 0, st, p);
-	else if (!(p.view.flags & RTX_FLAG_BACKFACE_CULL)) {
-		if (!s->boxPrune) hipLaunchKernelGGL((rtxFrameKernel<true, false, 0>), dim3(blocks), dim3(256), 0, st, p);
-		else hipLaunchKernelGGL((rtxFrameKernel<true, true, 0>), dim3(blocks), dim3(256), 0, st, p);
-	}
-	else if (!s->boxPrune) hipLaunchKernelGGL((rtxFrameKernel<true, false>), dim3(blocks), dim3(256), 0, st, p);
-	else hipLaunchKernelGGL(rtxFrameKernel<true>, dim3(blocks), dim3(256), 0, st, p);
+	else RTX_LAUNCH_MESH_KERNEL(rtxFrameKernel, true RTX_COMMA, blocks, st, p);
 	HIPCHK(hipGetLastError());
 	if ((rc = stamp(s, 4, st))) return rc;
 	return RTX_OK;
@@ -1679,12 +1687,7 @@ int rtx_render_ssaa(rtx_scene* s, const uint8_t* mask_dev, uint32_t rowBegin, ui
 	HIPCHK(hipGetLastError());
 	if (s->stats) hipLaunchKernelGGL(rtxSsaaKernel<true>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
 	else if (s->analytic) hipLaunchKernelGGL((rtxSsaaKernel<false, false>), dim3(s->blocksSsaa), dim3(256), 0, st, p);
-	else if (!(p.view.flags & RTX_FLAG_BACKFACE_CULL)) {
-		if (!s->boxPrune) hipLaunchKernelGGL((rtxSsaaKernel<false, true, false, 0>), dim3(s->blocksSsaa), dim3(256), 0, st, p);
-		else hipLaunchKernelGGL((rtxSsaaKernel<false, true, true, 0>), dim3(s->blocksSsaa), dim3(256), 0, st, p);
-	}
-	else if (!s->boxPrune) hipLaunchKernelGGL((rtxSsaaKernel<false, true, false>), dim3(s->blocksSsaa), dim3(256), 0, st, p);
-	else hipLaunchKernelGGL(rtxSsaaKernel<false>, dim3(s->blocksSsaa), dim3(256), 0, st, p);
+	else RTX_LAUNCH_MESH_KERNEL(rtxSsaaKernel, false RTX_COMMA true RTX_COMMA, s->blocksSsaa, st, p);
 	HIPCHK(hipGetLastError());
 	if ((rc = stamp(s, 2, st))) return rc;
 	return RTX_OK;

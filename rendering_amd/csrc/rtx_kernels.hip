@@ -1517,6 +1517,10 @@ __device__ __forceinline__ void shadePrimary(const Params& P, Lane& s, const Hit
 struct LightRec { int type; V3 color; float intensity; V3 dir, pos; uint32_t nPoints; const float* points; };
 
 // Runs the lane's castRay state machine until it needs a Render::trace (returns true) or is finished.
+// PLAIN (round 6): the kernel was chosen for a scene whose objects are all Diffuse and whose lights are all point / distant lights (rtx_scene_create checks; nothing can change
+// either afterwards) -- the mirror / glass recursion with its frame stack, Phong's powf (a real call) and the area-light sums cannot be reached, and are not compiled in: a third of
+// the state machine's code and half of the kernel's scratch go with them (pass 1 of the headline -2.7 %: profiles/r06_ab_plain.txt).
+template <bool PLAIN = false>
 __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 {
 	const int maxDepth = P.view.maxDepth;
@@ -1549,6 +1553,7 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 			}
 			const LightRec* l = &lr;
 			const int lt = l->type;
+			if (PLAIN && lt == 3) __builtin_unreachable();
 			float dist;
 			if (lt == 1) {                 // DistantLight::illuminate, lights.cpp:18-23
 				s.L = l->dir;
@@ -1600,6 +1605,7 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 		if (s.state == ST_LIGHTS_DONE) {
 			RTX_T0
 			const Object* ob = P.objects + s.obj;
+			if (PLAIN && s.mat != 0) __builtin_unreachable();
 			if (s.mat == 0) { s.col = s.objColor * s.diff; s.state = ST_RETURN; continue; }       // scene.cpp:808
 			if (s.mat == 3) {                                                                   // scene.cpp:852
 				s.col = s.objColor * ob->ambient + s.diff * ob->diffuse + s.spec * s.specCoef;
@@ -1639,6 +1645,7 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 		if (s.state == ST_RETURN) {
 			RTX_T0
 			if (s.sp == 0) { s.state = ST_DONE; return; }
+			if (PLAIN) __builtin_unreachable();      // (nothing ever pushed a frame)
 			s.sp--;
 			// The whole frame is requested at once (14 coalesced loads, one round trip) instead of the kind first and then the fields of
 			// that kind: a deep reflect / refract tree is a chain of these, and a small frame lasts as long as its deepest pixel.
@@ -1669,6 +1676,7 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 }
 
 // Consumes a finished Render::trace for this lane.
+template <bool PLAIN = false>
 __device__ __forceinline__ void consume(const Params& P, Lane& s, const Hit& h)
 {
 	if (s.state == ST_WAIT_PRIMARY) {
@@ -1682,6 +1690,7 @@ __device__ __forceinline__ void consume(const Params& P, Lane& s, const Hit& h)
 	if (s.state == ST_WAIT_SHADOW) {
 		RTX_T0
 		const float vis = (h.obj < 0) ? 1.0f : 0.0f;       // bool vis = !trace(...)
+		if (PLAIN && (s.mat != 0 || s.qarea)) __builtin_unreachable();
 		const bool area = s.qarea;
 		const V3 nL = -s.L;
 		if (s.mat == 0) {
@@ -1752,7 +1761,7 @@ __device__ __forceinline__ const Params& freshParams(const Params& P)
 }
 
 // CAM: the rays handed in start at the camera (o == view.camPos bit for bit: pass 1, SSAA, the frame kernel -- not the probe rays)
-template <bool STATS, bool MESH = true, bool FEWRAYS = false, bool BOXES = true, bool CAM = true, int CULLK = -1>
+template <bool STATS, bool MESH = true, bool FEWRAYS = false, bool BOXES = true, bool CAM = true, int CULLK = -1, bool PLAIN = false>
 __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3 d, uint32_t gl, Counts& cnt)
 {
 	const Params& P = freshParams(P0);
@@ -1763,7 +1772,7 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 	s.P = s.N = s.objColor = s.diff = s.spec = s.L = s.I = mk(0, 0, 0);
 	s.specCoef = s.nSpec = s.dsum = s.ssum = 0;
 	s.qtmax = kFltMax; s.qmoot = false; s.qarea = false; s.qsrc = 0;
-	advance(P, s, gl);
+	advance<PLAIN>(P, s, gl);
 	RTX_DBG_ONLY(unsigned long long dbgRounds = 0, dbgTrace = 0, dbgState = 0;)
 	while (ballot(s.state != ST_DONE) != 0) {
 		Hit h;
@@ -1809,8 +1818,8 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 		RTX_DBG_ONLY(const unsigned long long dbgT1 = __builtin_readcyclecounter();)
 		if (s.state != ST_DONE) {
 			const Params& Pa = freshParams(P0);
-			consume(Pa, s, h);
-			advance(Pa, s, gl);
+			consume<PLAIN>(Pa, s, h);
+			advance<PLAIN>(Pa, s, gl);
 		}
 		RTX_DBG_ONLY(dbgRounds++; dbgTrace += dbgT1 - dbgT0; dbgState += __builtin_readcyclecounter() - dbgT1;)
 	}
@@ -1871,7 +1880,7 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 // ------------------------------------------------------------------------------------------------
 // BOXES = false: the variant for scenes whose meshes all have triangles too large for the box test of the prune records to prune
 // anything (rtxd::Object::pruneBoxes; cfg4): the same kernel without that test (the plane test stays).
-template <bool STATS, bool MESH = true, bool BOXES = true, int CULLK = (STATS || !MESH) ? -1 : 1>
+template <bool STATS, bool MESH = true, bool BOXES = true, int CULLK = (STATS || !MESH) ? -1 : 1, bool PLAIN = false>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rtxPass1Kernel(const Params P)
 {
 	fillPowTab();
@@ -1924,7 +1933,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 			else
 			if (sload1(P.tileCost + ty * P.tilesXFull + tx) > RTX_PRIO_TICKS) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 			const unsigned long long t0 = wall_clock64();
-			const V3 c = castRayWave<STATS, MESH, false, BOXES, true, CULLK>(P, valid, o, d, gl, cnt);
+			const V3 c = castRayWave<STATS, MESH, false, BOXES, true, CULLK, PLAIN>(P, valid, o, d, gl, cnt);
 			const unsigned long long dt = wall_clock64() - t0;
 			RTX_TRACE_ONLY(dbgEnd = t0 + dt; dbgBusy += dt;)
 			if (lane == 0) {
@@ -1960,7 +1969,7 @@ __device__ __forceinline__ uint32_t nthSetBit(uint64_t m, uint32_t n)   // posit
 	return pos;
 }
 
-template <bool STATS, bool MESH = true, bool BOXES = true, int CULLK = (STATS || !MESH) ? -1 : 1>
+template <bool STATS, bool MESH = true, bool BOXES = true, int CULLK = (STATS || !MESH) ? -1 : 1, bool PLAIN = false>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTIC) rtxSsaaKernel(const Params P)
 {
 	fillPowTab();
@@ -1988,7 +1997,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTI
 		V3 o, d;
 		primaryRay(P, fx, fy, o, d);
 		const unsigned long long t0 = wall_clock64();
-		const V3 c = castRayWave<STATS, MESH, true, BOXES, true, CULLK>(P, valid, o, d, gl, cnt);      // (work items of 16, 4 or 1 pixels: see the exact tests of meshWalk)
+		const V3 c = castRayWave<STATS, MESH, true, BOXES, true, CULLK, PLAIN>(P, valid, o, d, gl, cnt);      // (work items of 16, 4 or 1 pixels: see the exact tests of meshWalk)
 		if (!STATS) {
 			// what the item cost, as the time of a 16-pixel item (a 4-pixel item takes at least a quarter of it), kept per tile
 			// in the second half of tileCost: a profiling aid (rtx_tile_cost_read, tools/ssaa_items.py).  Ordering and sizing
@@ -2583,7 +2592,7 @@ enum : uint32_t {
 };
 #define RTX_FRAME_QUEUES 64u
 
-template <bool MESH, bool BOXES = true, int CULLK = MESH ? 1 : -1>
+template <bool MESH, bool BOXES = true, int CULLK = MESH ? 1 : -1, bool PLAIN = false>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYTIC) rtxFrameKernel(const Params P)
 {
 	fillPowTab();
@@ -2745,7 +2754,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYT
 		primaryRay(P, fx, fy, o, d);
 		if (slow) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 		const unsigned long long t0 = wall_clock64();
-		const V3 c = castRayWave<false, MESH, true, BOXES, true, CULLK>(P, valid, o, d, gl, cnt);
+		const V3 c = castRayWave<false, MESH, true, BOXES, true, CULLK, PLAIN>(P, valid, o, d, gl, cnt);
 		const unsigned long long dt = wall_clock64() - t0;
 		RTX_DBG_ONLY(
 		if (lane == 0 && wave < 8192 && dbgItems < 160) {
@@ -2914,3 +2923,10 @@ template __global__ void rtxSsaaKernel<false, true, true, 0>(const Params);
 template __global__ void rtxSsaaKernel<false, true, false, 0>(const Params);
 template __global__ void rtxFrameKernel<true, true, 0>(const Params);
 template __global__ void rtxFrameKernel<true, false, 0>(const Params);
+// ... and all of them again for scenes of Diffuse objects under point / distant lights only (PLAIN: see advance)
+#define RTX_PLAIN_INSTANCES(B, C)                                                  \
+template __global__ void rtxPass1Kernel<false, true, B, C, true>(const Params);    \
+template __global__ void rtxSsaaKernel<false, true, B, C, true>(const Params);     \
+template __global__ void rtxFrameKernel<true, B, C, true>(const Params);
+RTX_PLAIN_INSTANCES(true, 1) RTX_PLAIN_INSTANCES(false, 1) RTX_PLAIN_INSTANCES(true, 0) RTX_PLAIN_INSTANCES(false, 0)
+#undef RTX_PLAIN_INSTANCES

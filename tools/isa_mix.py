@@ -10,10 +10,11 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from srchash import source_hash, ROOT
 
-KERNELS = {"rtxPass1Kernel<false, true, true>": "_Z14rtxPass1KernelILb0ELb1ELb1ELi1EEvN4rtxd6ParamsE", "rtxFrameKernel<true, true>": "_Z14rtxFrameKernelILb1ELb1ELi1EEvN4rtxd6ParamsE",
-           "rtxSsaaKernel<false, true, true>": "_Z13rtxSsaaKernelILb0ELb1ELb1ELi1EEvN4rtxd6ParamsE",
-           # options::useBackfaceCulling = 0 (round 6: every mesh kernel exists per culling mode)
-           "rtxPass1Kernel<false, true, true, 0>": "_Z14rtxPass1KernelILb0ELb1ELb1ELi0EEvN4rtxd6ParamsE"}
+# (round 6: every mesh kernel exists per culling mode -- Li1 / Li0 -- and per PLAIN -- Lb1: scenes of Diffuse objects under point / distant lights, what the headline runs)
+KERNELS = {"rtxPass1Kernel<false, true, true>": "_Z14rtxPass1KernelILb0ELb1ELb1ELi1ELb1EEvN4rtxd6ParamsE", "rtxFrameKernel<true, true>": "_Z14rtxFrameKernelILb1ELb1ELi1ELb1EEvN4rtxd6ParamsE",
+           "rtxSsaaKernel<false, true, true>": "_Z13rtxSsaaKernelILb0ELb1ELb1ELi1ELb1EEvN4rtxd6ParamsE",
+           "rtxPass1Kernel<false, true, true, 1, false> (any material)": "_Z14rtxPass1KernelILb0ELb1ELb1ELi1ELb0EEvN4rtxd6ParamsE",
+           "rtxPass1Kernel<false, true, true, 0, true> (culling off)": "_Z14rtxPass1KernelILb0ELb1ELb1ELi0ELb1EEvN4rtxd6ParamsE"}
 
 
 def klass(op, line):

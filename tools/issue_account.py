@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from srchash import source_hash
 from isa_mix import klass, issue_cycles
 
-K = "_Z14rtxPass1KernelILb0ELb1ELb1ELi1EEvN4rtxd6ParamsE"
+K = "_Z14rtxPass1KernelILb0ELb1ELb1ELi1ELb1EEvN4rtxd6ParamsE"
 lines = open(os.path.join(ROOT, "build", "rtx_api-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith(K + ":"))
 loops, order, cur = {}, [], "top"

@@ -6,7 +6,7 @@ import re
 import sys
 
 path = sys.argv[1] if len(sys.argv) > 1 else "build/rtx_api-hip-amdgcn-amd-amdhsa-gfx950.s"
-K = sys.argv[2] if len(sys.argv) > 2 else "_Z14rtxPass1KernelILb0ELb1ELb1ELi1EEvN4rtxd6ParamsE"
+K = sys.argv[2] if len(sys.argv) > 2 else "_Z14rtxPass1KernelILb0ELb1ELb1ELi1ELb1EEvN4rtxd6ParamsE"
 lines = open(path).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith(K + ":"))
 end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
