@@ -506,10 +506,17 @@ __device__ __forceinline__ Bundle makeBundle(bool active, const V3& o, const V3&
 // Magnitudes outside the assumed range (or NaN) make the compares false: nothing is rejected.
 // Evaluated in two stages so that a wave whose 64 references all fail the cheap first stage (orientation and t range:
 // the back of the mesh, everything behind a shadow ray's origin) skips the second (u, v).
-struct FilterState { float kda, detHi1, sg; bool ok; };      // (kept small: it is live across the ballot between the stages)
+// RTX_FILTER_MASKS: the verdicts as wave masks -- every compare feeds a ballot directly (a v_cmp into an SGPR pair) and the masks are combined on the scalar side.
+// As bools, `ballot(valid && !rej1)` of values that went through the `||` chains' control flow compiled to v_cndmask + v_cmp per ballot.
+#if RTX_FILTER_MASKS
+typedef uint64_t FilterVerdict;
+#else
+typedef bool FilterVerdict;
+#endif
+struct FilterState { float kda, detHi1, sg; FilterVerdict ok; };      // (kept small: it is live across the ballot between the stages)
 
 template <bool CULL>
-__device__ __forceinline__ bool bundleRejects1(const Bundle& B, float tmaxB, const RefA& ra, const RefB& rb, const RefC& rc, FilterState& f)
+__device__ __forceinline__ FilterVerdict bundleRejects1(const Bundle& B, float tmaxB, const RefA& ra, const RefB& rb, const RefC& rc, FilterState& f)
 {
 	const float e1x = rb.e1x, e1y = rb.e1y, e1z = rb.e1z, e2x = rb.e2x, e2y = rc.e2y, e2z = rc.e2z;
 	const float ax = B.ocx - ra.v0x, ay = B.ocy - ra.v0y, az = B.ocz - ra.v0z;
@@ -518,34 +525,53 @@ __device__ __forceinline__ bool bundleRejects1(const Bundle& B, float tmaxB, con
 	const float s1 = fabsf(e1x) + fabsf(e1y) + fabsf(e1z), s2 = fabsf(e2x) + fabsf(e2y) + fabsf(e2z);
 	const float s12 = s1 * s2;
 	const float ainf = (fmaxf(fmaxf(fabsf(ax), fabsf(ay)), fabsf(az)) + B.roMax) * (1.0f + 0x1p-20f);
+#if !RTX_FILTER_MASKS
 	const bool tame = s1 < 0x1p20f && s2 < 0x1p20f && ainf < 0x1p41f;
+#endif
 	// det over the bundle
 	float detc = __builtin_fmaf(B.dcz, mz, __builtin_fmaf(B.dcy, my, B.dcx * mx));
 	const float detr = __builtin_fmaf(B.rdz, fabsf(mz), __builtin_fmaf(B.rdy, fabsf(my), B.rdx * fabsf(mx)));
 	const float Ed = __builtin_fmaf(B.kd, s12, kFilterEta);
 	float sg = 1.0f;
+#if RTX_FILTER_MASKS
+	uint64_t usable = ~0ull;
+#else
 	bool usable = true;
+#endif
 	if (!CULL) {
 		// culling off: the tests need the sign of det_c; both signs are handled by mirroring, an uncertain sign by not testing
 		const bool neg = detc + detr + Ed < 0;
+#if RTX_FILTER_MASKS
+		usable = ballot(neg) | ballot(detc - detr - Ed > 0);
+#else
 		usable = neg || detc - detr - Ed > 0;
+#endif
 		sg = neg ? -1.0f : 1.0f;
 		detc *= sg;
 	}
 	const float detHi = detc + detr + Ed;
+#if RTX_FILTER_MASKS
+	f.ok = B.sane ? usable & ballot(s1 < 0x1p20f) & ballot(s2 < 0x1p20f) & ballot(ainf < 0x1p41f) : 0ull;
+	const uint64_t rejO = CULL ? ballot(detHi < 0) & f.ok : 0ull;
+	// (an exit here for passes whose open references all face away -- before the t range -- measured neutral: profiles/r06_ab_control_flow.txt)
+#endif
 	// t: Nt = -(a . m), radius from the origin box
 	const float ntc = -sg * __builtin_fmaf(az, mz, __builtin_fmaf(ay, my, ax * mx));
 	const float ntr = __builtin_fmaf(B.roz, fabsf(mz), __builtin_fmaf(B.roy, fabsf(my), B.rox * fabsf(mx)));
 	const float Et = __builtin_fmaf(kFilterK * ainf, s12, kFilterEta);
 	const float detHi1 = detHi * (1.0f + 0x1p-18f);
-	const bool rej = (CULL && detHi < 0) || ntc + ntr < -Et || ntc - ntr - Et >= tmaxB * detHi1;
 	f.kda = B.kd * ainf; f.detHi1 = detHi1; f.sg = sg;
+#if RTX_FILTER_MASKS
+	return rejO | ((ballot(ntc + ntr < -Et) | ballot(ntc - ntr - Et >= tmaxB * detHi1)) & f.ok);
+#else
+	const bool rej = (CULL && detHi < 0) || ntc + ntr < -Et || ntc - ntr - Et >= tmaxB * detHi1;
 	f.ok = usable && tame && B.sane;
 	return rej && f.ok;
+#endif
 }
 
 template <bool CULL>
-__device__ __forceinline__ bool bundleRejects2(const Bundle& B, const RefA& ra, const RefB& rb, const RefC& rc, const FilterState& f)
+__device__ __forceinline__ FilterVerdict bundleRejects2(const Bundle& B, const RefA& ra, const RefB& rb, const RefC& rc, const FilterState& f, FilterVerdict open = FilterVerdict(0))      // open: the lanes still undecided (mask form)
 {
 	const float e1x = rb.e1x, e1y = rb.e1y, e1z = rb.e1z, e2x = rb.e2x, e2y = rc.e2y, e2z = rc.e2z;
 	const float ax = B.ocx - ra.v0x, ay = B.ocy - ra.v0y, az = B.ocz - ra.v0z;      // (recomputed: cheaper than three live registers)
@@ -562,6 +588,12 @@ __device__ __forceinline__ bool bundleRejects2(const Bundle& B, const RefA& ra, 
 	const float nurO = __builtin_fmaf(B.roRd, s2, __builtin_fmaf(B.roz, fabsf(cuz), __builtin_fmaf(B.roy, fabsf(cuy), B.rox * fabsf(cux))));
 	const float nur = (nurO + __builtin_fmaf(B.rdz, fabsf(wuz), __builtin_fmaf(B.rdy, fabsf(wuy), B.rdx * fabsf(wux)))) * (1.0f + 0x1p-19f);
 	const float Eu = __builtin_fmaf(f.kda, s2, kFilterEta);
+	if (!CULL) nuc *= f.sg;
+	const float nuLo = nuc - nur - Eu;
+#if RTX_FILTER_MASKS
+	const uint64_t rejU = (ballot(nuc + nur < -Eu) | ballot(nuLo > f.detHi1)) & f.ok;
+	if ((open & ~rejU) == 0) return rejU;      // (u decides every open lane: the wave skips v)
+#endif
 	// v: Nv = d . (a x e1)
 	const float wvx = __builtin_fmaf(ay, e1z, -(az * e1y)), wvy = __builtin_fmaf(az, e1x, -(ax * e1z)), wvz = __builtin_fmaf(ax, e1y, -(ay * e1x));
 	float nvc = __builtin_fmaf(B.dcz, wvz, __builtin_fmaf(B.dcy, wvy, B.dcx * wvx));
@@ -570,10 +602,13 @@ __device__ __forceinline__ bool bundleRejects2(const Bundle& B, const RefA& ra, 
 	const float nvrO = __builtin_fmaf(B.roRd, s1, __builtin_fmaf(B.roz, fabsf(cvz), __builtin_fmaf(B.roy, fabsf(cvy), B.rox * fabsf(cvx))));
 	const float nvr = (nvrO + __builtin_fmaf(B.rdz, fabsf(wvz), __builtin_fmaf(B.rdy, fabsf(wvy), B.rdx * fabsf(wvx)))) * (1.0f + 0x1p-19f);
 	const float Ev = __builtin_fmaf(f.kda, s1, kFilterEta);
-	if (!CULL) { nuc *= f.sg; nvc *= f.sg; }
-	const float nuLo = nuc - nur - Eu;
+	if (!CULL) nvc *= f.sg;
+#if RTX_FILTER_MASKS
+	return rejU | ((ballot(nvc + nvr < -Ev) | ballot(nuLo + (nvc - nvr - Ev) > f.detHi1)) & f.ok);
+#else
 	const bool rej = nuc + nur < -Eu || nuLo > f.detHi1 || nvc + nvr < -Ev || nuLo + (nvc - nvr - Ev) > f.detHi1;
 	return rej && f.ok;
+#endif
 }
 
 // The reference's test (objects.cpp:59-95) of the rays in exec against ONE triangle whose record is wave-uniform (read
@@ -777,10 +812,29 @@ __device__ __forceinline__ bool planeAlive(const f4v& r0, const f4v& r1, const B
 //     sign uncertain -> alive.
 // The box test rests on |det_c| >= 1e-8 and magnitudes only (pruneAlive; the source certificates likewise: rtx_source.hip works with |a . m|, and its
 // error terms are symmetric in e1, e2 -- a back face is the front face (e2, e1) with u and v exchanged), so it is the same with and without culling.
+#if RTX_PRUNE_LANEK
+// What a lane of pruneEval8 reads, as ONE register kept across the walk: bits 0-15 the byte offset of its two words in a node's PruneBlock, bits 16-31 the LDS
+// address of its axis record.  Deriving both from the lane index on every visit took 12 VALU instructions; kept as two or three separate registers they spilled.
+__device__ __forceinline__ uint32_t pruneLaneK(const float* pu)
+{
+	const uint32_t lane = laneNow(), axis = lane & 3u;
+	const uint32_t word = 2u * lane - axis;                   // record lane >> 2 (eight words each), word lane & 3
+	uint32_t ui = (lane >> 5) * 3u + axis;
+	ui = ui < 5u ? ui : 5u;                      // (the fourth lane of a plane quad reads a record that exists; what it computes is never used)
+	const uint32_t lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)(pu + ui * 8u);
+	return lds << 16 | word * 4u;
+}
+#endif
 template <bool BOXES, bool CULL = true>
-__device__ __forceinline__ uint32_t pruneEval8(const RTX_AS1 char* blk, const float* pu, float tmaxB)
+__device__ __forceinline__ uint32_t pruneEval8(const RTX_AS1 char* blk, const float* pu, float tmaxB, uint32_t laneK = 0)
 {
 	static_assert(kWideSlots == 8, "pruneEval8: lanes = 16 records x 4");
+#if RTX_PRUNE_LANEK
+	const uint32_t off = laneK & 0xffffu;
+	const float f0 = *(const RTX_AS1 float*)(blk + off), f1 = *(const RTX_AS1 float*)(blk + off + 16u);      // (uniform base + a 32-bit lane offset)
+	const __attribute__((address_space(3))) f4v* ur = (const __attribute__((address_space(3))) f4v*)(uintptr_t)(laneK >> 16);
+	const f4v ua = ur[0], ub = ur[1];
+#else
 	const uint32_t lane = laneNow();      // (recomputed here: the addresses derived from it are otherwise hoisted out of the node loop and live -- spilled -- across the walk)
 	const uint32_t axis = lane & 3u;
 	const RTX_AS1 float* pf = (const RTX_AS1 float*)blk;      // (uniform base + a 32-bit lane offset: one scalar-base load, no 64-bit address arithmetic per lane)
@@ -789,6 +843,7 @@ __device__ __forceinline__ uint32_t pruneEval8(const RTX_AS1 char* blk, const fl
 	uint32_t ui = (lane >> 5) * 3u + axis;
 	ui = ui < 5u ? ui : 5u;                      // (the fourth lane of a plane quad reads a record that exists; what it computes is never used)
 	const f4v ua = *(const f4v*)(pu + ui * 8u), ub = *(const f4v*)(pu + ui * 8u + 4u);
+#endif
 	// ---- per axis, both tests (each meaningful on its own half of the wave)
 	// box (pruneAlive): centre mirrored, the largest |orig - vertex| along this axis
 	const float c = __uint_as_float(__float_as_uint(f0) ^ __float_as_uint(ub.x));
@@ -943,6 +998,12 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 		}
 	}
 	if (WIDE && RTX_DBG) { cnt.aWalks++; if (shadow) cnt.sWalks++; }
+#if RTX_PRUNE_LANEK
+	uint32_t laneK = WIDE ? pruneLaneK(pu) : 0u;
+	asm volatile("" : "+v"(laneK));      // (one register, computed once per walk: not re-derived inside the node loop)
+#else
+	const uint32_t laneK = 0;
+#endif
 	if (WIDE) {
 		// (the rays in `consider` have passed the root box: traceWave)
 		const uint64_t m0 = ballot(consider);
@@ -1006,7 +1067,7 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				// (aliveM in the form pruneEval8 returns: slot k = bit 4 k)
 				aliveM = 0x11111111u;
 				if (evalPrune) {
-					aliveM = pruneEval8<BOXES, CULL>(pruneRecs + ((size_t)(uint32_t)(link - 1) << 9), pu, tmaxB);
+					aliveM = pruneEval8<BOXES, CULL>(pruneRecs + ((size_t)(uint32_t)(link - 1) << 9), pu, tmaxB, laneK);
 					if (RTX_DBG) { cnt.wS4++; cnt.wLeafSkips += (uint32_t)kWideSlots - (uint32_t)__popc(aliveM); }
 				}
 #define RTX_ALIVE(k) ((aliveM >> (4 * (k))) & 1u)
@@ -1170,11 +1231,18 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 			rb.e1x = vb.x; rb.e1y = vb.y; rb.e1z = vb.z; rb.e2x = vb.w; rc.e2y = vc.x; rc.e2z = vc.y;
 			FilterState fs;
 			const bool valid = p0 + lane < total;
+#if RTX_FILTER_MASKS
+			const uint64_t open1 = ballot(valid) & ~bundleRejects1<CULL>(B, tmaxB, ra, rb, rc, fs);
+			if (RTX_DBG) { cnt.wChunks++; if (shadow) cnt.sPasses++; }
+			if (open1 == 0) { if (RTX_DBG) cnt.wChunkSkips++; return false; }
+			uint64_t cand = open1 & ~bundleRejects2<CULL>(B, ra, rb, rc, fs, open1);
+#else
 			const bool rej1 = bundleRejects1<CULL>(B, tmaxB, ra, rb, rc, fs);
 			if (RTX_DBG) { cnt.wChunks++; if (shadow) cnt.sPasses++; }
 			if (ballot(valid && !rej1) == 0) { if (RTX_DBG) cnt.wChunkSkips++; return false; }
 			const bool rej2 = bundleRejects2<CULL>(B, ra, rb, rc, fs);
 			uint64_t cand = ballot(valid && !rej1 && !rej2);
+#endif
 			if (RTX_DBG) { cnt.wTri += __popcll(cand); if (shadow) cnt.sExact += __popcll(cand); if (cand == 0) cnt.wS2++; }
 			if (cand == 0) return false;
 			bool improved = false;
@@ -1211,6 +1279,9 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				}
 				cand = 0;
 			}
+#if RTX_EXACT_HOIST
+			const float btBefore = bt;      // (bt only falls: one compare after the survivors instead of one per survivor, and no copy of bt carried round the loop)
+#endif
 			while (cand != 0) {
 				const int c = __builtin_ctzll(cand);
 				cand &= cand - 1;
@@ -1227,10 +1298,17 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				// the rays that reached the survivor's leaf
 				const uint32_t ent = (kLeafBatch == 1 && !FEWRAYS) ? 0u : (uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)myEnt);
 				const bool pass = ((myReach >> ent) & 1u) != 0;      // (no dependent LDS read of the table's mask per survivor)
+#if !RTX_EXACT_HOIST
 				const float before = bt;
+#endif
 				if (pass) triTestOne<CULL, STATS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, tri, o, d, bt, bu, bv, btri);
+#if !RTX_EXACT_HOIST
 				improved = improved || bt < before;
+#endif
 			}
+#if RTX_EXACT_HOIST
+			improved = improved || bt < btBefore;
+#endif
 			RTX_DBG_ONLY(dbgExact += __builtin_readcyclecounter() - dbgE0;)
 			if (ballot(improved) != 0) {
 				// any-hit: a shadow ray only asks "is some t < light distance" (scene.cpp:787); once that is true
@@ -1520,6 +1598,164 @@ struct LightRec { int type; V3 color; float intensity; V3 dir, pos; uint32_t nPo
 // PLAIN (round 6): the kernel was chosen for a scene whose objects are all Diffuse and whose lights are all point / distant lights (rtx_scene_create checks; nothing can change
 // either afterwards) -- the mirror / glass recursion with its frame stack, Phong's powf (a real call) and the area-light sums cannot be reached, and are not compiled in: a third of
 // the state machine's code and half of the kernel's scratch go with them (pass 1 of the headline -2.7 %: profiles/r06_ab_plain.txt).
+#if RTX_ADVANCE_UNIFORM
+template <bool PLAIN = false>
+__device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
+{
+	const int maxDepth = P.view.maxDepth;
+	const float bias = P.view.bias;
+	// One loop for the whole wave with a UNIFORM exit: a lane that has reached a waiting state (or ST_DONE) sits out the remaining steps (run = false) instead
+	// of leaving the loop.  With per-lane `return`s the compiler kept every field of the lane state twice -- the value a lane left with and the value the others go on
+	// changing -- and copied 16-20 registers at the head of every step and at every exit (RTX_ADVANCE_UNIFORM = 0: that form).
+	bool run = true;
+	do {
+		if (!run) continue;
+		if (s.state == ST_NEWRAY) {
+			RTX_T0
+			if (s.sp > maxDepth) { s.col = skyColor(P, s.rd); s.state = ST_RETURN; RTX_ACC(0) continue; }   // scene.cpp:760
+			s.qtmax = kFltMax;
+			s.state = ST_WAIT_PRIMARY;
+			run = false; continue;
+		}
+		if (s.state == ST_NEXT_LIGHT) {
+			RTX_T0
+			if (s.li >= P.nLights) { s.state = ST_LIGHTS_DONE; continue; }
+			// The light's record comes through the scalar unit in one load, for the lanes that are at the light of the first lane here -- nearly always all of
+			// them; the others stay in this state and take their turn in a later step of the loop (the per-lane form was a chain of dependent vector loads --
+			// type, then the fields of that type -- and merging it with the scalar form cost 13 copies per step).
+			const uint32_t li0 = __builtin_amdgcn_readfirstlane(s.li);
+			if (s.li != li0) continue;
+			LightRec lr;
+			{
+				const u32x16 w = sload16(P.lights + li0);
+				lr.type = (int)w[0]; lr.color = mk(F(w[1]), F(w[2]), F(w[3])); lr.intensity = F(w[4]);
+				lr.dir = mk(F(w[5]), F(w[6]), F(w[7])); lr.pos = mk(F(w[8]), F(w[9]), F(w[10])); lr.nPoints = w[11];
+				lr.points = (const float*)(((uint64_t)w[13] << 32) | w[12]);
+			}
+			const LightRec* l = &lr;
+			const int lt = l->type;
+			if (PLAIN && lt != 1 && lt != 2) __builtin_unreachable();      // (rtx_scene_create: light types are 1 .. 3, and a PLAIN scene has no area light)
+			float dist;
+			if (lt == 1) {                 // DistantLight::illuminate, lights.cpp:18-23
+				s.L = l->dir;
+				s.I = l->color * l->intensity;
+				dist = kFltMax;
+			}
+			else if (lt == 2) {            // PointLight::illuminate, lights.cpp:32-38
+				const V3 lp = l->pos;
+				V3 L = s.P - lp;
+				s.I = l->color * attenuation(l->intensity, len2(L));
+				s.L = normalized(L);
+				dist = length(s.P - lp);
+			}
+			else {                         // area light sample loop, scene.cpp:790-806 etc.
+				const uint32_t np = l->nPoints;
+				if (s.si == 0) {
+					const V3 lp = l->pos;
+					s.I = l->color * attenuation(l->intensity, len2(s.P - lp));
+					s.dsum = 0; s.ssum = 0;
+				}
+				if (s.si >= np) {
+					const float fn = (float)np;
+					if (s.mat == 0) s.diff = s.diff + s.I * (s.dsum / fn);                       // scene.cpp:805
+					else if (s.mat == 3) {                                                      // scene.cpp:845-846
+						s.diff = s.diff + s.I * (s.dsum / fn);
+						s.spec = s.spec + s.I * powfRef(s.ssum / fn, s.nSpec);
+					}
+					else s.spec = s.spec + s.I * powfRef(s.ssum / fn, s.nSpec);                  // scene.cpp:887, 937
+					s.li++; s.si = 0;
+					continue;
+				}
+				V3 L = s.P - load3(inGlobal(l->points) + (size_t)s.si * 3);
+				dist = length(L);
+				s.L = normalized(L);
+			}
+			// Diffuse (scene.cpp:780-809): the only use of the shadow ray is  vis * max(0, N . -L)  with vis in {0, 1}.  When
+			// the max is +0 (surface turned away from the light, or NaN) the product is the same +0 for either answer: the
+			// ray cannot influence the pixel ("moot"), and the product kernels do not walk it (castRayWave).
+			s.qmoot = s.mat == 0 && fmaxRef(0.f, dot(s.N, -s.L)) == 0.f;
+			s.qarea = lt == 3;
+			// (a light's source copy was derived for shadow-ray origins within srcNmax |bias| of the surface: a shading normal longer than the host
+			// looked at -- a caller's un-normalised tri_nrm, a future object type -- or NaN falls back to copy 0 instead of pruning with too small a sigma)
+			s.qsrc = (lt == 2 && s.li < P.nSrcLights && len2(s.N) <= P.srcNmax2) ? 2u + s.li : 0u;
+			s.qtmax = dist;               // the ray itself: Ray{P + N*bias, -L, ShadowRay} (scene.cpp:787), built in castRayWave
+			s.state = ST_WAIT_SHADOW;
+			RTX_ACC(1)
+			run = false; continue;
+		}
+		if (s.state == ST_LIGHTS_DONE) {
+			RTX_T0
+			const Object* ob = P.objects + s.obj;
+			if (PLAIN && s.mat != 0) __builtin_unreachable();
+			if (s.mat == 0) { s.col = s.objColor * s.diff; s.state = ST_RETURN; continue; }       // scene.cpp:808
+			if (s.mat == 3) {                                                                   // scene.cpp:852
+				s.col = s.objColor * ob->ambient + s.diff * ob->diffuse + s.spec * s.specCoef;
+				s.state = ST_RETURN; continue;
+			}
+			if (s.mat == 1) {                                                                   // scene.cpp:856-858, 890
+				frameAt(P, gl, s.sp, 0) = __int_as_float(FR_REFL);
+				frameAt(P, gl, s.sp, 2) = s.spec.x; frameAt(P, gl, s.sp, 3) = s.spec.y; frameAt(P, gl, s.sp, 4) = s.spec.z;
+				const V3 nd = s.rd - s.N * (2 * dot(s.rd, s.N));
+				s.ro = s.P + s.N * bias; s.rd = nd;
+				s.sp++; s.state = ST_NEWRAY; RTX_ACC(2) continue;
+			}
+			// Transparent, scene.cpp:893-907
+			const float ior = ob->ior;
+			const float kr = fresnelKr(s.rd, s.N, ior);
+			const bool outside = dot(s.rd, s.N) < 0;
+			const V3 biasVec = s.N * bias;
+			const V3 fd = normalized(reflectDir(s.rd, s.N));
+			const V3 fo = outside ? s.P + biasVec : s.P - biasVec;
+			frameAt(P, gl, s.sp, 1) = kr;
+			frameAt(P, gl, s.sp, 2) = s.spec.x; frameAt(P, gl, s.sp, 3) = s.spec.y; frameAt(P, gl, s.sp, 4) = s.spec.z;
+			if (kr < 1) {
+				const V3 rd = normalized(refractDir(s.rd, s.N, ior));
+				const V3 ro = outside ? s.P - biasVec : s.P + biasVec;
+				frameAt(P, gl, s.sp, 0) = __int_as_float(FR_TRANS1);
+				frameAt(P, gl, s.sp, 8) = fo.x; frameAt(P, gl, s.sp, 9) = fo.y; frameAt(P, gl, s.sp, 10) = fo.z;
+				frameAt(P, gl, s.sp, 11) = fd.x; frameAt(P, gl, s.sp, 12) = fd.y; frameAt(P, gl, s.sp, 13) = fd.z;
+				s.ro = ro; s.rd = rd;
+			}
+			else {
+				frameAt(P, gl, s.sp, 0) = __int_as_float(FR_TRANS2);
+				frameAt(P, gl, s.sp, 5) = 0.f; frameAt(P, gl, s.sp, 6) = 0.f; frameAt(P, gl, s.sp, 7) = 0.f;
+				s.ro = fo; s.rd = fd;
+			}
+			s.sp++; s.state = ST_NEWRAY; RTX_ACC(3) continue;
+		}
+		if (s.state == ST_RETURN) {
+			RTX_T0
+			if (s.sp == 0) { s.state = ST_DONE; run = false; continue; }
+			if (PLAIN) __builtin_unreachable();      // (nothing ever pushed a frame)
+			s.sp--;
+			// The whole frame is requested at once (14 coalesced loads, one round trip) instead of the kind first and then the fields of
+			// that kind: a deep reflect / refract tree is a chain of these, and a small frame lasts as long as its deepest pixel.
+			float fr[kFrameFields];
+			for (int k = 0; k < kFrameFields; ++k) fr[k] = frameAt(P, gl, s.sp, k);
+			asm volatile("" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]), "+v"(fr[4]), "+v"(fr[5]), "+v"(fr[6]));
+			asm volatile("" : "+v"(fr[7]), "+v"(fr[8]), "+v"(fr[9]), "+v"(fr[10]), "+v"(fr[11]), "+v"(fr[12]), "+v"(fr[13]));
+			const int kind = __float_as_int(fr[0]);
+			const V3 spec = mk(fr[2], fr[3], fr[4]);
+			if (kind == FR_REFL) { s.col = s.col * 0.8f + spec; RTX_ACC(4) continue; }                      // scene.cpp:858, 890
+			const float kr = fr[1];
+			if (kind == FR_TRANS1) {                                                             // scene.cpp:896-902
+				const V3 acc = mk(0, 0, 0) + s.col * (1 - kr);
+				frameAt(P, gl, s.sp, 0) = __int_as_float(FR_TRANS2);
+				frameAt(P, gl, s.sp, 5) = acc.x; frameAt(P, gl, s.sp, 6) = acc.y; frameAt(P, gl, s.sp, 7) = acc.z;
+				s.ro = mk(fr[8], fr[9], fr[10]);
+				s.rd = mk(fr[11], fr[12], fr[13]);
+				s.sp++; s.state = ST_NEWRAY; RTX_ACC(5) continue;
+			}
+			V3 acc = mk(fr[5], fr[6], fr[7]);
+			acc = acc + s.col * kr;                                                              // scene.cpp:908
+			s.col = acc + spec * kr;                                                             // scene.cpp:940
+			RTX_ACC(6)
+			continue;
+		}
+		run = false;   // ST_DONE / waiting states
+	} while (ballot(run) != 0);
+}
+#else
 template <bool PLAIN = false>
 __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 {
@@ -1674,6 +1910,7 @@ __device__ __forceinline__ void advance(const Params& P, Lane& s, uint32_t gl)
 		return;   // ST_DONE / waiting states
 	}
 }
+#endif
 
 // Consumes a finished Render::trace for this lane.
 template <bool PLAIN = false>
@@ -1772,9 +2009,16 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 	s.P = s.N = s.objColor = s.diff = s.spec = s.L = s.I = mk(0, 0, 0);
 	s.specCoef = s.nSpec = s.dsum = s.ssum = 0;
 	s.qtmax = kFltMax; s.qmoot = false; s.qarea = false; s.qsrc = 0;
-	advance<PLAIN>(P, s, gl);
 	RTX_DBG_ONLY(unsigned long long dbgRounds = 0, dbgTrace = 0, dbgState = 0;)
+#if RTX_ONE_ADVANCE
+	// (one copy of advance() in the kernel: at the head of the round instead of before the loop and at its end -- the same sequence of steps)
+	for (;;) {
+		advance<PLAIN>(freshParams(P0), s, gl);
+		if (ballot(s.state != ST_DONE) == 0) break;
+#else
+	advance<PLAIN>(P, s, gl);
 	while (ballot(s.state != ST_DONE) != 0) {
+#endif
 		Hit h;
 		RTX_DBG_ONLY(const unsigned long long dbgT0 = __builtin_readcyclecounter();)
 		// moot shadow rays (see advance): only the instrumented variant walks them -- the reference's statistics count
@@ -1819,7 +2063,9 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 		if (s.state != ST_DONE) {
 			const Params& Pa = freshParams(P0);
 			consume<PLAIN>(Pa, s, h);
+#if !RTX_ONE_ADVANCE
 			advance<PLAIN>(Pa, s, gl);
+#endif
 		}
 		RTX_DBG_ONLY(dbgRounds++; dbgTrace += dbgT1 - dbgT0; dbgState += __builtin_readcyclecounter() - dbgT1;)
 	}

@@ -61,3 +61,18 @@
 #ifndef RTX_WIDE_NOCULL
 #define RTX_WIDE_NOCULL 1       // options::useBackfaceCulling = 0 takes the wide walk with prune records too (0: the stackless binary walk, as until round 5)
 #endif
+#ifndef RTX_FILTER_MASKS
+#define RTX_FILTER_MASKS 1      // bundle filter: verdicts as wave masks (a ballot per compare, combined on the scalar side) instead of bools (whose ballots compiled to v_cndmask + v_cmp)
+#endif
+#ifndef RTX_EXACT_HOIST
+#define RTX_EXACT_HOIST 1       // exact tests of a pass: "did a lane's t improve" is one compare after the survivors, not one per survivor (0: the per-survivor form, with its copies of t)
+#endif
+#ifndef RTX_ADVANCE_UNIFORM
+#define RTX_ADVANCE_UNIFORM 1   // castRay state machine: advance() steps all lanes in one loop with a uniform exit (finished lanes sit out) instead of per-lane returns
+#endif
+#ifndef RTX_ONE_ADVANCE
+#define RTX_ONE_ADVANCE 1       // castRayWave: advance() once per round, at its head (0: before the loop and at the end of every round -- two copies of its code)
+#endif
+#ifndef RTX_PRUNE_LANEK
+#define RTX_PRUNE_LANEK 1       // pruneEval8: a lane's two addresses (PruneBlock words, LDS axis record) packed in one register per walk instead of 12 VALU instructions per visit
+#endif
