@@ -2165,6 +2165,52 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 			RTX_DBG_ONLY(if (P.pad3 != 0 && tile != P.pad3 - 1) continue;)   // RTX_DBG_TILE=tx,ty: only this tile (counters of one work item)
 			// a tile (ty << 16 | tx), or a 64 x 1 strip of a halo row (0x10000000 | strip << 16 | y: rtx_api.hip, buildTileList),
 			// which is accounted to the first of the eight tiles it runs through
+#if RTX_TILE_RECOMPUTE
+			// What the tile's pixels are is derived from the list entry twice -- before the rays are cast and again afterwards, from fresh copies of the parameters --
+			// instead of being kept (x, y and a dozen scalars: spilled) across castRayWave.
+			uint32_t tx, ty, x, y; bool strip, valid;
+			auto place = [&](const Params& Pt, uint32_t ln) {
+				strip = (tile & Pt.stripBit) != 0;      // (stripBit = 0 when the list holds no strips: tile rows from 4096 on use bit 28 themselves)
+				tx = strip ? ((tile >> 16) & 0xfffu) * 8 : tile & 0xffffu; ty = strip ? (tile & 0x7fffu) >> 3 : tile >> 16;
+				x = strip ? tx * 8 + ln : tx * 8 + (ln & 7); y = strip ? tile & 0x7fffu : ty * 8 + (ln >> 3);
+				// x1/y1 are clamped to W-1/H-1: the last column and row are never rendered (scene.cpp:369-372)
+				valid = x < Pt.view.width - 1 && y < Pt.view.height - 1 && y >= Pt.rowBegin && y < Pt.rowEnd && rowRendered(Pt, y);
+			};
+			const Params& Pa = freshParams(P);
+			place(Pa, laneNow());
+			if (ballot(valid) == 0) continue;
+			V3 o, d;
+			primaryRay(Pa, (float)x + 0.5f, (float)y + 0.5f, o, d);
+			if (take > 1) __builtin_amdgcn_s_setprio(0);      // (the cheap part of the queue: no look at the tile's cost)
+			else
+			if (sload1(Pa.tileCost + ty * Pa.tilesXFull + tx) > RTX_PRIO_TICKS) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+			const unsigned long long t0 = wall_clock64();
+			const V3 c = castRayWave<STATS, MESH, false, BOXES, true, CULLK, PLAIN>(Pa, valid, o, d, gl, cnt);
+			const unsigned long long dt = wall_clock64() - t0;
+			RTX_TRACE_ONLY(dbgEnd = t0 + dt; dbgBusy += dt;)
+			uint32_t tileWas = tile;
+			asm volatile("" : "+s"(tileWas));      // (opaque: the expressions below are evaluated again, not carried over)
+			const Params& Pb = freshParams(P);
+			{
+				const uint32_t ln = laneNow();
+				const bool strip2 = (tileWas & Pb.stripBit) != 0;
+				const uint32_t tx2 = strip2 ? ((tileWas >> 16) & 0xfffu) * 8 : tileWas & 0xffffu, ty2 = strip2 ? (tileWas & 0x7fffu) >> 3 : tileWas >> 16;
+				const uint32_t x2 = strip2 ? tx2 * 8 + ln : tx2 * 8 + (ln & 7), y2 = strip2 ? tileWas & 0x7fffu : ty2 * 8 + (ln >> 3);
+				const bool valid2 = x2 < Pb.view.width - 1 && y2 < Pb.view.height - 1 && y2 >= Pb.rowBegin && y2 < Pb.rowEnd && rowRendered(Pb, y2);
+				if (ln == 0) {
+					// remembered per tile: the SSAA pass starts with the tiles that were expensive here (longest job first)
+					if (!strip2) Pb.tileCost[ty2 * Pb.tilesXFull + tx2] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
+					if (STATS) { atomicMax(Pb.counters + 3, dt); atomicAdd(Pb.counters + 4, dt); }
+				}
+				if (strip2 && ln < 8 && tx2 + ln < Pb.tilesX) Pb.tileCost[ty2 * Pb.tilesXFull + tx2 + ln] = (uint32_t)((dt > 0xffffffffull ? 0xffffffffull : dt) / 8);
+				if (valid2) {
+					float* px = Pb.fb + ((size_t)y2 * Pb.view.width + x2) * 3;
+					px[0] = c.x; px[1] = c.y; px[2] = c.z;
+				}
+			}
+		}
+	}
+#else
 			const bool strip = (tile & P.stripBit) != 0;      // (stripBit = 0 when the list holds no strips: tile rows from 4096 on use bit 28 themselves)
 			const uint32_t tx = strip ? ((tile >> 16) & 0xfffu) * 8 : tile & 0xffffu, ty = strip ? (tile & 0x7fffu) >> 3 : tile >> 16;
 			const uint32_t x = strip ? tx * 8 + lane : tx * 8 + (lane & 7), y = strip ? tile & 0x7fffu : ty * 8 + (lane >> 3);
@@ -2194,6 +2240,7 @@ __global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rt
 			}
 		}
 	}
+#endif
 	RTX_TRACE_ONLY(if (lane == 0 && (gl >> 6) < 16384) { gDbgWave[3 * (gl >> 6)] = dbgStart; gDbgWave[3 * (gl >> 6) + 1] = dbgEnd; gDbgWave[3 * (gl >> 6) + 2] = dbgBusy; })
 	if (STATS || RTX_DBG) flushCounts(P, cnt);
 }

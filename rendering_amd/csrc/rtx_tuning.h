@@ -76,3 +76,6 @@
 #ifndef RTX_PRUNE_LANEK
 #define RTX_PRUNE_LANEK 1       // pruneEval8: a lane's two addresses (PruneBlock words, LDS axis record) packed in one register per walk instead of 12 VALU instructions per visit
 #endif
+#ifndef RTX_TILE_RECOMPUTE
+#define RTX_TILE_RECOMPUTE 1    // rtxPass1Kernel: a tile's pixel coordinates are derived from the list entry again after castRayWave (fresh parameters) instead of being kept across it
+#endif
