@@ -44,7 +44,19 @@ for ln in lines[start + 1:]:
 # (the INNERMOST such loop: since round 6 the object loop around the walk holds a mesh's three record loads and the split constants' reload as well)
 node = max((k for k in order if loops[k]["smem16"] >= 2 and loops[k]["vmem"] >= 2), key=lambda k: (loops[k]["smem16"], int(k.split()[-1])))
 after = order[order.index(node) + 1:]
-passes = [k for k in after if loops[k]["bperm"] >= 10][:4]
+depth = lambda k: int(k.split()[-1])
+bp = [k for k in after if loops[k]["bperm"] >= 10][:4]
+if depth(bp[0]) == depth(node):
+    # (until the control-flow campaign of round 6 the broadcasts were counted to the pass loop, in front of the rotated exact-test loop)
+    passes = bp
+    ex = [k for k in after if depth(k) == depth(passes[0]) + 1 and loops[k]["valu"] > 40][:4]
+else:
+    # the loops holding the broadcasts ARE the exact-test loops; a pass body is the loop around each of them
+    ex = bp
+    passes = []
+    for e in ex:
+        before = order[:order.index(e)]
+        passes.append(next(k for k in reversed(before) if depth(k) == depth(e) - 1 and loops[k]["valu"] > 40))
 dbg = open(os.path.join(ROOT, "gpurun_out", TAG, TAG + "_dbg_counts.txt")).read()
 sec = dbg.split("== nosrc")[0]
 m = re.search(r"node visits (\d+), reached leaves (\d+), filter passes \(64 references\) (\d+), of which rejected whole by stage 1 (\d+), by stage 2 (\d+); survivors tested exactly (\d+)", sec)
@@ -53,9 +65,6 @@ pmc = json.load(open(os.path.join(ROOT, "profiles", TAG + "_pass1_pmc.json")))
 kern = [v for n, v in pmc["workloads"]["headline"]["kernels"].items() if "Pass1Kernel<false, true, true" in n][0]
 total = kern["SQ_INSTS_VALU"]
 pv = sum(loops[k]["valu"] for k in passes) / len(passes)
-# the exact-test loop: the deepest loops nested right after each pass body
-depth = lambda k: int(k.split()[-1])
-ex = [k for k in after if depth(k) == depth(passes[0]) + 1 and loops[k]["valu"] > 40][:4]
 ev = sum(loops[k]["valu"] for k in ex) / max(len(ex), 1)
 print("sources %s, counters of sources %s; headline frame, rtxPass1Kernel<false, true, true>, one launch" % (source_hash(), pmc["source_hash"]))
 print("SQ_INSTS_VALU (hardware)                                   %.3e wave-instructions" % total)
