@@ -93,7 +93,7 @@ def one(path, lines, name, KERNEL):
            "by_innermost_loop": {k: v for k, v in sorted(loops.items(), key=lambda kv: -sum(kv[1].values()))[:12]}}
     txt = "\n".join(lines)
     i = txt.index(".name:           " + KERNEL)
-    blk = txt[max(0, i - 1500):i + 1500]
+    blk = txt[i:i + 1500]      # (the keys wanted follow .name in the kernel's metadata map; looking in front of it finds the previous kernel's)
     for key in ("sgpr_count", "vgpr_count", "sgpr_spill_count", "vgpr_spill_count", "private_segment_fixed_size"):
         m = re.search(r"\.%s:\s+(\d+)" % key, blk)
         if m:
