@@ -283,7 +283,9 @@ int ensureWork(rtx_scene* s)
 		HIPCHK(hipMalloc((void**)&s->counters, 16 * sizeof(unsigned long long)));
 		HIPCHK(hipMemset(s->counters, 0, 16 * sizeof(unsigned long long)));
 		int b = 0;
-		HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxPass1Kernel<false>, 256, 0));
+		// (a PLAIN scene's pass-1 kernels may hold more blocks per CU than the general ones: RTX_WAVES_PLAIN)
+		if (s->plain) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxPass1Kernel<false, true, true, 1, true>, 256, 0));
+		else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, rtxPass1Kernel<false>, 256, 0));
 		if (b < 1) b = 1;
 		if (s->knobs.pass1BlocksPerCU >= 1 && s->knobs.pass1BlocksPerCU < b) b = s->knobs.pass1BlocksPerCU;
 		s->blocksPass1 = b * s->numCUs;

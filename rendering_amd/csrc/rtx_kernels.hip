@@ -966,6 +966,25 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 			if (laneNow() == 0) {
 				const bool nx = hx < 0, ny = hy < 0, nz = hz < 0;
 				const bool okx = usx && (lx > 0 || nx), oky = usy && (ly > 0 || ny), okz = usz && (lz > 0 || nz);
+#if RTX_PRUNE_AXIS
+				// (plain scalars, each record built in one go: assembled from the components of other vectors, the records went through 32 bytes of scratch per lane --
+				// the kernel's only scratch)
+				const float ilx = nx ? -hx : lx, ihx = nx ? -lx : hx, ily = ny ? -hy : ly, ihy = ny ? -ly : hy, ilz = nz ? -hz : lz, ihz = nz ? -lz : hz;
+				const float ocx = nx ? -B.ocx : B.ocx, ocy = ny ? -B.ocy : B.ocy, ocz = nz ? -B.ocz : B.ocz;
+				const float cap = B.kd * (kPruneC / kFilterK);      // 216 dmax (kd = K dmax, rounded up)
+				const float omax = fmaxf(fmaxf(fabsf(B.ocx) + B.rox, fabsf(B.ocy) + B.roy), fabsf(B.ocz) + B.roz);
+				const float eB = kFilterK * (omax + F(mp[13])) * (1.0f + 0x1p-20f) + 1e-30f;      // K (|orig| + |vertex|): see planeAlive
+				const float inf = __builtin_inff(), kd2 = 2.0f * B.kd;
+				*(f4v*)(pu + 0) = f4v{ ilx, ihx, ocx - B.rox, ocx + B.rox };  *(f4v*)(pu + 4) = f4v{ __uint_as_float(nx ? 0x80000000u : 0u), okx ? inf : -inf, cap, omax };
+				*(f4v*)(pu + 8) = f4v{ ily, ihy, ocy - B.roy, ocy + B.roy };  *(f4v*)(pu + 12) = f4v{ __uint_as_float(ny ? 0x80000000u : 0u), oky ? inf : -inf, cap, omax };
+				*(f4v*)(pu + 16) = f4v{ ilz, ihz, ocz - B.roz, ocz + B.roz }; *(f4v*)(pu + 20) = f4v{ __uint_as_float(nz ? 0x80000000u : 0u), okz ? inf : -inf, cap, omax };
+				// (the bundle's fields as opaque scalars: the compiler keeps the struct in four-float slices and gathered these records from them through scratch)
+				float dcx = B.dcx, dcy = B.dcy, dcz = B.dcz, rdx = B.rdx, rdy = B.rdy, rdz = B.rdz;
+				asm volatile("" : "+v"(dcx), "+v"(dcy), "+v"(dcz), "+v"(rdx), "+v"(rdy), "+v"(rdz));
+				*(f4v*)(pu + 24) = f4v{ dcx, rdx, B.ocx, B.rox }; *(f4v*)(pu + 28) = f4v{ kd2, eB, 0.0f, 0.0f };
+				*(f4v*)(pu + 32) = f4v{ dcy, rdy, B.ocy, B.roy }; *(f4v*)(pu + 36) = f4v{ kd2, eB, 0.0f, 0.0f };
+				*(f4v*)(pu + 40) = f4v{ dcz, rdz, B.ocz, B.roz }; *(f4v*)(pu + 44) = f4v{ kd2, eB, 0.0f, 0.0f };
+#else
 				f4v a, b, c, e;
 				a.x = nx ? -hx : lx; a.y = nx ? -lx : hx; a.z = ny ? -hy : ly; a.w = ny ? -ly : hy;
 				b.x = nz ? -hz : lz; b.y = nz ? -lz : hz;
@@ -980,16 +999,6 @@ __device__ __forceinline__ void meshWalk(const u32x16& mp, const Bundle& B, bool
 				f.x = __uint_as_float(nx ? 0x80000000u : 0u); f.y = __uint_as_float(ny ? 0x80000000u : 0u); f.z = __uint_as_float(nz ? 0x80000000u : 0u);
 				f.w = okx ? __builtin_inff() : -__builtin_inff();
 				g.x = oky ? __builtin_inff() : -__builtin_inff(); g.y = okz ? __builtin_inff() : -__builtin_inff(); g.z = 0; g.w = 0;
-#if RTX_PRUNE_AXIS
-				f4v r;
-				r.x = a.x; r.y = a.y; r.z = b.z; r.w = b.w; *(f4v*)(pu + 0) = r;  r.x = f.x; r.y = f.w; r.z = e.x; r.w = e.y; *(f4v*)(pu + 4) = r;
-				r.x = a.z; r.y = a.w; r.z = c.x; r.w = c.y; *(f4v*)(pu + 8) = r;  r.x = f.y; r.y = g.x; r.z = e.x; r.w = e.y; *(f4v*)(pu + 12) = r;
-				r.x = b.x; r.y = b.y; r.z = c.z; r.w = c.w; *(f4v*)(pu + 16) = r; r.x = f.z; r.y = g.y; r.z = e.x; r.w = e.y; *(f4v*)(pu + 20) = r;
-				const float kd2 = 2.0f * B.kd;
-				r.x = B.dcx; r.y = B.rdx; r.z = B.ocx; r.w = B.rox; *(f4v*)(pu + 24) = r; r.x = kd2; r.y = e.w; r.z = 0; r.w = 0; *(f4v*)(pu + 28) = r;
-				r.x = B.dcy; r.y = B.rdy; r.z = B.ocy; r.w = B.roy; *(f4v*)(pu + 32) = r; r.x = kd2; r.y = e.w; r.z = 0; r.w = 0; *(f4v*)(pu + 36) = r;
-				r.x = B.dcz; r.y = B.rdz; r.z = B.ocz; r.w = B.roz; *(f4v*)(pu + 40) = r; r.x = kd2; r.y = e.w; r.z = 0; r.w = 0; *(f4v*)(pu + 44) = r;
-#else
 				*(f4v*)(pu + 0) = a; *(f4v*)(pu + 4) = b; *(f4v*)(pu + 8) = c; *(f4v*)(pu + 12) = e;
 				*(f4v*)(pu + 16) = f; *(f4v*)(pu + 20) = g;
 #endif
@@ -1979,11 +1988,20 @@ __device__ __forceinline__ void primaryRay(const Params& P, float x, float y, V3
 constexpr bool kParkColor = kWideSlots < 16;      // (sixteen-slot nodes: the stack takes the 3 KB of objColor's three fields)
 constexpr int kParkFields = 25 - (kParkColor ? 0 : 3);
 constexpr int kPk = kParkColor ? 0 : -3;          // index shift of the fields behind objColor      // (26 with nSpec until the eight-slot walk's stack needed the kilobyte: five blocks per CU hold 31 744 B each)
-__shared__ float parkedState[kParkFields][256];
+// (PLAIN kernels: no specular sum and no specular coefficient to park -- four kilobytes less, which with the pow table they do not touch is what a SIXTH block per CU needs)
+template <bool PLAIN> struct ParkLayout { static constexpr int kFields = kParkFields - (PLAIN ? 4 : 0), kSp = PLAIN ? -3 : 0; };
+template <bool PLAIN>
+__device__ __forceinline__ float (*parkArea())[256]
+{
+	__shared__ float area[ParkLayout<PLAIN>::kFields][256];
+	return area;
+}
 // Five blocks per CU hold 31 744 B of LDS each (160 KB / 5, rounded down to the allocation granule): one array over the edge and the pass-1 kernel silently
 // runs four blocks per CU (-3 ... -20 %, DESIGN_HISTORY.md 3.1e).  sobelStage belongs to the frame kernel only (four blocks per CU: 40 960 B each).
-static_assert(sizeof(powTab) + sizeof(leafBatch) + sizeof(wideStack) + sizeof(pruneUni) + sizeof(parkedState) <= (RTX_WAVES >= 5 ? 31744 : 40960),
+static_assert(sizeof(powTab) + sizeof(leafBatch) + sizeof(wideStack) + sizeof(pruneUni) + ParkLayout<false>::kFields * 1024 <= (RTX_WAVES >= 5 ? 31744 : 40960),
               "the ray kernels' LDS no longer fits the blocks per CU that RTX_WAVES asks for");
+static_assert(RTX_WAVES_PLAIN < 6 || sizeof(leafBatch) + sizeof(wideStack) + sizeof(pruneUni) + ParkLayout<true>::kFields * 1024 <= 27136,
+              "the PLAIN kernels' LDS no longer fits six blocks per CU (160 KB / 6, rounded down to the allocation granule)");
 
 // The kernel's argument block, read afresh from the kernarg segment.  Every ray kernel takes `const Params P` as its only
 // argument, so the segment starts with it.  The empty asm makes the pointer opaque: fields read through it are loaded where
@@ -2034,30 +2052,34 @@ __device__ __forceinline__ V3 castRayWave(const Params& P0, bool valid, V3 o, V3
 		const uint32_t qsrc = qshadow ? s.qsrc : ((CAM && s.sp == 0) ? 1u : 0u);
 		if (MESH) {
 			const uint32_t t = threadIdx.x;
+			float (*parkedState)[256] = parkArea<PLAIN>();
+			constexpr int kSp = ParkLayout<PLAIN>::kSp;
 			parkedState[0][t] = s.P.x; parkedState[1][t] = s.P.y; parkedState[2][t] = s.P.z;
 			parkedState[3][t] = s.N.x; parkedState[4][t] = s.N.y; parkedState[5][t] = s.N.z;
 			if (kParkColor) { parkedState[6][t] = s.objColor.x; parkedState[7][t] = s.objColor.y; parkedState[8][t] = s.objColor.z; }
 			parkedState[9 + kPk][t] = s.diff.x; parkedState[10 + kPk][t] = s.diff.y; parkedState[11 + kPk][t] = s.diff.z;
-			parkedState[12 + kPk][t] = s.spec.x; parkedState[13 + kPk][t] = s.spec.y; parkedState[14 + kPk][t] = s.spec.z;
-			parkedState[15 + kPk][t] = s.L.x; parkedState[16 + kPk][t] = s.L.y; parkedState[17 + kPk][t] = s.L.z;
-			parkedState[18 + kPk][t] = s.I.x; parkedState[19 + kPk][t] = s.I.y; parkedState[20 + kPk][t] = s.I.z;
-			parkedState[21 + kPk][t] = s.rd.x; parkedState[22 + kPk][t] = s.rd.y; parkedState[23 + kPk][t] = s.rd.z;
-			parkedState[24 + kPk][t] = s.specCoef;
+			if (!PLAIN) { parkedState[12 + kPk][t] = s.spec.x; parkedState[13 + kPk][t] = s.spec.y; parkedState[14 + kPk][t] = s.spec.z; }
+			parkedState[15 + kPk + kSp][t] = s.L.x; parkedState[16 + kPk + kSp][t] = s.L.y; parkedState[17 + kPk + kSp][t] = s.L.z;
+			parkedState[18 + kPk + kSp][t] = s.I.x; parkedState[19 + kPk + kSp][t] = s.I.y; parkedState[20 + kPk + kSp][t] = s.I.z;
+			parkedState[21 + kPk + kSp][t] = s.rd.x; parkedState[22 + kPk + kSp][t] = s.rd.y; parkedState[23 + kPk + kSp][t] = s.rd.z;
+			if (!PLAIN) parkedState[24 + kPk][t] = s.specCoef;
 			asm volatile("" ::: "memory");
 		}
 		traceWave<STATS, MESH, FEWRAYS, BOXES, CULLK>(freshParams(P0), qactive, qshadow, qo, qd, qtmax, h, cnt, qsrc);
 		if (MESH) {
 			asm volatile("" ::: "memory");
 			const uint32_t t = threadIdx.x;
+			float (*parkedState)[256] = parkArea<PLAIN>();
+			constexpr int kSp = ParkLayout<PLAIN>::kSp;
 			s.P = mk(parkedState[0][t], parkedState[1][t], parkedState[2][t]);
 			s.N = mk(parkedState[3][t], parkedState[4][t], parkedState[5][t]);
 			if (kParkColor) s.objColor = mk(parkedState[6][t], parkedState[7][t], parkedState[8][t]);
 			s.diff = mk(parkedState[9 + kPk][t], parkedState[10 + kPk][t], parkedState[11 + kPk][t]);
-			s.spec = mk(parkedState[12 + kPk][t], parkedState[13 + kPk][t], parkedState[14 + kPk][t]);
-			s.L = mk(parkedState[15 + kPk][t], parkedState[16 + kPk][t], parkedState[17 + kPk][t]);
-			s.I = mk(parkedState[18 + kPk][t], parkedState[19 + kPk][t], parkedState[20 + kPk][t]);
-			s.rd = mk(parkedState[21 + kPk][t], parkedState[22 + kPk][t], parkedState[23 + kPk][t]);
-			s.specCoef = parkedState[24 + kPk][t];
+			if (!PLAIN) s.spec = mk(parkedState[12 + kPk][t], parkedState[13 + kPk][t], parkedState[14 + kPk][t]);
+			s.L = mk(parkedState[15 + kPk + kSp][t], parkedState[16 + kPk + kSp][t], parkedState[17 + kPk + kSp][t]);
+			s.I = mk(parkedState[18 + kPk + kSp][t], parkedState[19 + kPk + kSp][t], parkedState[20 + kPk + kSp][t]);
+			s.rd = mk(parkedState[21 + kPk + kSp][t], parkedState[22 + kPk + kSp][t], parkedState[23 + kPk + kSp][t]);
+			if (!PLAIN) s.specCoef = parkedState[24 + kPk][t];
 		}
 		RTX_DBG_ONLY(const unsigned long long dbgT1 = __builtin_readcyclecounter();)
 		if (s.state != ST_DONE) {
@@ -2127,9 +2149,9 @@ __device__ __forceinline__ void flushCounts(const Params& P, const Counts& c)
 // BOXES = false: the variant for scenes whose meshes all have triangles too large for the box test of the prune records to prune
 // anything (rtxd::Object::pruneBoxes; cfg4): the same kernel without that test (the plane test stays).
 template <bool STATS, bool MESH = true, bool BOXES = true, int CULLK = (STATS || !MESH) ? -1 : 1, bool PLAIN = false>
-__global__ void __launch_bounds__(256, MESH ? RTX_WAVES : RTX_WAVES_ANALYTIC) rtxPass1Kernel(const Params P)
+__global__ void __launch_bounds__(256, MESH ? (PLAIN ? RTX_WAVES_PLAIN : RTX_WAVES) : RTX_WAVES_ANALYTIC) rtxPass1Kernel(const Params P)
 {
-	fillPowTab();
+	if (!PLAIN) fillPowTab();      // (Phong's powf: not reachable in a PLAIN kernel, whose LDS then does not hold the table)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
@@ -2265,7 +2287,7 @@ __device__ __forceinline__ uint32_t nthSetBit(uint64_t m, uint32_t n)   // posit
 template <bool STATS, bool MESH = true, bool BOXES = true, int CULLK = (STATS || !MESH) ? -1 : 1, bool PLAIN = false>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_SSAA : RTX_WAVES_ANALYTIC) rtxSsaaKernel(const Params P)
 {
-	fillPowTab();
+	if (!PLAIN) fillPowTab();      // (Phong's powf: not reachable in a PLAIN kernel, whose LDS then does not hold the table)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;
@@ -2888,7 +2910,7 @@ enum : uint32_t {
 template <bool MESH, bool BOXES = true, int CULLK = MESH ? 1 : -1, bool PLAIN = false>
 __global__ void __launch_bounds__(256, MESH ? RTX_WAVES_FRAME : RTX_WAVES_ANALYTIC) rtxFrameKernel(const Params P)
 {
-	fillPowTab();
+	if (!PLAIN) fillPowTab();      // (Phong's powf: not reachable in a PLAIN kernel, whose LDS then does not hold the table)
 	const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = __lane_id();
 	const uint32_t W = P.view.width, H = P.view.height;

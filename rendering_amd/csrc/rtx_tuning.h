@@ -13,6 +13,9 @@
 #ifndef RTX_WAVES
 #define RTX_WAVES 5             // waves per SIMD of the pass-1 kernel (512 / RTX_WAVES VGPRs): 6 = 80 VGPRs spills the round loop (+8 %), 4 loses 20 %
 #endif
+#ifndef RTX_WAVES_PLAIN
+#define RTX_WAVES_PLAIN 6       // waves per SIMD of the PLAIN pass-1 kernels: their LDS fits six blocks per CU; 80 VGPRs and 48 B of scratch, 3-4 % faster than 5 (89 VGPRs, no scratch at all)
+#endif
 #ifndef RTX_WAVES_SSAA
 #define RTX_WAVES_SSAA 4        // the SSAA launch lasts as long as its slowest wave: fewer, unspilled waves (128 VGPRs)
 #endif
