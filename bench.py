@@ -84,7 +84,23 @@ def reference_baseline(scene_path, width, height, gpu_scene, cores, ssaa=True, f
         torch.cuda.synchronize()
         got = fb.cpu().numpy()
         nd = int((got.view(np.uint32) != ref1.view(np.uint32)).any(-1).sum())
-        res["parity"] = {"pass1_equals_reference_full_frame": nd == 0, "pass1_pixels_differing": nd}
+        res["parity"] = {}
+        if nd != 0:
+            # The reference is not always equal to ITSELF: AreaLight::setPoints (lights.cpp:46-63) fills the light's sample points lazily, from whichever
+            # worker thread needs them first, while the others already read them -- with 256 workers the first pixels of some of their tiles come out NaN
+            # now and then.  So a differing pixel is looked at again in a second run of the reference: where its two runs disagree with each other, the
+            # product has to equal one of them; everywhere else, both.
+            out2 = subprocess.run([sys.executable, "-c", REF_CHILD % ROOT, scene_path, str(width), str(height), str(cores), dump + "b", "0", json.dumps(flags or {})],
+                                  cwd=ROOT, capture_output=True, text=True, timeout=900)
+            if out2.returncode == 0 and os.path.exists(dump + "b.pass1.npy"):
+                ref1b = np.load(dump + "b.pass1.npy")
+                a = (got.view(np.uint32) != ref1.view(np.uint32)).any(-1)
+                b = (got.view(np.uint32) != ref1b.view(np.uint32)).any(-1)
+                unstable = (ref1.view(np.uint32) != ref1b.view(np.uint32)).any(-1)
+                nd = int(((a | b) & ~unstable).sum() + (a & b & unstable).sum())
+                res["parity"]["reference_pixels_differing_between_its_own_two_runs"] = int(unstable.sum())
+                os.remove(dump + "b.pass1.npy")
+        res["parity"].update({"pass1_equals_reference_full_frame": nd == 0, "pass1_pixels_differing": nd})
         if ssaa and os.path.exists(dump + ".frame.npy"):
             ref2 = np.load(dump + ".frame.npy")
             mask = torch.zeros((height, width), dtype=torch.uint8, device="cuda")

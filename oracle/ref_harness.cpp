@@ -126,8 +126,17 @@ void ref_camera(void* h, float* scale, float* aspect, float* rMatrix16, float* p
 }
 
 // fb must be zero-initialised H*W*3 floats, like `new Vec3f[H*W]` (scene.cpp:599).
-void ref_pass1(void* h, float* fb) { ((Scene*)h)->launchWorkers((Vec3f*)fb); }
-void ref_ssaa(void* h, float* fb) { ((Scene*)h)->launchSSAA((Vec3f*)fb); }
+// The reference fills an area light's sample points lazily, from whichever worker thread shades with it first (scene.cpp:794 / 830 / 873 / 923 ->
+// AreaLight::setPoints, lights.cpp:46-63: `pointsCreated = true` BEFORE the vector is filled) while the other workers already read them: with the 256 workers
+// of a GPU box's host the first pixels of their tiles -- now and then tens of thousands of pixels -- come out wrong, differently in every run.  The harness
+// makes the same call before the workers start: the same points, no race.
+static void areaLightPointsFirst(Scene* s)
+{
+	for (auto& l : s->lights)
+		if (l->type == LightType::AreaLight) static_cast<AreaLight*>(l.get())->setPoints();
+}
+void ref_pass1(void* h, float* fb) { areaLightPointsFirst((Scene*)h); ((Scene*)h)->launchWorkers((Vec3f*)fb); }
+void ref_ssaa(void* h, float* fb) { areaLightPointsFirst((Scene*)h); ((Scene*)h)->launchSSAA((Vec3f*)fb); }
 
 void ref_stats_reset()
 {
