@@ -11,7 +11,7 @@
 #define RTX_WAVE_TRACE 0        // 1: three timestamps per pass-1 wave (first pop, end of the last tile, busy ticks) in a PRODUCT build: tools/wave_tail.py
 #endif
 #ifndef RTX_WAVES
-#define RTX_WAVES 5             // waves per SIMD of the pass-1 kernel (512 / RTX_WAVES VGPRs): 6 = 80 VGPRs spills the round loop (+8 %), 4 loses 20 %
+#define RTX_WAVES 5             // waves per SIMD of the general pass-1 kernels (512 / RTX_WAVES VGPRs; their 31.7 KB of LDS hold five blocks per CU): 4 loses 11-20 %; the PLAIN kernels: RTX_WAVES_PLAIN
 #endif
 #ifndef RTX_WAVES_PLAIN
 #define RTX_WAVES_PLAIN 6       // waves per SIMD of the PLAIN pass-1 kernels: their LDS fits six blocks per CU; 80 VGPRs and 48 B of scratch, 3-4 % faster than 5 (89 VGPRs, no scratch at all)
