@@ -36,15 +36,7 @@ else
     bash tools/profile.sh r06$c --config $c --steps 5 --warmup 1 > $O/profile_$c.log 2>&1
     cp $(find gpurun_out/prof_r06$c -name '*kernel_stats.csv' | head -1) $O/r06_kernel_stats_$c.csv
   done
-  : > $O/r06_configs.txt
-  for c in $WL; do
-    python -c "
-import json; d=json.loads(open('$O/r06_bench_$c.json').read()); c=d['config']; r=d['roofline']; b=d.get('cpu_baseline') or {}; p=b.get('parity') or {}
-print('$c', c['workload'], c.get('flags') or '', '|', d['value'], 'Mrays/s walked (', d['value_counted'], 'counted )', d['ms_per_step'], 'ms/frame |', c['frame'], '| pass1', c['pass1_ms'], 'sobel', c.get('sobel_ms'), 'ssaa', c['ssaa_ms'], 'frame kernel', c['frame_kernel_ms'], '| pipelined', c.get('pipelined_ms_per_frame'),
-      '| first frame of a new view', c.get('new_view_first_frame_ms'), 'cold scene', c.get('cold_frame_gpu_busy_before_ms'), '| rays', c['rays_per_frame'],
-      '| roofline', r.get('kernel'), 'frac', r.get('frac'), 'useful', r.get('useful_frac'), 'hbm_frac', r.get('hbm_frac'),
-      '| reference CPU', b.get('value'), 'Mrays/s on', b.get('cores'), 'cores; whole frame == reference: pass 1', p.get('pass1_equals_reference_full_frame'), 'frame', p.get('frame_equals_reference_full_frame'))" >> $O/r06_configs.txt
-  done
+  python tools/r06_configs_txt.py $O > $O/r06_configs.txt
   (python tools/shard_time.py 2 4 8; python tools/shard_time.py 2 4 8 --size 8192) 2>&1 | grep -v amdgpu > $O/r06_shard_emulation.txt
   python tools/new_view_probe.py 2>&1 | grep -v amdgpu > $O/r06_new_view_probe.txt
   python tools/bvh_build_time.py 2>&1 | grep -v amdgpu | tail -3 > $O/r06_bvh_build_time.txt
