@@ -47,3 +47,31 @@ def test_reference_scene_class_drives_the_gpu_meshes(ra, oracle, tmp_path, scene
         # (row 0 / column 0 of the reference's SSAA are its uninitialised mask border, SURVEY 0.7: defined as "not re-rendered" here and in the oracle alike)
         a = np.frombuffer(bmp, np.uint8)[54:].reshape(h, w, 3); b = np.frombuffer(want, np.uint8)[54:].reshape(h, w, 3)
         raise AssertionError("%d pixels of the binding's BMP differ from the oracle's" % int((a != b).any(-1).sum()))
+
+
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "libref_harness.so")
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/libref_harness.so not built (needs /root/reference at build time)")
+def test_area_light_frame_equals_the_reference_on_every_host_core(ra, tmp_path):
+    """The reference itself (oracle/_ref/libref_harness.so: its own translation units), pass 1 of the area-light scene at 1920x1080 with one worker per host core,
+    three times, against the GPU's pass 1, whole frame, bit for bit.  With 256 workers the reference used to differ from ITSELF here -- AreaLight::setPoints
+    (lights.cpp:46-63) is filled lazily by racing workers; the harness makes the call before they start (oracle/ref_harness.cpp).  Nothing here reads /root/reference."""
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    w, h = 1920, 1080
+    g = ra.Scene("scenes/area_light.scene", w, h)
+    fb = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    g.render_pass1(fb)
+    torch.cuda.synchronize()
+    got = fb.cpu().numpy().view(np.uint32)
+    for k in range(3):
+        dump = str(tmp_path / ("ref%d" % k))
+        out = subprocess.run([sys.executable, "-c", bench.REF_CHILD % ROOT, "scenes/area_light.scene", str(w), str(h), str(os.cpu_count()), dump, "0", "{}"],
+                             cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-1000:]
+        ref = np.load(dump + ".pass1.npy").view(np.uint32)
+        nd = int((got != ref).any(-1).sum())
+        assert nd == 0, "run %d of the reference (%d workers): %d pixels differ from the GPU's pass 1" % (k, os.cpu_count(), nd)

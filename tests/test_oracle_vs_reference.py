@@ -114,3 +114,27 @@ def test_oracle_bit_identical_to_reference_on_edge_scenes(tmp_path, name):
     path.write_text(_fuzz_module().EDGE_SCENES[name])
     out = subprocess.run([sys.executable, "-c", FUZZ_CHILD % ROOT, str(path), "-1", "-1"], cwd=ROOT, capture_output=True, text=True)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+RACE_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from tools import ref_harness as R
+b = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+w, h = 640, 480
+one = b(R.RefScene('scenes/area_light.scene', w, h, workers=1).pass1()).copy()
+assert not np.isnan(one.view(np.float32)).any()
+for workers in (16, 64, 256):
+    many = b(R.RefScene('scenes/area_light.scene', w, h, workers=workers).pass1())
+    assert np.array_equal(one, many), ('workers', workers, int((one != many).any(-1).sum()))
+print('OK')
+"""
+
+
+def test_reference_area_light_frame_does_not_depend_on_the_number_of_workers():
+    """AreaLight::setPoints (lights.cpp:46-63) is filled lazily by whichever worker shades with the light first while the others already read it: with the 256
+    workers of a GPU box's host between 2 and 35 000 pixels of the reference's own frame came out wrong, differently in every run (found by bench.py's whole-frame
+    comparison in round 6).  The harness makes the call before the workers start (oracle/ref_harness.cpp); every scene load here is a fresh light, so every
+    render is a first use."""
+    out = subprocess.run([sys.executable, "-c", RACE_CHILD % ROOT], cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
